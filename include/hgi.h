@@ -1,0 +1,129 @@
+/*
+ * hgi.h -- C ABI of the MI355X-native HGI encode/decode core (libhgi_hip.so).
+ *
+ * This is the drop-in boundary for the hot path of pl0q1n/RustyHGI: the
+ * per-level grid interpolation + residual quantize loop.  The reference has no
+ * FFI today; each entry point below names the reference interface it replaces
+ * (paths relative to the reference repository).  INTEGRATION.md shows the
+ * `extern "C"` block a maintainer adds on the Rust side.
+ *
+ * Conventions
+ *  - plain pointers and sizes, no C++/torch types; never throws or aborts
+ *    across the ABI: every call returns hgi_status, hgi_last_error() holds the
+ *    thread-local message of the last failure;
+ *  - images and grids are tightly packed row-major u8, stride == width
+ *    (reference: GrayImage / Grid, src/grid.rs:2-27); a batch is `batch`
+ *    frames `frame_stride` bytes apart;
+ *  - there is NO CPU fallback in this library: without a usable HIP device
+ *    hgi_ctx_create fails with HGI_EDEVICE;
+ *  - a ctx is not thread-safe; distinct ctxs are independent;
+ *  - encode never modifies its input (the reference consumes it by value,
+ *    src/encoder.rs:39);
+ *  - `levels` in 0..=31 (1 << e on u32, src/utils.rs:17); levels == 0 makes
+ *    grid == image; width or height == 0 is a successful no-op.
+ */
+#ifndef HGI_H_
+#define HGI_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct hgi_ctx hgi_ctx;
+
+/* src/interpolator.rs:15 (LeftTop), :30 (Crossed) -- the two implemented predictors */
+typedef enum { HGI_INTERP_LEFTTOP = 0, HGI_INTERP_CROSSED = 1 } hgi_interp;
+
+/* src/quantizator.rs:3-8 QuantizationLevel (bincode variant index) */
+typedef enum {
+    HGI_QUANT_LOSSLESS = 0,
+    HGI_QUANT_LOW = 1,
+    HGI_QUANT_MEDIUM = 2,
+    HGI_QUANT_HIGH = 3
+} hgi_quant_level;
+
+typedef enum {
+    HGI_OK = 0,
+    HGI_EINVAL = 1,
+    HGI_ENOMEM = 2,
+    HGI_EDEVICE = 3,
+    HGI_EUNSUPPORTED = 4
+} hgi_status;
+
+/* Which device implementation serves encode/decode (testing / benchmarking knob).   */
+/* AUTO = FUSED.  Both run on the GPU; neither is a CPU path.                       */
+typedef enum {
+    HGI_PATH_AUTO = 0,
+    HGI_PATH_LEVELWISE = 1, /* one launch per level, global-memory stencil            */
+    HGI_PATH_FUSED = 2      /* all levels of a tile in one launch, LDS-resident       */
+} hgi_path;
+
+/* synthetic inputs of the harness; XY is benches/bench.rs:26-28 */
+typedef enum { HGI_SYNTH_XY = 0, HGI_SYNTH_NOISE = 1, HGI_SYNTH_RAMP = 2 } hgi_synth_kind;
+
+/* ---- context ---------------------------------------------------------------------- */
+/* Owns the device id, a stream and scratch memory.  device >= 0 is a HIP ordinal.     */
+hgi_status hgi_ctx_create(int device, hgi_ctx **out);
+void hgi_ctx_destroy(hgi_ctx *ctx);
+/* Borrow the caller's hipStream_t, used verbatim: NULL is HIP's default (null) stream,   */
+/* which is what torch.cuda.current_stream() is unless a side stream is active.           */
+hgi_status hgi_ctx_set_stream(hgi_ctx *ctx, void *hip_stream);
+/* Return to the ctx's private non-blocking stream (the state after hgi_ctx_create).      */
+hgi_status hgi_ctx_use_own_stream(hgi_ctx *ctx);
+hgi_status hgi_ctx_set_path(hgi_ctx *ctx, hgi_path path);
+/* Pre-size scratch so later *_dev calls allocate nothing (needed before graph capture). */
+hgi_status hgi_ctx_reserve(hgi_ctx *ctx, uint32_t width, uint32_t height, uint32_t levels,
+                           size_t batch);
+hgi_status hgi_sync(hgi_ctx *ctx);
+const char *hgi_last_error(void);
+const char *hgi_version(void);
+
+/* ---- quantizers (host side: any Quantizator is tabulated into 256 bytes) ----------- */
+/* replaces Linear::from(QuantizationLevel) + Linear::error, src/quantizator.rs:41-63,71 */
+hgi_status hgi_linear_lut(int level, uint8_t lut[256], uint8_t *max_err);
+/* replaces NoOp::quantize, src/quantizator.rs:26-29 */
+void hgi_noop_lut(uint8_t lut[256]);
+
+/* ---- host-pointer, synchronous ------------------------------------------------------ */
+/* replaces Encoder::<I,Q>::new(..).encode(image) -> Grid, src/encoder.rs:18,39          */
+hgi_status hgi_encode_u8(hgi_ctx *ctx, const uint8_t *img, uint32_t width, uint32_t height,
+                         uint32_t levels, hgi_interp interp, const uint8_t lut[256],
+                         uint8_t *grid_out);
+/* replaces Decoder::<I>::new(..).decode((w,h), levels, &grid) -> GrayImage, src/decoder.rs:14,18 */
+hgi_status hgi_decode_u8(hgi_ctx *ctx, const uint8_t *grid, uint32_t width, uint32_t height,
+                         uint32_t levels, hgi_interp interp, uint8_t *img_out);
+
+/* ---- device-pointer, asynchronous on the ctx stream, batched -------------------------- */
+/* Same semantics per frame; `lut` is a HOST pointer (256 bytes, copied into the launch).   */
+/* frame_stride >= width*height; d_img / d_grid must not alias.                            */
+hgi_status hgi_encode_u8_dev(hgi_ctx *ctx, const void *d_img, uint32_t width, uint32_t height,
+                             uint32_t levels, hgi_interp interp, const uint8_t lut[256],
+                             void *d_grid, size_t batch, size_t frame_stride);
+hgi_status hgi_decode_u8_dev(hgi_ctx *ctx, const void *d_grid, uint32_t width, uint32_t height,
+                             uint32_t levels, hgi_interp interp, void *d_img, size_t batch,
+                             size_t frame_stride);
+
+/* ---- harness helpers (not part of the reference surface) ------------------------------ */
+/* Fill `batch` frames with a synthetic pattern; frame f uses index first_frame + f.        */
+hgi_status hgi_synth_u8_dev(hgi_ctx *ctx, hgi_synth_kind kind, uint64_t seed,
+                            uint64_t first_frame, uint32_t width, uint32_t height, void *d_out,
+                            size_t batch, size_t frame_stride);
+/* Streaming copy of n bytes (16-B vectors): the same-run HBM copy ceiling.                 */
+hgi_status hgi_copy_u8_dev(hgi_ctx *ctx, const void *d_src, void *d_dst, size_t n);
+/* Per-frame statistics of before/after pairs as `hgi test` prints them (src/main.rs:84-92): */
+/* out[3*f+0] = sum of squared differences, +1 = max abs difference, +2 = count of differing */
+/* pixels.  d_out is device memory for 3*batch uint64.                                       */
+hgi_status hgi_diff_stats_dev(hgi_ctx *ctx, const void *d_before, const void *d_after,
+                              uint32_t width, uint32_t height, size_t batch, size_t frame_stride,
+                              void *d_out);
+/* hipEvent pair on the ctx stream: start, ...launches..., stop -> elapsed milliseconds.     */
+hgi_status hgi_timer_start(hgi_ctx *ctx);
+hgi_status hgi_timer_stop(hgi_ctx *ctx, float *elapsed_ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HGI_H_ */

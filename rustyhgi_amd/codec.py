@@ -1,0 +1,125 @@
+"""Mirror of `hgi::{Encoder, Decoder}` (reference src/encoder.rs, src/decoder.rs) over the C ABI.
+
+numpy arrays take the host-pointer entry points (hgi_encode_u8 / hgi_decode_u8); torch CUDA
+tensors take the device-pointer, asynchronous, batched entry points on torch's current stream.
+Every path ends in the HIP kernels; there is no host implementation.
+"""
+import ctypes
+
+import numpy as np
+
+from . import _ffi
+from .grid import Grid
+from .interpolator import Interpolator
+from .quantizator import Quantizator
+
+
+def _is_torch(x):
+    return type(x).__module__.startswith("torch")
+
+
+def _interp_id(interpolator):
+    kid = getattr(interpolator, "kernel_id", None)
+    if kid is None:
+        raise _ffi.HgiError(_ffi.EUNSUPPORTED,
+                            "interpolator %r has no device predictor" % type(interpolator).__name__)
+    return int(kid)
+
+
+def _torch_ctx(t, ctx=None):
+    """The context serving tensor `t`, bound to torch's current stream on t's device so that the
+    launches are ordered with the torch ops around them."""
+    import torch
+    if not t.is_cuda:
+        raise ValueError("torch tensors must live on the GPU (use numpy for host buffers)")
+    if t.dtype != torch.uint8 or not t.is_contiguous():
+        raise ValueError("expected a contiguous uint8 tensor")
+    dev = t.device.index if t.device.index is not None else torch.cuda.current_device()
+    if ctx is None:
+        ctx = _ffi.default_context(dev)
+    elif ctx.device != dev:
+        raise ValueError("tensor lives on cuda:%d but the context was created for cuda:%d" % (dev, ctx.device))
+    ctx.set_stream(torch.cuda.current_stream(dev).cuda_stream)
+    return ctx
+
+
+def _np_image(a):
+    a = np.ascontiguousarray(a, dtype=np.uint8)
+    if a.ndim != 2:
+        raise ValueError("expected a (height, width) uint8 image")
+    return a
+
+
+class Encoder:
+    """`Encoder::new(interpolator, quantizator, scale_level)` -- src/encoder.rs:18."""
+
+    def __init__(self, interpolator, quantizator, scale_level, context=None):
+        if not isinstance(interpolator, Interpolator) or not isinstance(quantizator, Quantizator):
+            raise TypeError("Encoder(interpolator: Interpolator, quantizator: Quantizator, scale_level)")
+        self.interpolator, self.quantizator = interpolator, quantizator
+        self._interp = _interp_id(interpolator)
+        self.scale_level = int(scale_level)
+        self._lut = np.ascontiguousarray(quantizator.table(), dtype=np.uint8)
+        self._ctx = context
+
+    def encode(self, image):
+        """`encode(GrayImage) -> Grid` -- src/encoder.rs:39.  The input is not modified."""
+        if _is_torch(image):
+            if image.dim() != 2:
+                raise ValueError("expected a (height, width) image; use encode_batch for stacks")
+            out = self.encode_batch(image.unsqueeze(0))
+            return Grid(out[0], image.shape[1])
+        img = _np_image(image)
+        h, w = img.shape
+        grid = np.empty_like(img)
+        ctx = self._ctx or _ffi.default_context(0)
+        _ffi.check(_ffi.lib().hgi_encode_u8(ctx.handle, img.ctypes.data, w, h, self.scale_level,
+                                            self._interp, self._lut.ctypes.data,
+                                            grid.ctypes.data))
+        return Grid(grid, w)
+
+    def encode_batch(self, images, out=None):
+        """(B, H, W) uint8 CUDA tensor -> (B, H, W) residual planes, asynchronous on the current stream."""
+        import torch
+        ctx = _torch_ctx(images, self._ctx)
+        b, h, w = images.shape
+        if out is None:
+            out = torch.empty_like(images)
+        _ffi.check(_ffi.lib().hgi_encode_u8_dev(ctx.handle, images.data_ptr(), w, h, self.scale_level,
+                                                self._interp, self._lut.ctypes.data,
+                                                out.data_ptr(), b, h * w))
+        return out
+
+
+class Decoder:
+    """`Decoder::new(interpolator)` -- src/decoder.rs:14."""
+
+    def __init__(self, interpolator, context=None):
+        if not isinstance(interpolator, Interpolator):
+            raise TypeError("Decoder(interpolator: Interpolator)")
+        self.interpolator = interpolator
+        self._interp = _interp_id(interpolator)
+        self._ctx = context
+
+    def decode(self, dimensions, levels, grid):
+        """`decode((width, height), levels, &Grid) -> GrayImage` -- src/decoder.rs:18."""
+        width, height = int(dimensions[0]), int(dimensions[1])
+        buf = grid.buffer if isinstance(grid, Grid) else grid
+        if _is_torch(buf):
+            return self.decode_batch(buf.reshape(1, height, width), levels)[0]
+        g = np.ascontiguousarray(buf, dtype=np.uint8).reshape(height, width)
+        img = np.empty_like(g)
+        ctx = self._ctx or _ffi.default_context(0)
+        _ffi.check(_ffi.lib().hgi_decode_u8(ctx.handle, g.ctypes.data, width, height, int(levels),
+                                            self._interp, img.ctypes.data))
+        return img
+
+    def decode_batch(self, grids, levels, out=None):
+        import torch
+        ctx = _torch_ctx(grids, self._ctx)
+        b, h, w = grids.shape
+        if out is None:
+            out = torch.empty_like(grids)
+        _ffi.check(_ffi.lib().hgi_decode_u8_dev(ctx.handle, grids.data_ptr(), w, h, int(levels),
+                                                self._interp, out.data_ptr(), b, h * w))
+        return out

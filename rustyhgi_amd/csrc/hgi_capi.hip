@@ -1,0 +1,439 @@
+// C ABI of libhgi_hip.so (include/hgi.h): argument checking, scratch management, level scheduling.
+// No CPU implementation lives here: every encode/decode goes to the gfx950 kernels or fails.
+#include <hip/hip_runtime.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "../../include/hgi.h"
+#include "hgi_kernels.h"
+
+using namespace hgi;
+
+namespace {
+
+thread_local char g_err[512] = "";
+
+hgi_status fail(hgi_status st, const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return st;
+}
+
+#define HIP_TRY(expr)                                                                       \
+    do {                                                                                    \
+        hipError_t e_ = (expr);                                                             \
+        if (e_ != hipSuccess)                                                               \
+            return fail(e_ == hipErrorOutOfMemory ? HGI_ENOMEM : HGI_EDEVICE, "%s: %s", #expr, \
+                        hipGetErrorString(e_));                                             \
+    } while (0)
+
+#define HGI_TRY(expr)                  \
+    do {                               \
+        hgi_status s_ = (expr);        \
+        if (s_ != HGI_OK) return s_;   \
+    } while (0)
+
+inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+}  // namespace
+
+struct hgi_ctx {
+    int device;
+    hipStream_t own_stream, stream;
+    hgi_path path;
+    uint8_t *ws;
+    size_t ws_bytes, ws_used;
+    hipEvent_t ev0, ev1;
+};
+
+namespace {
+
+// Scratch is a bump allocator over one device buffer; it only grows between calls.
+hgi_status ws_ensure(hgi_ctx *c, size_t bytes)
+{
+    if (bytes <= c->ws_bytes) return HGI_OK;
+    // growing means freeing memory that queued work may still use
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (c->ws) HIP_TRY(hipFree(c->ws));
+    c->ws = nullptr;
+    c->ws_bytes = 0;
+    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&c->ws), bytes));
+    c->ws_bytes = bytes;
+    return HGI_OK;
+}
+
+uint8_t *ws_take(hgi_ctx *c, size_t bytes)
+{
+    size_t off = align_up(c->ws_used, 256);
+    if (off + bytes > c->ws_bytes) return nullptr;
+    c->ws_used = off + bytes;
+    return c->ws + off;
+}
+
+struct SubGeom {
+    uint32_t sw, sh;
+    uint64_t stride;
+};
+
+SubGeom sub_geom(uint32_t w, uint32_t h, uint32_t k)
+{
+    SubGeom g;
+    g.sw = (uint32_t)((((uint64_t)w - 1) >> k) + 1);
+    g.sh = (uint32_t)((((uint64_t)h - 1) >> k) + 1);
+    g.stride = align_up((size_t)g.sw * g.sh, 256);
+    return g;
+}
+
+// Scratch bytes one encode (or decode) of this shape takes, recursion included.
+size_t ws_need(const hgi_ctx *c, uint32_t w, uint32_t h, uint32_t levels, size_t batch, size_t stride)
+{
+    if (levels == 0) return 0;
+    if (c->path == HGI_PATH_LEVELWISE) return align_up(batch * stride, 256) + 256;
+    size_t need = 0;
+    while (levels > (uint32_t)kFusedMaxLevels) {
+        SubGeom g = sub_geom(w, h, kFusedMaxLevels);
+        need += 3 * (align_up(batch * g.stride, 256) + 256);
+        w = g.sw;
+        h = g.sh;
+        levels -= kFusedMaxLevels;
+    }
+    return need;
+}
+
+Lut256 pack_lut(const uint8_t lut[256])
+{
+    Lut256 l;
+    memcpy(l.w, lut, 256);
+    return l;
+}
+
+bool is_identity(const uint8_t lut[256])
+{
+    for (int i = 0; i < 256; ++i)
+        if (lut[i] != i) return false;
+    return true;
+}
+
+hgi_status decode_impl(hgi_ctx *c, const uint8_t *grid, uint32_t w, uint32_t h, uint32_t levels, int interp,
+                       uint8_t *img, size_t batch, size_t stride);
+
+hgi_status encode_impl(hgi_ctx *c, const uint8_t *img, uint32_t w, uint32_t h, uint32_t levels, int interp,
+                       const uint8_t lut[256], uint8_t *grid, size_t batch, size_t stride)
+{
+    Frames f = {w, h, (uint64_t)stride, (uint32_t)batch};
+    if (levels == 0) {   // src/encoder.rs:28-36 with step 1: the grid is the image
+        for (size_t b = 0; b < batch; ++b)
+            HIP_TRY(launch_copy(img + b * stride, grid + b * stride, (size_t)w * h, c->stream));
+        return HGI_OK;
+    }
+    Lut256 l = pack_lut(lut);
+    if (c->path == HGI_PATH_LEVELWISE) {
+        uint8_t *rec = ws_take(c, batch * stride);
+        if (!rec) return fail(HGI_ENOMEM, "scratch exhausted (level-wise reconstruction plane)");
+        HIP_TRY(launch_copy(img, rec, batch * stride, c->stream));
+        HIP_TRY(launch_seed(img, grid, f, levels, c->stream));
+        for (uint32_t level = 0; level < levels; ++level)   // src/encoder.rs:45, sequential
+            HIP_TRY(launch_encode_level(rec, grid, f, levels - level - 1, interp, l, c->stream));
+        return HGI_OK;
+    }
+    const uint32_t k = levels < (uint32_t)kFusedMaxLevels ? levels : (uint32_t)kFusedMaxLevels;
+    if (levels > k) {
+        // Deeper pyramid: the lattice = 0 (mod 2^k) is itself an HGI image with levels-k levels
+        // (same OOB rule: x < W <=> x >> k < ceil(W / 2^k) on the lattice).  Code it first, then
+        // hand its reconstruction and residuals to the tile kernel as seeds.
+        SubGeom g = sub_geom(w, h, k);
+        uint8_t *sub_img = ws_take(c, batch * g.stride);
+        uint8_t *sub_grid = ws_take(c, batch * g.stride);
+        uint8_t *sub_rec = ws_take(c, batch * g.stride);
+        if (!sub_img || !sub_grid || !sub_rec) return fail(HGI_ENOMEM, "scratch exhausted (lattice planes)");
+        HIP_TRY(launch_gather_lattice(img, f, k, sub_img, g.sw, g.sh, g.stride, c->stream));
+        HGI_TRY(encode_impl(c, sub_img, g.sw, g.sh, levels - k, interp, lut, sub_grid, batch, g.stride));
+        HGI_TRY(decode_impl(c, sub_grid, g.sw, g.sh, levels - k, interp, sub_rec, batch, g.stride));
+        Seeds sd = {sub_rec, sub_grid, g.sw, g.sh, g.stride};
+        HIP_TRY(launch_encode_fused(img, grid, f, k, interp, l, is_identity(lut), &sd, c->stream));
+    } else {
+        HIP_TRY(launch_encode_fused(img, grid, f, k, interp, l, is_identity(lut), nullptr, c->stream));
+    }
+    return HGI_OK;
+}
+
+hgi_status decode_impl(hgi_ctx *c, const uint8_t *grid, uint32_t w, uint32_t h, uint32_t levels, int interp,
+                       uint8_t *img, size_t batch, size_t stride)
+{
+    Frames f = {w, h, (uint64_t)stride, (uint32_t)batch};
+    if (levels == 0) {
+        for (size_t b = 0; b < batch; ++b)
+            HIP_TRY(launch_copy(grid + b * stride, img + b * stride, (size_t)w * h, c->stream));
+        return HGI_OK;
+    }
+    if (c->path == HGI_PATH_LEVELWISE) {
+        HIP_TRY(launch_seed(grid, img, f, levels, c->stream));   // src/decoder.rs:22-28
+        for (uint32_t level = 0; level < levels; ++level)        // src/decoder.rs:30
+            HIP_TRY(launch_decode_level(grid, img, f, levels - level - 1, interp, c->stream));
+        return HGI_OK;
+    }
+    const uint32_t k = levels < (uint32_t)kFusedMaxLevels ? levels : (uint32_t)kFusedMaxLevels;
+    if (levels > k) {
+        SubGeom g = sub_geom(w, h, k);
+        uint8_t *sub_grid = ws_take(c, batch * g.stride);
+        uint8_t *sub_rec = ws_take(c, batch * g.stride);
+        if (!sub_grid || !sub_rec) return fail(HGI_ENOMEM, "scratch exhausted (lattice planes)");
+        HIP_TRY(launch_gather_lattice(grid, f, k, sub_grid, g.sw, g.sh, g.stride, c->stream));
+        HGI_TRY(decode_impl(c, sub_grid, g.sw, g.sh, levels - k, interp, sub_rec, batch, g.stride));
+        Seeds sd = {sub_rec, nullptr, g.sw, g.sh, g.stride};
+        HIP_TRY(launch_decode_fused(grid, img, f, k, interp, &sd, c->stream));
+    } else {
+        HIP_TRY(launch_decode_fused(grid, img, f, k, interp, nullptr, c->stream));
+    }
+    return HGI_OK;
+}
+
+hgi_status check_common(hgi_ctx *c, const void *a, const void *b, uint32_t levels, int interp, size_t batch,
+                        size_t stride, uint32_t w, uint32_t h)
+{
+    if (!c) return fail(HGI_EINVAL, "ctx is NULL");
+    if (levels > 31) return fail(HGI_EINVAL, "levels %u out of range 0..=31", levels);
+    if (interp != HGI_INTERP_LEFTTOP && interp != HGI_INTERP_CROSSED)
+        return fail(HGI_EUNSUPPORTED, "interpolator %d not implemented (0 = LeftTop, 1 = Crossed)", interp);
+    if (w == 0 || h == 0 || batch == 0) return HGI_OK;
+    if (!a || !b) return fail(HGI_EINVAL, "NULL buffer");
+    if (a == b) return fail(HGI_EINVAL, "input and output must not alias");
+    if (batch > 1 && stride < (size_t)w * h) return fail(HGI_EINVAL, "frame_stride %zu < width*height", stride);
+    if (batch > 0x7fffffffu) return fail(HGI_EINVAL, "batch too large");
+    return HGI_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char *hgi_last_error(void) { return g_err; }
+const char *hgi_version(void) { return "hgi-hip 0.1.0 (gfx950)"; }
+
+hgi_status hgi_ctx_create(int device, hgi_ctx **out)
+{
+    if (!out) return fail(HGI_EINVAL, "out is NULL");
+    *out = nullptr;
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0)
+        return fail(HGI_EDEVICE, "no usable HIP device (%s); this library has no CPU path",
+                    e != hipSuccess ? hipGetErrorString(e) : "device count is 0");
+    if (device < 0 || device >= n) return fail(HGI_EDEVICE, "device %d not in 0..%d", device, n - 1);
+    HIP_TRY(hipSetDevice(device));
+    hgi_ctx *c = new (std::nothrow) hgi_ctx();
+    if (!c) return fail(HGI_ENOMEM, "host allocation failed");
+    c->device = device;
+    c->path = HGI_PATH_FUSED;
+    c->ws = nullptr;
+    c->ws_bytes = c->ws_used = 0;
+    if (hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess) {
+        delete c;
+        return fail(HGI_EDEVICE, "stream/event creation failed");
+    }
+    c->stream = c->own_stream;
+    *out = c;
+    return HGI_OK;
+}
+
+void hgi_ctx_destroy(hgi_ctx *c)
+{
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    if (c->ws) (void)hipFree(c->ws);
+    (void)hipEventDestroy(c->ev0);
+    (void)hipEventDestroy(c->ev1);
+    (void)hipStreamDestroy(c->own_stream);
+    delete c;
+}
+
+hgi_status hgi_ctx_set_stream(hgi_ctx *c, void *hip_stream)
+{
+    if (!c) return fail(HGI_EINVAL, "ctx is NULL");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipStreamSynchronize(c->stream));   // scratch hand-over between streams
+    c->stream = static_cast<hipStream_t>(hip_stream);
+    return HGI_OK;
+}
+
+hgi_status hgi_ctx_use_own_stream(hgi_ctx *c)
+{
+    if (!c) return fail(HGI_EINVAL, "ctx is NULL");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    c->stream = c->own_stream;
+    return HGI_OK;
+}
+
+hgi_status hgi_ctx_set_path(hgi_ctx *c, hgi_path path)
+{
+    if (!c) return fail(HGI_EINVAL, "ctx is NULL");
+    if (path != HGI_PATH_AUTO && path != HGI_PATH_LEVELWISE && path != HGI_PATH_FUSED)
+        return fail(HGI_EINVAL, "unknown path %d", (int)path);
+    c->path = path == HGI_PATH_AUTO ? HGI_PATH_FUSED : path;
+    return HGI_OK;
+}
+
+hgi_status hgi_ctx_reserve(hgi_ctx *c, uint32_t w, uint32_t h, uint32_t levels, size_t batch)
+{
+    if (!c) return fail(HGI_EINVAL, "ctx is NULL");
+    if (levels > 31) return fail(HGI_EINVAL, "levels %u out of range 0..=31", levels);
+    HIP_TRY(hipSetDevice(c->device));
+    size_t stride = (size_t)w * h;
+    size_t need = ws_need(c, w, h, levels, batch, stride);
+    size_t host = 2 * (align_up(stride, 256) + 256);   // staging of the host-pointer entry points
+    return ws_ensure(c, need + host);
+}
+
+hgi_status hgi_sync(hgi_ctx *c)
+{
+    if (!c) return fail(HGI_EINVAL, "ctx is NULL");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return HGI_OK;
+}
+
+// src/quantizator.rs:41-63
+hgi_status hgi_linear_lut(int level, uint8_t lut[256], uint8_t *max_err)
+{
+    static const uint8_t errs[4] = {0, 10, 20, 30};
+    if (!lut) return fail(HGI_EINVAL, "lut is NULL");
+    if (level < 0 || level > 3) return fail(HGI_EINVAL, "quantization level %d not in 0..3", level);
+    const unsigned error = errs[level], scale = 2 * error + 1;
+    for (unsigned i = 0; i < 256; ++i) lut[i] = (uint8_t)(((i + error) / scale) * scale);
+    if (max_err) *max_err = (uint8_t)error;
+    return HGI_OK;
+}
+
+// src/quantizator.rs:26-29
+void hgi_noop_lut(uint8_t lut[256])
+{
+    if (lut)
+        for (unsigned i = 0; i < 256; ++i) lut[i] = (uint8_t)i;
+}
+
+hgi_status hgi_encode_u8_dev(hgi_ctx *c, const void *d_img, uint32_t w, uint32_t h, uint32_t levels,
+                             hgi_interp interp, const uint8_t lut[256], void *d_grid, size_t batch,
+                             size_t frame_stride)
+{
+    HGI_TRY(check_common(c, d_img, d_grid, levels, interp, batch, frame_stride, w, h));
+    if (!lut) return fail(HGI_EINVAL, "lut is NULL");
+    if (w == 0 || h == 0 || batch == 0) return HGI_OK;
+    if (batch == 1 && frame_stride < (size_t)w * h) frame_stride = (size_t)w * h;
+    HIP_TRY(hipSetDevice(c->device));
+    HGI_TRY(ws_ensure(c, ws_need(c, w, h, levels, batch, frame_stride)));
+    c->ws_used = 0;
+    return encode_impl(c, static_cast<const uint8_t *>(d_img), w, h, levels, interp, lut,
+                       static_cast<uint8_t *>(d_grid), batch, frame_stride);
+}
+
+hgi_status hgi_decode_u8_dev(hgi_ctx *c, const void *d_grid, uint32_t w, uint32_t h, uint32_t levels,
+                             hgi_interp interp, void *d_img, size_t batch, size_t frame_stride)
+{
+    HGI_TRY(check_common(c, d_grid, d_img, levels, interp, batch, frame_stride, w, h));
+    if (w == 0 || h == 0 || batch == 0) return HGI_OK;
+    if (batch == 1 && frame_stride < (size_t)w * h) frame_stride = (size_t)w * h;
+    HIP_TRY(hipSetDevice(c->device));
+    HGI_TRY(ws_ensure(c, ws_need(c, w, h, levels, batch, frame_stride)));
+    c->ws_used = 0;
+    return decode_impl(c, static_cast<const uint8_t *>(d_grid), w, h, levels, interp,
+                       static_cast<uint8_t *>(d_img), batch, frame_stride);
+}
+
+// Host-pointer forms: stage through device scratch (PCIe-bound; never the number that is benchmarked).
+static hgi_status host_roundtrip(hgi_ctx *c, const uint8_t *in, uint8_t *out, uint32_t w, uint32_t h,
+                                 uint32_t levels, hgi_interp interp, const uint8_t *lut, bool encode)
+{
+    HGI_TRY(check_common(c, in, out, levels, interp, 1, (size_t)w * h, w, h));
+    if (encode && !lut) return fail(HGI_EINVAL, "lut is NULL");
+    if (w == 0 || h == 0) return HGI_OK;
+    HIP_TRY(hipSetDevice(c->device));
+    const size_t n = (size_t)w * h, slot = align_up(n, 256) + 256;
+    HGI_TRY(ws_ensure(c, ws_need(c, w, h, levels, 1, n) + 2 * slot));
+    c->ws_used = 0;
+    uint8_t *d_in = ws_take(c, n), *d_out = ws_take(c, n);
+    if (!d_in || !d_out) return fail(HGI_ENOMEM, "scratch exhausted (host staging)");
+    HIP_TRY(hipMemcpyAsync(d_in, in, n, hipMemcpyHostToDevice, c->stream));
+    if (encode)
+        HGI_TRY(encode_impl(c, d_in, w, h, levels, interp, lut, d_out, 1, n));
+    else
+        HGI_TRY(decode_impl(c, d_in, w, h, levels, interp, d_out, 1, n));
+    HIP_TRY(hipMemcpyAsync(out, d_out, n, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return HGI_OK;
+}
+
+hgi_status hgi_encode_u8(hgi_ctx *c, const uint8_t *img, uint32_t w, uint32_t h, uint32_t levels,
+                         hgi_interp interp, const uint8_t lut[256], uint8_t *grid_out)
+{
+    return host_roundtrip(c, img, grid_out, w, h, levels, interp, lut, true);
+}
+
+hgi_status hgi_decode_u8(hgi_ctx *c, const uint8_t *grid, uint32_t w, uint32_t h, uint32_t levels,
+                         hgi_interp interp, uint8_t *img_out)
+{
+    return host_roundtrip(c, grid, img_out, w, h, levels, interp, nullptr, false);
+}
+
+hgi_status hgi_synth_u8_dev(hgi_ctx *c, hgi_synth_kind kind, uint64_t seed, uint64_t first_frame, uint32_t w,
+                            uint32_t h, void *d_out, size_t batch, size_t frame_stride)
+{
+    if (!c) return fail(HGI_EINVAL, "ctx is NULL");
+    if ((int)kind < 0 || (int)kind > 2) return fail(HGI_EINVAL, "unknown synthetic kind %d", (int)kind);
+    if (w == 0 || h == 0 || batch == 0) return HGI_OK;
+    if (!d_out) return fail(HGI_EINVAL, "NULL buffer");
+    if (batch > 1 && frame_stride < (size_t)w * h) return fail(HGI_EINVAL, "frame_stride < width*height");
+    HIP_TRY(hipSetDevice(c->device));
+    Frames f = {w, h, (uint64_t)frame_stride, (uint32_t)batch};
+    HIP_TRY(launch_synth((int)kind, seed, first_frame, static_cast<uint8_t *>(d_out), f, c->stream));
+    return HGI_OK;
+}
+
+hgi_status hgi_copy_u8_dev(hgi_ctx *c, const void *d_src, void *d_dst, size_t n)
+{
+    if (!c) return fail(HGI_EINVAL, "ctx is NULL");
+    if (n == 0) return HGI_OK;
+    if (!d_src || !d_dst) return fail(HGI_EINVAL, "NULL buffer");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(launch_copy(static_cast<const uint8_t *>(d_src), static_cast<uint8_t *>(d_dst), n, c->stream));
+    return HGI_OK;
+}
+
+hgi_status hgi_diff_stats_dev(hgi_ctx *c, const void *d_before, const void *d_after, uint32_t w, uint32_t h,
+                              size_t batch, size_t frame_stride, void *d_out)
+{
+    if (!c) return fail(HGI_EINVAL, "ctx is NULL");
+    if (batch == 0) return HGI_OK;
+    if (!d_out || ((w && h) && (!d_before || !d_after))) return fail(HGI_EINVAL, "NULL buffer");
+    HIP_TRY(hipSetDevice(c->device));
+    Frames f = {w, h, (uint64_t)frame_stride, (uint32_t)batch};
+    HIP_TRY(launch_diff_stats(static_cast<const uint8_t *>(d_before), static_cast<const uint8_t *>(d_after), f,
+                              static_cast<unsigned long long *>(d_out), c->stream));
+    return HGI_OK;
+}
+
+hgi_status hgi_timer_start(hgi_ctx *c)
+{
+    if (!c) return fail(HGI_EINVAL, "ctx is NULL");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipEventRecord(c->ev0, c->stream));
+    return HGI_OK;
+}
+
+hgi_status hgi_timer_stop(hgi_ctx *c, float *elapsed_ms)
+{
+    if (!c || !elapsed_ms) return fail(HGI_EINVAL, "NULL argument");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipEventRecord(c->ev1, c->stream));
+    HIP_TRY(hipEventSynchronize(c->ev1));
+    HIP_TRY(hipEventElapsedTime(elapsed_ms, c->ev0, c->ev1));
+    return HGI_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,65 @@
+// Internal launch interface between hgi_capi.hip (host logic) and hgi_kernels.hip (gfx950 kernels).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+namespace hgi {
+
+constexpr int kInterpLeftTop = 0;
+constexpr int kInterpCrossed = 1;
+
+// Fused tile geometry (see DESIGN.md "Kernels").
+constexpr int kTileW = 256;   // pixels per tile row   (16 lanes x 16 B)
+constexpr int kTileH = 64;    // tile rows
+constexpr int kFusedMaxLevels = 6;  // 2^6 == kTileH: deepest pyramid one tile can hold
+constexpr int kThreads = 256;
+
+// 256-entry quantizer table passed BY VALUE in the kernarg segment: no device-side table to
+// keep alive, nothing to synchronise, capturable.
+struct Lut256 {
+    uint32_t w[64];
+};
+
+struct Frames {
+    uint32_t width, height;
+    uint64_t frame_stride;  // bytes between frames
+    uint32_t batch;
+};
+
+// Compact planes holding the stride-2^k lattice of a deeper pyramid (levels > kFusedMaxLevels):
+// seed_rec = reconstructed values, seed_q = grid (residual) values, both sw x sh per frame.
+struct Seeds {
+    const uint8_t *rec;
+    const uint8_t *q;
+    uint32_t sw, sh;
+    uint64_t stride;
+};
+
+// ---- level-wise path: one launch per level, straight global-memory stencil -----------------
+hipError_t launch_seed(const uint8_t *src, uint8_t *dst, const Frames &f, uint32_t levels,
+                       hipStream_t s);
+hipError_t launch_decode_level(const uint8_t *grid, uint8_t *img, const Frames &f, uint32_t log2sub,
+                               int interp, hipStream_t s);
+hipError_t launch_encode_level(uint8_t *rec, uint8_t *grid, const Frames &f, uint32_t log2sub,
+                               int interp, const Lut256 &lut, hipStream_t s);
+
+// ---- fused path: the last k <= kFusedMaxLevels levels of every tile in one launch ------------
+hipError_t launch_decode_fused(const uint8_t *grid, uint8_t *img, const Frames &f, uint32_t k,
+                               int interp, const Seeds *seeds, hipStream_t s);
+hipError_t launch_encode_fused(const uint8_t *img, uint8_t *grid, const Frames &f, uint32_t k,
+                               int interp, const Lut256 &lut, bool lut_is_identity,
+                               const Seeds *seeds, hipStream_t s);
+
+// dst[f][j][i] = src[f][j << k][i << k]  (the stride-2^k lattice as a dense plane)
+hipError_t launch_gather_lattice(const uint8_t *src, const Frames &f, uint32_t k, uint8_t *dst,
+                                 uint32_t sw, uint32_t sh, uint64_t dst_stride, hipStream_t s);
+
+// ---- harness kernels --------------------------------------------------------------------------
+hipError_t launch_synth(int kind, uint64_t seed, uint64_t first_frame, uint8_t *out, const Frames &f,
+                        hipStream_t s);
+hipError_t launch_copy(const uint8_t *src, uint8_t *dst, size_t n, hipStream_t s);
+hipError_t launch_diff_stats(const uint8_t *a, const uint8_t *b, const Frames &f,
+                             unsigned long long *out, hipStream_t s);
+
+}  // namespace hgi

@@ -1,0 +1,105 @@
+"""CPU suite: the C-ABI library loads, exports every symbol include/hgi.h declares, its host-side
+table builders agree with the oracle, and the product path fails loudly without a GPU."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+from rustyhgi_amd import _ffi
+
+
+def header_symbols():
+    text = open(os.path.join(ROOT, "include", "hgi.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(hgi_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    names = header_symbols()
+    assert len(names) >= 19
+    L = ctypes.CDLL(_ffi.LIB_PATH)
+    for n in names:
+        assert hasattr(L, n), "libhgi_hip.so lacks %s" % n
+    assert sorted(s[0] for s in _ffi.SYMBOLS) == names     # the binding covers the whole header
+
+
+def test_version_and_error_strings():
+    assert b"gfx950" in _ffi.lib().hgi_version()
+    assert isinstance(_ffi.lib().hgi_last_error(), bytes)
+
+
+def test_lut_builders_match_oracle(oracle):
+    from rustyhgi_amd.quantizator import Linear, NoOp, QuantizationLevel
+    for level in QuantizationLevel:
+        q = Linear.from_level(level)
+        lut, err = oracle.linear_lut(int(level))
+        assert (q.table() == lut).all() and q.error() == err
+        assert all(q.quantize(i) == lut[i] for i in range(256))
+    assert (NoOp().table() == oracle.noop_lut()).all() and NoOp().error() == 0
+    bad = np.zeros(256, np.uint8)
+    assert _ffi.lib().hgi_linear_lut(7, bad.ctypes.data, None) == _ffi.EINVAL
+    assert b"quantization level" in _ffi.lib().hgi_last_error()
+    assert QuantizationLevel.parse("mEdIuM") is QuantizationLevel.Medium      # src/options.rs:61
+    with pytest.raises(ValueError):
+        QuantizationLevel.parse("loseless")                                   # not typo tolerant
+
+
+def test_argument_checks_need_no_device():
+    L = _ffi.lib()
+    assert L.hgi_ctx_create(0, None) == _ffi.EINVAL
+    assert L.hgi_sync(None) == _ffi.EINVAL
+    assert L.hgi_encode_u8_dev(None, None, 4, 4, 2, 1, None, None, 1, 16) == _ffi.EINVAL
+    assert L.hgi_decode_u8(None, None, 4, 4, 2, 1, None) == _ffi.EINVAL
+
+
+def test_no_cpu_fallback_without_gpu():
+    """Without a usable HIP device the product path must fail loudly, never compute on the host."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present; the loud-failure leg is for CPU-only hosts")
+    import rustyhgi_amd as H
+    from rustyhgi_amd.interpolator import Crossed
+    from rustyhgi_amd.quantizator import NoOp
+    with pytest.raises(H.HgiError) as ei:
+        H.Encoder(Crossed(), NoOp(), 2).encode(np.zeros((8, 8), np.uint8))
+    assert ei.value.status == _ffi.EDEVICE and "no CPU path" in str(ei.value)
+    with pytest.raises(H.HgiError):
+        H.Decoder(Crossed()).decode((8, 8), 2, H.Grid(np.zeros(64, np.uint8), 8))
+
+
+def test_product_package_never_touches_the_oracle():
+    pkg = os.path.join(ROOT, "rustyhgi_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for fn in files:
+            if fn.endswith((".py", ".hip", ".h", ".cpp", ".hpp")) or fn == "Makefile":
+                text = open(os.path.join(dirpath, fn)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle|hgi_oracle|oracle/", text, re.M), \
+                    "%s references the oracle" % fn
+
+
+def test_mirror_surface():
+    """Crate-root surface of src/lib.rs:16-23 and the types benches/bench.rs:9-11 imports."""
+    import rustyhgi_amd as H
+    from rustyhgi_amd.interpolator import Crossed, InterpolationType, Interpolator, LeftTop
+    from rustyhgi_amd.quantizator import Linear, NoOp, QuantizationLevel, Quantizator
+    assert [m.name for m in QuantizationLevel] == ["Lossless", "Low", "Medium", "High"]
+    assert [m.name for m in InterpolationType] == ["Crossed", "Line", "Previous"]
+    assert (LeftTop.kernel_id, Crossed.kernel_id) == (0, 1)
+    assert issubclass(Linear, Quantizator) and issubclass(NoOp, Quantizator)
+    enc = H.Encoder(Crossed(), Linear.from_level(QuantizationLevel.Medium), 4)
+    assert enc.scale_level == 4
+    with pytest.raises(TypeError):
+        H.Encoder(object(), NoOp(), 1)
+
+    class Mine(Interpolator):
+        pass
+    with pytest.raises(H.HgiError) as ei:
+        H.Decoder(Mine())
+    assert ei.value.status == _ffi.EUNSUPPORTED
+    g = H.Grid(np.arange(12, dtype=np.uint8), 4)
+    assert g.get(1, 2) == 9 and g.height == 3
+    g.set((1, 2), 77)
+    assert g.get(1, 2) == 77 and g == H.Grid(g.buffer.copy(), 4)

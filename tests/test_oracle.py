@@ -1,0 +1,205 @@
+"""CPU suite: the oracle against the committed golden vectors, SURVEY Appendix B and the
+domain's invariants.  Nothing here touches the GPU library's compute entry points."""
+import hashlib
+
+import numpy as np
+import pytest
+
+from oracle import hgi_numpy as NP
+
+
+def sha(a):
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+def lut_for(oracle, q):
+    return oracle.noop_lut() if q == "noop" else oracle.linear_lut(int(q))[0]
+
+
+def parse_key(key):
+    name, lv, q, i = key.split("/")
+    return name, int(lv[1:]), q[1:], int(i[1:])
+
+
+def test_linear_lut_matches_reference_formula(oracle):
+    # src/quantizator.rs:41-63; Medium's outputs listed in SURVEY Appendix A.1
+    for level, err in enumerate((0, 10, 20, 30)):
+        lut, e = oracle.linear_lut(level)
+        assert e == err
+        scale = 2 * err + 1
+        assert [(i + err) // scale * scale for i in range(256)] == lut.tolist()
+        assert np.abs(lut.astype(int) - np.arange(256)).max() <= err
+        assert (lut == NP.linear_lut(level)[0]).all()
+    assert sorted(set(oracle.linear_lut(2)[0].tolist())) == [0, 41, 82, 123, 164, 205, 246]
+    assert (oracle.noop_lut() == np.arange(256)).all()
+
+
+def test_appendix_b1_lib_rs_case(oracle):
+    """12x8 xy image, levels=3 (src/lib.rs:45-48): SURVEY Appendix B.1 rows and hashes."""
+    img = oracle.synth(oracle.SYNTH_XY, 0, 0, 12, 8)
+    yy, xx = np.mgrid[0:8, 0:12]
+    assert (img == ((xx * yy) & 0xFF)).all()
+    expect = {0: (0, 0, "38aa39a03be8578c"), 1: (10, 8, "6e51b00b6e83e1d6"),
+              2: (20, 4, "947ae38b5c870a01"), 3: (29, 5, "ba1384f0037878fc")}
+    for level, (mx, fb, h16) in expect.items():
+        lut, err = oracle.linear_lut(level)
+        grid, rec, nfb = oracle.encode(img, 3, lut, want_rec=True)
+        dec = oracle.decode(grid, 3)
+        assert (dec == rec).all()
+        assert int(np.abs(img.astype(int) - dec).max()) == mx <= err
+        assert nfb == fb and sha(grid)[:16] == h16
+    lossless = oracle.encode(img, 3, oracle.linear_lut(0)[0])
+    assert lossless[0].tolist() == [0, 255, 252, 253, 0, 251, 244, 249, 0, 247, 248, 251]
+    assert lossless[7].tolist() == [253, 4, 5, 12, 13, 20, 21, 28, 29, 36, 55, 62]
+    medium = oracle.encode(img, 3, oracle.linear_lut(2)[0])
+    assert medium[0].tolist() == [0, 0, 0, 0, 0, 254, 246, 251, 0, 251, 246, 254]   # 254/251: fallback
+    assert medium[7].tolist() == [0, 0, 0, 0, 0, 0, 0, 41, 41, 41, 41, 82]
+
+
+def test_appendix_b2_lena(oracle, lena):
+    assert sha(lena).startswith("f6a26c7641342ed5")
+    expect = {0: (0, 0, 0, "ad84562f0403d27a", "f6a26c7641342ed5"),
+              1: (10, 39, 26, "d00582ba34c73691", "009eca639238603e"),
+              2: (20, 235, 84, "3a992020370c96a4", "e17f5ad9f400234e"),
+              3: (30, 425, 145, "6efd1ae27bde1fa5", "1db1b14b159b18a8")}
+    for level, (mx, fb, mse, hg, hd) in expect.items():
+        grid, rec, nfb = oracle.encode(lena, 4, oracle.linear_lut(level)[0], want_rec=True)
+        dec = oracle.decode(grid, 4)
+        _, int_mse, max_abs = oracle.sq_error(lena, dec)
+        assert (max_abs, nfb, int_mse) == (mx, fb, mse)
+        assert sha(grid)[:16] == hg and sha(dec)[:16] == hd
+    # `hgi test res/LENA.TIF` defaults (L=4, Medium) print SD 9.17 (src/main.rs:106,111)
+    assert "%.2f" % np.sqrt(84) == "9.17"
+
+
+def test_small_golden_full_grids(oracle, golden, small):
+    n = 0
+    for key, meta in golden.items():
+        if ("grid/" + key) not in small:
+            continue
+        name, levels, q, interp = parse_key(key)
+        img = small["in/" + name]
+        lut = lut_for(oracle, q)
+        grid, rec, fb = oracle.encode(img, levels, lut, interp, want_rec=True)
+        assert (grid == small["grid/" + key]).all(), key
+        assert (oracle.decode(grid, levels, interp) == small["dec/" + key]).all(), key
+        assert fb == meta["fallbacks"] and sha(grid) == meta["sha_grid"]
+        g2, r2, fb2 = NP.encode(img, levels, lut, interp, want_rec=True)
+        assert (g2 == grid).all() and (r2 == rec).all() and fb2 == fb, key
+        n += 1
+    assert n >= 100
+
+
+def test_image_golden_hashes(oracle, golden, lena, fullhd):
+    for name, img in (("lena_256", lena), ("fullhd_luma", fullhd)):
+        for q in range(4):
+            for interp in (0, 1):
+                meta = golden["%s/L4/q%d/i%d" % (name, q, interp)]
+                assert sha(img) == meta["sha_in"]
+                grid = oracle.encode(img, 4, oracle.linear_lut(q)[0], interp)
+                assert sha(grid) == meta["sha_grid"]
+                assert sha(oracle.decode(grid, 4, interp)) == meta["sha_dec"]
+
+
+def test_criterion_image_golden(oracle, golden):
+    img = oracle.synth(oracle.SYNTH_XY, 0, 0, 1920, 1080)     # benches/bench.rs:15-31
+    for q in ("0", "2", "noop"):
+        for interp in (0, 1):
+            meta = golden["xy_1920x1080/L4/q%s/i%d" % (q, interp)]
+            grid = oracle.encode(img, 4, lut_for(oracle, q), interp)
+            assert sha(grid) == meta["sha_grid"]
+
+
+@pytest.mark.parametrize("w,h,levels", [(12, 8, 3), (8, 8, 3), (13, 7, 3), (30, 17, 4), (5, 5, 2),
+                                        (1, 1, 3), (3, 9, 4), (300, 70, 7), (64, 64, 6), (65, 129, 8)])
+def test_partition_and_dependencies(oracle, w, h, levels):
+    """base + levels visit every pixel exactly once, and a lossless grid decodes
+    to the input whatever the content (coverage-once + reads-only-coarser)."""
+    rng = np.random.default_rng(w * 1000 + h)
+    img = rng.integers(0, 256, (h, w), dtype=np.uint8)
+    cover = np.zeros((h, w), int)
+    b = 1 << levels
+    cover[::b, ::b] += 1
+    for level in range(levels):
+        sub = 1 << (levels - level - 1)
+        for v in NP._level_views(cover, sub):
+            v += 1
+    assert (cover == 1).all()
+    for interp in (0, 1):
+        grid = oracle.encode(img, levels, oracle.noop_lut(), interp)
+        assert (oracle.decode(grid, levels, interp) == img).all()
+        assert (grid[::b, ::b] == img[::b, ::b]).all()      # src/encoder.rs:26-37
+
+
+@pytest.mark.parametrize("level", [1, 2, 3])
+def test_lossy_error_bound_and_closed_loop(oracle, level):
+    """|x - decode(encode(x))| <= e (the bound src/lib.rs:71-75 meant to assert) and
+    decode(encode(x)) == the encoder's in-place reconstruction."""
+    rng = np.random.default_rng(level)
+    lut, err = oracle.linear_lut(level)
+    for (h, w, L) in [(97, 131, 5), (64, 48, 4), (33, 200, 6)]:
+        for img in (rng.integers(0, 256, (h, w), dtype=np.uint8),
+                    oracle.synth(oracle.SYNTH_RAMP, 7, 0, w, h)):
+            grid, rec, fb = oracle.encode(img, L, lut, want_rec=True)
+            dec = oracle.decode(grid, L)
+            assert (dec == rec).all()
+            assert np.abs(img.astype(int) - dec).max() <= err
+            assert (NP.encode(img, L, lut) == grid).all()
+
+
+def test_fallback_rule_equals_range_test():
+    """The kernels' packed form of src/encoder.rs:56-60: the fallback fires exactly when
+    a + q - d leaves 0..255 (a = original, d = a - p mod 256, q = any table value)."""
+    a, p = np.meshgrid(np.arange(256), np.arange(256), indexing="ij")
+    d = (a - p) & 255
+    for q in range(256):
+        ref = ((p + q) > 255) != ((p + d) > 255)
+        t = a + q - d
+        assert ((t < 0) | (t > 255) == ref).all()
+
+
+def test_packed_predictor_identity():
+    """(L+R+T+B)>>2 == lerp(lerp(L,R,0), lerp(T,B,0), (L^R)&(T^B)) with lerp = v_lerp_u8
+    semantics -- the packed form used by the fine-level kernels."""
+    rng = np.random.default_rng(1)
+    lt, rt, lb, rb = (rng.integers(0, 256, 2_000_000) for _ in range(4))
+    lerp = lambda x, y, c: (x + y + (c & 1)) >> 1
+    L, R, T, B = lerp(lt, lb, 1), lerp(rb, rt, 1), lerp(rt, lt, 1), lerp(rb, lb, 1)
+    packed = lerp(lerp(L, R, 0), lerp(T, B, 0), (L ^ R) & (T ^ B))
+    assert (packed == (L + R + T + B) >> 2).all()
+    plain = (lt + rt + lb + rb + 2) >> 2                      # NOT the plain rounded mean
+    assert (packed != plain).mean() > 0.1
+
+
+def test_synth_formulas(oracle):
+    w, h = 37, 21
+    yy, xx = np.mgrid[0:h, 0:w].astype(np.uint64)
+
+    def mix64(z):
+        z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+        z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+        return z ^ (z >> np.uint64(31))
+
+    seed, frame = np.uint64(0x48474933), np.uint64(5)
+    with np.errstate(over="ignore"):
+        nz = (mix64(seed ^ (frame << np.uint64(40)) ^ (yy << np.uint64(20)) ^ xx) >> np.uint64(56)).astype(np.uint8)
+    assert (oracle.synth(oracle.SYNTH_NOISE, int(seed), 5, w, h) == nz).all()
+    ramp = ((((3 * xx + 5 * yy) >> np.uint64(4)) + (nz & 0x0F)) & np.uint64(0xFF)).astype(np.uint8)
+    assert (oracle.synth(oracle.SYNTH_RAMP, int(seed), 5, w, h) == ramp).all()
+
+
+def test_levels_zero_and_empty(oracle):
+    img = np.arange(35, dtype=np.uint8).reshape(5, 7)
+    grid = oracle.encode(img, 0, oracle.linear_lut(3)[0])
+    assert (grid == img).all() and (oracle.decode(grid, 0) == img).all()
+    assert oracle.encode(np.zeros((0, 5), np.uint8), 3, oracle.noop_lut()).size == 0
+
+
+def test_threaded_batch_matches_single(oracle):
+    imgs = np.stack([oracle.synth(oracle.SYNTH_RAMP, 3, f, 160, 96) for f in range(5)])
+    lut = oracle.linear_lut(2)[0]
+    r = oracle.bench_batch(imgs, 4, lut, threads=3)
+    for f in range(5):
+        g = oracle.encode(imgs[f], 4, lut)
+        assert (r["grids"][f] == g).all() and (r["outs"][f] == oracle.decode(g, 4)).all()
+    assert r["wall_s"] > 0

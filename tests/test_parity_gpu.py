@@ -1,0 +1,261 @@
+"""GPU parity suite (run with -m gpu on an MI355X): every case goes through the C ABI
+(libhgi_hip.so) and is compared bit for bit with the CPU oracle and the committed golden vectors."""
+import ctypes
+import hashlib
+
+import numpy as np
+import pytest
+
+from conftest import SEED0
+
+pytestmark = pytest.mark.gpu
+
+
+def sha(a):
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+def lut_for(oracle, q):
+    return oracle.noop_lut() if q == "noop" else oracle.linear_lut(int(q))[0]
+
+
+@pytest.fixture(scope="module")
+def H():
+    import torch
+    assert torch.cuda.is_available(), "GPU tests need a device"
+    import rustyhgi_amd
+    from rustyhgi_amd import _ffi
+    assert _ffi.lib() is not None          # the HIP library is what runs; no fallback exists
+    return rustyhgi_amd
+
+
+@pytest.fixture(scope="module")
+def ctxs(H):
+    from rustyhgi_amd import _ffi
+    fused, levelwise = H.Context(0), H.Context(0)
+    levelwise.set_path(_ffi.PATH_LEVELWISE)
+    yield {"fused": fused, "levelwise": levelwise}
+    fused.close()
+    levelwise.close()
+
+
+def gpu_encode(ctx, img, levels, lut, interp=1):
+    from rustyhgi_amd import _ffi
+    img = np.ascontiguousarray(img, np.uint8)
+    lut = np.ascontiguousarray(lut, np.uint8)
+    h, w = img.shape
+    grid = np.full_like(img, 0xA5)
+    _ffi.check(_ffi.lib().hgi_encode_u8(ctx.handle, img.ctypes.data, w, h, levels, interp,
+                                        lut.ctypes.data, grid.ctypes.data))
+    return grid
+
+
+def gpu_decode(ctx, grid, levels, interp=1):
+    from rustyhgi_amd import _ffi
+    grid = np.ascontiguousarray(grid, np.uint8)
+    h, w = grid.shape
+    img = np.full_like(grid, 0x5A)
+    _ffi.check(_ffi.lib().hgi_decode_u8(ctx.handle, grid.ctypes.data, w, h, levels, interp,
+                                        img.ctypes.data))
+    return img
+
+
+def assert_same(a, b, what):
+    if not (a == b).all():
+        bad = np.argwhere(a != b)
+        y, x = bad[0]
+        raise AssertionError("%s: %d mismatches, first at (x=%d, y=%d): got %d want %d"
+                             % (what, len(bad), x, y, a[y, x], b[y, x]))
+
+
+@pytest.mark.parametrize("path", ["fused", "levelwise"])
+def test_small_golden_cases(ctxs, oracle, golden, small, path):
+    """Tiny / odd-sized / ragged cases incl. the reference's own 12x8 and 8x8 (src/lib.rs:45-48,99-105),
+    levels 0 and levels > log2(size), both interpolators, all quantizers."""
+    ctx = ctxs[path]
+    n = 0
+    for key in golden:
+        if ("grid/" + key) not in small:
+            continue
+        name, lv, q, i = key.split("/")
+        levels, interp = int(lv[1:]), int(i[1:])
+        img = small["in/" + name]
+        lut = lut_for(oracle, q[1:])
+        assert_same(gpu_encode(ctx, img, levels, lut, interp), small["grid/" + key], "encode " + key)
+        assert_same(gpu_decode(ctx, small["grid/" + key], levels, interp), small["dec/" + key], "decode " + key)
+        n += 1
+    assert n >= 100
+
+
+@pytest.mark.parametrize("path", ["fused", "levelwise"])
+def test_lena_and_fullhd(ctxs, oracle, golden, lena, fullhd, path):
+    """BASELINE configs C0 (LENA.TIF, really 256x256) and C1 (fullhd luma; 1080 is not a multiple of 16)."""
+    ctx = ctxs[path]
+    for name, img in (("lena_256", lena), ("fullhd_luma", fullhd)):
+        for q in range(4):
+            for interp in (0, 1):
+                meta = golden["%s/L4/q%d/i%d" % (name, q, interp)]
+                lut = oracle.linear_lut(q)[0]
+                grid = gpu_encode(ctx, img, 4, lut, interp)
+                assert_same(grid, oracle.encode(img, 4, lut, interp), "encode %s q%d i%d" % (name, q, interp))
+                assert sha(grid) == meta["sha_grid"]
+                dec = gpu_decode(ctx, grid, 4, interp)
+                assert sha(dec) == meta["sha_dec"]
+                _, mse, mx = oracle.sq_error(img, dec)
+                assert (mx, mse) == (meta["max_abs"], meta["int_mse"])
+
+
+@pytest.mark.parametrize("path", ["fused", "levelwise"])
+def test_criterion_bench_image(ctxs, oracle, golden, path):
+    """The eight criterion cases' input (benches/bench.rs:15-31): 1920x1080 xy, levels 4."""
+    img = oracle.synth(oracle.SYNTH_XY, 0, 0, 1920, 1080)
+    for q in ("0", "2", "noop"):
+        for interp in (0, 1):
+            meta = golden["xy_1920x1080/L4/q%s/i%d" % (q, interp)]
+            grid = gpu_encode(ctxs[path], img, 4, lut_for(oracle, q), interp)
+            assert sha(grid) == meta["sha_grid"], (q, interp)
+            assert sha(gpu_decode(ctxs[path], grid, 4, interp)) == meta["sha_dec"]
+
+
+@pytest.mark.parametrize("w,h,levels", [(256, 64, 1), (256, 64, 6), (512, 128, 5), (272, 80, 4), (16, 16, 4),
+                                        (1040, 200, 3), (255, 63, 4), (257, 65, 6), (300, 70, 7), (64, 700, 9),
+                                        (1, 1, 3), (1, 300, 5), (300, 1, 5), (1600, 520, 12), (4096, 64, 2)])
+@pytest.mark.parametrize("path", ["fused", "levelwise"])
+def test_random_shapes_and_tables(ctxs, oracle, w, h, levels, path):
+    """Tile-edge, ragged and deeper-than-tile (levels > 6: lattice recursion) shapes with noise input
+    and ARBITRARY quantizer tables, so the overflow fallback fires often (src/encoder.rs:56-60)."""
+    rng = np.random.default_rng(w * 7919 + h * 31 + levels)
+    img = rng.integers(0, 256, (h, w), dtype=np.uint8)
+    tables = [oracle.linear_lut(2)[0], rng.integers(0, 256, 256, dtype=np.uint8), oracle.noop_lut()]
+    for t, lut in enumerate(tables):
+        for interp in (1, 0):
+            want, _, fb = oracle.encode(img, levels, lut, interp, want_rec=True)
+            assert_same(gpu_encode(ctxs[path], img, levels, lut, interp), want,
+                        "encode %dx%d L%d table%d interp%d (fallbacks=%d)" % (w, h, levels, t, interp, fb))
+            assert_same(gpu_decode(ctxs[path], want, levels, interp), oracle.decode(want, levels, interp),
+                        "decode %dx%d L%d table%d interp%d" % (w, h, levels, t, interp))
+
+
+def test_smooth_images_all_levels(ctxs, oracle):
+    for levels in range(0, 9):
+        img = oracle.synth(oracle.SYNTH_RAMP, SEED0 + 1, levels, 784, 330)
+        for q in range(4):
+            lut = oracle.linear_lut(q)[0]
+            want = oracle.encode(img, levels, lut)
+            assert_same(gpu_encode(ctxs["fused"], img, levels, lut), want, "encode L%d q%d" % (levels, q))
+            assert_same(gpu_decode(ctxs["fused"], want, levels), oracle.decode(want, levels), "decode L%d q%d" % (levels, q))
+
+
+def test_4k_configs_against_golden(ctxs, oracle, golden):
+    """BASELINE C2 (4096^2 L6 Lossless, bit-exact round trip) and single C3 frames (L4 Medium)."""
+    cases = {"noise2_4096/L6/q0/i1": (oracle.SYNTH_NOISE, SEED0 + 2, 0), "xy_4096/L6/q0/i1": (oracle.SYNTH_XY, 0, 0),
+             "ramp3_f0_4096/L4/q2/i1": (oracle.SYNTH_RAMP, SEED0 + 3, 0),
+             "ramp3_f511_4096/L4/q2/i1": (oracle.SYNTH_RAMP, SEED0 + 3, 511),
+             "noise3_f7_4096/L4/q2/i1": (oracle.SYNTH_NOISE, SEED0 + 3, 7)}
+    for key, (kind, seed, frame) in cases.items():
+        meta = golden[key]
+        img = oracle.synth(kind, seed, frame, 4096, 4096)
+        assert sha(img) == meta["sha_in"]
+        lut = oracle.linear_lut(int(meta["quant"]))[0]
+        grid = gpu_encode(ctxs["fused"], img, meta["levels"], lut)
+        assert sha(grid) == meta["sha_grid"], key
+        dec = gpu_decode(ctxs["fused"], grid, meta["levels"])
+        assert sha(dec) == meta["sha_dec"], key
+        if meta["quant"] == 0:
+            assert (dec == img).all()
+        assert_same(grid, oracle.encode(img, meta["levels"], lut), key)
+
+
+def test_device_batch_and_generators(H, ctxs, oracle):
+    """Device-pointer batched entry points + on-device synthetic generators vs the oracle."""
+    import torch
+    from rustyhgi_amd import _ffi
+    ctx = ctxs["fused"]
+    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    B, Hh, W = 5, 200, 528
+    for kind in (oracle.SYNTH_XY, oracle.SYNTH_NOISE, oracle.SYNTH_RAMP):
+        imgs = torch.empty((B, Hh, W), dtype=torch.uint8, device="cuda")
+        _ffi.check(_ffi.lib().hgi_synth_u8_dev(ctx.handle, kind, SEED0 + 3, 100, W, Hh, imgs.data_ptr(), B, Hh * W))
+        host = imgs.cpu().numpy()
+        for f in range(B):
+            assert (host[f] == oracle.synth(kind, SEED0 + 3, 100 + f, W, Hh)).all(), (kind, f)
+    from rustyhgi_amd.interpolator import Crossed
+    from rustyhgi_amd.quantizator import Linear, QuantizationLevel
+    enc = H.Encoder(Crossed(), Linear.from_level(QuantizationLevel.Medium), 4, context=ctx)
+    dec = H.Decoder(Crossed(), context=ctx)
+    before = imgs.clone()
+    grids = enc.encode_batch(imgs)
+    outs = dec.decode_batch(grids, 4)
+    torch.cuda.synchronize()
+    assert torch.equal(before, imgs)                      # encode must not modify its input
+    lut = oracle.linear_lut(2)[0]
+    g, o, im = grids.cpu().numpy(), outs.cpu().numpy(), imgs.cpu().numpy()
+    stats = torch.zeros(3 * B, dtype=torch.int64, device="cuda")
+    _ffi.check(_ffi.lib().hgi_diff_stats_dev(ctx.handle, imgs.data_ptr(), outs.data_ptr(), W, Hh, B, Hh * W,
+                                             stats.data_ptr()))
+    st = stats.cpu().numpy().reshape(B, 3)
+    for f in range(B):
+        want = oracle.encode(im[f], 4, lut)
+        assert_same(g[f], want, "batch frame %d" % f)
+        assert_same(o[f], oracle.decode(want, 4), "batch frame %d decode" % f)
+        sd, _, mx = oracle.sq_error(im[f], o[f])
+        assert (int(st[f, 0]), int(st[f, 1])) == (sd, mx) and int(st[f, 2]) == int((im[f] != o[f]).sum())
+    # mirror objects on single tensors / numpy
+    grid = enc.encode(imgs[2])
+    assert isinstance(grid, H.Grid) and grid.width == W
+    assert torch.equal(dec.decode((W, Hh), 4, grid), outs[2])
+    ctx.use_own_stream()
+
+
+def test_levelwise_equals_fused_on_device(ctxs, oracle):
+    img = oracle.synth(oracle.SYNTH_NOISE, 99, 0, 2048, 520)
+    lut = oracle.linear_lut(3)[0]
+    a = gpu_encode(ctxs["fused"], img, 5, lut)
+    b = gpu_encode(ctxs["levelwise"], img, 5, lut)
+    assert_same(a, b, "fused vs levelwise encode")
+    assert_same(gpu_decode(ctxs["fused"], a, 5), gpu_decode(ctxs["levelwise"], a, 5), "fused vs levelwise decode")
+
+
+def test_full_size_properties(H, ctxs, oracle, golden):
+    """BASELINE C4 (16384^2 L8 High) at full size through size-independent properties: golden hash of
+    the grid, error bound, decode(encode(x)) idempotence (re-encoding the reconstruction with the
+    lossless table decodes to itself)."""
+    import torch
+    from rustyhgi_amd import _ffi
+    ctx = ctxs["fused"]
+    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    W = Hh = 16384
+    meta = golden["ramp4_16384/L8/q3/i1"]
+    img = torch.empty((1, Hh, W), dtype=torch.uint8, device="cuda")
+    _ffi.check(_ffi.lib().hgi_synth_u8_dev(ctx.handle, _ffi.SYNTH_RAMP, SEED0 + 4, 0, W, Hh, img.data_ptr(), 1, W * Hh))
+    from rustyhgi_amd.interpolator import Crossed
+    from rustyhgi_amd.quantizator import Linear, QuantizationLevel
+    enc = H.Encoder(Crossed(), Linear.from_level(QuantizationLevel.High), 8, context=ctx)
+    dec = H.Decoder(Crossed(), context=ctx)
+    grid = enc.encode_batch(img)
+    out = dec.decode_batch(grid, 8)
+    torch.cuda.synchronize()
+    assert sha(img.cpu().numpy()) == meta["sha_in"]
+    assert sha(grid.cpu().numpy()) == meta["sha_grid"]
+    assert sha(out.cpu().numpy()) == meta["sha_dec"]
+    diff = (img.to(torch.int16) - out.to(torch.int16)).abs().max().item()
+    assert diff == meta["max_abs"] <= 30
+    lossless = H.Encoder(Crossed(), Linear.from_level(QuantizationLevel.Lossless), 8, context=ctx)
+    again = dec.decode_batch(lossless.encode_batch(out), 8)
+    assert torch.equal(again, out)
+    ctx.use_own_stream()
+
+
+def test_error_paths_on_device(ctxs):
+    from rustyhgi_amd import _ffi
+    L, ctx = _ffi.lib(), ctxs["fused"]
+    img = np.zeros((8, 8), np.uint8)
+    lut = np.arange(256, dtype=np.uint8)
+    assert L.hgi_encode_u8(ctx.handle, img.ctypes.data, 8, 8, 32, 1, lut.ctypes.data, img.ctypes.data) == _ffi.EINVAL
+    out = np.zeros_like(img)
+    assert L.hgi_encode_u8(ctx.handle, img.ctypes.data, 8, 8, 2, 5, lut.ctypes.data, out.ctypes.data) == _ffi.EUNSUPPORTED
+    assert L.hgi_encode_u8(ctx.handle, img.ctypes.data, 8, 8, 2, 1, lut.ctypes.data, img.ctypes.data) == _ffi.EINVAL
+    assert L.hgi_encode_u8(ctx.handle, img.ctypes.data, 0, 8, 2, 1, lut.ctypes.data, out.ctypes.data) == _ffi.OK
+    assert L.hgi_decode_u8(ctx.handle, None, 8, 8, 2, 1, out.ctypes.data) == _ffi.EINVAL
+    bad = ctypes.c_void_p()
+    assert L.hgi_ctx_create(99, ctypes.byref(bad)) == _ffi.EDEVICE
