@@ -10,10 +10,10 @@ constexpr int kInterpLeftTop = 0;
 constexpr int kInterpCrossed = 1;
 
 // Fused tile geometry (see DESIGN.md "Kernels").
-constexpr int kTileW = 256;   // pixels per tile row   (16 lanes x 16 B)
+constexpr int kTileW = 128;   // pixels per tile row: 8 lanes x 16 B = one 128-B line
 constexpr int kTileH = 64;    // tile rows
 constexpr int kFusedMaxLevels = 6;  // 2^6 == kTileH: deepest pyramid one tile can hold
-constexpr int kThreads = 256;
+constexpr int kThreads = 64;  // ONE wave owns a tile: no workgroup barriers anywhere
 
 // 256-entry quantizer table passed BY VALUE in the kernarg segment: no device-side table to
 // keep alive, nothing to synchronise, capturable.

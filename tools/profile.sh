@@ -1,0 +1,26 @@
+#!/bin/bash
+# rocprofv3 collection for bench.py on the GPU box.  Writes raw output under gpurun_out/prof/<tag>/
+# and a compact summary gpurun_out/prof/<tag>/summary.md (copy that into profiles/).
+#   tools/profile.sh <tag> [bench args...]
+# Passes are separate on purpose: kernel-trace/stats alone, then one --pmc pass per counter group
+# (FETCH_SIZE and WRITE_SIZE do not fit one TCC pass; never mix --pmc with API tracing).
+set -u
+TAG=${1:-r01}; shift || true
+ARGS=${@:---steps 5 --warmup 1 --no-cpu}
+OUT=$PWD/gpurun_out/prof/$TAG
+mkdir -p "$OUT"
+export TMPDIR=/tmp
+run() { # name, rocprof flags...
+  local name=$1; shift
+  ( cd /tmp && rocprofv3 "$@" --output-format csv -d "$OUT/$name" -- python3 "$OLDPWD/bench.py" $ARGS ) > "$OUT/$name.log" 2>&1
+  echo "$name rc=$?" >> "$OUT/passes.log"
+}
+run trace --kernel-trace --stats
+run fetch --kernel-trace --pmc FETCH_SIZE
+run write --kernel-trace --pmc WRITE_SIZE
+run sq1 --kernel-trace --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_LDS
+run sq2 --kernel-trace --pmc SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAIT_INST_LDS SQ_INSTS_SALU
+run tcc --kernel-trace --pmc TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum
+python3 tools/summarize_prof.py "$OUT" > "$OUT/summary.md" 2>"$OUT/summarize.err"
+cat "$OUT/passes.log"
+tail -60 "$OUT/summary.md"

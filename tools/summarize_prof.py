@@ -1,0 +1,60 @@
+#!/usr/bin/env python3
+"""Condenses the rocprofv3 CSVs written by tools/profile.sh into one markdown summary:
+per-kernel launch statistics from the kernel trace, and per-kernel, per-launch averages of
+every PMC counter collected.  FETCH_SIZE on gfx950 under-reports wide coalesced reads by 2x
+(MI355X_MICROARCH.md, HBM section); both the raw and the corrected figure are printed."""
+import csv
+import glob
+import os
+import sys
+from collections import defaultdict
+
+
+def short(name):
+    for tok in ("(anonymous namespace)::", "void ", "hgi::"):
+        name = name.replace(tok, "")
+    return name.split("(")[0][:70]
+
+
+def main(out):
+    print("# rocprofv3 summary: %s\n" % os.path.basename(out))
+    traces = glob.glob(os.path.join(out, "trace", "**", "*kernel_trace.csv"), recursive=True)
+    dur = defaultdict(list)
+    for path in traces:
+        for row in csv.DictReader(open(path)):
+            dur[short(row["Kernel_Name"])].append(int(row["End_Timestamp"]) - int(row["Start_Timestamp"]))
+    print("## kernel trace (pass `trace`, --kernel-trace --stats)\n")
+    print("| kernel | launches | avg us | min us | max us | total ms |")
+    print("|---|---|---|---|---|---|")
+    for k, v in sorted(dur.items(), key=lambda kv: -sum(kv[1])):
+        print("| %s | %d | %.2f | %.2f | %.2f | %.3f |" % (k, len(v), sum(v) / len(v) / 1e3, min(v) / 1e3,
+                                                           max(v) / 1e3, sum(v) / 1e6))
+    print("\n## PMC (one pass per group; averages per launch)\n")
+    for name in ("fetch", "write", "sq1", "sq2", "tcc"):
+        files = glob.glob(os.path.join(out, name, "**", "*counter_collection.csv"), recursive=True)
+        acc = defaultdict(lambda: defaultdict(list))
+        for path in files:
+            for row in csv.DictReader(open(path)):
+                acc[short(row["Kernel_Name"])][row["Counter_Name"]].append(float(row["Counter_Value"]))
+        if not acc:
+            print("pass `%s`: no counter rows\n" % name)
+            continue
+        print("### pass `%s`\n" % name)
+        for k, ctrs in sorted(acc.items()):
+            if not k.startswith("k_"):
+                continue
+            parts = []
+            for c, vals in sorted(ctrs.items()):
+                avg = sum(vals) / len(vals)
+                if c == "FETCH_SIZE":
+                    parts.append("FETCH_SIZE=%.1f KB raw (x2 gfx950 correction = %.1f MB)" % (avg, 2 * avg / 1024))
+                elif c == "WRITE_SIZE":
+                    parts.append("WRITE_SIZE=%.1f KB (= %.1f MB)" % (avg, avg / 1024))
+                else:
+                    parts.append("%s=%.4g" % (c, avg))
+            print("- `%s` (%d launches): %s" % (k, len(next(iter(ctrs.values()))), "; ".join(parts)))
+        print()
+
+
+if __name__ == "__main__":
+    main(sys.argv[1])
