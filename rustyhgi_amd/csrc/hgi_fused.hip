@@ -51,6 +51,42 @@ typedef u32 v2u __attribute__((ext_vector_type(2)));
         : "+v"(dst)                                                                                 \
         : "v"(src))
 
+// Quantize + overflow fallback of ONE pixel in four single-issue VALU ops (src/encoder.rs:53-60):
+//   d   = a - p (mod 256)                        Q_SUB   (clean byte, ready as LDS address)
+//   q   = table[d]                               ds_read_u8
+//   expected overflow  p + d > 255  <=>  a < p   Q_LT    (borrow of a - p)
+//   actual overflow    p + q > 255  <=>  q > ~p  Q_GT    (np = 255 - p per byte)
+//   residual = (expected != actual) ? d : q      Q_SEL   (s_xor + v_cndmask straight into byte K)
+typedef unsigned long long lanemask;
+#define Q_SUB(d, a, K, p, J)                                                                                   \
+    asm("v_sub_u16_sdwa %0, %1, %2 dst_sel:BYTE_0 dst_unused:UNUSED_PAD src0_sel:BYTE_" #K " src1_sel:BYTE_" #J \
+        : "=v"(d) : "v"(a), "v"(p))
+#define Q_LT(m, a, K, p, J) \
+    asm("v_cmp_lt_u16_sdwa %0, %1, %2 src0_sel:BYTE_" #K " src1_sel:BYTE_" #J : "=s"(m) : "v"(a), "v"(p))
+#define Q_GT(m, q, np, J) \
+    asm("v_cmp_gt_u16_sdwa %0, %1, %2 src0_sel:BYTE_0 src1_sel:BYTE_" #J : "=s"(m) : "v"(q), "v"(np))
+#define Q_SEL(out, K, mb, mc, q, d)                                                                    \
+    asm("s_xor_b64 vcc, %1, %2\n\tv_cndmask_b32_sdwa %0, %3, %4, vcc dst_sel:BYTE_" #K                 \
+        " dst_unused:UNUSED_PRESERVE src0_sel:BYTE_0 src1_sel:BYTE_0"                                  \
+        : "+v"(out) : "s"(mb), "s"(mc), "v"(q), "v"(d) : "vcc", "scc")
+// four pixels: byte Kn of register On (original in, residual out) predicted by byte Jn of P
+#define Q_PIX4(slut, P, NP, O0, K0, J0, O1, K1, J1, O2, K2, J2, O3, K3, J3)                              \
+    do {                                                                                               \
+        u32 d0_, d1_, d2_, d3_;                                                                        \
+        lanemask b0_, b1_, b2_, b3_, c0_, c1_, c2_, c3_;                                               \
+        Q_SUB(d0_, O0, K0, P, J0); Q_SUB(d1_, O1, K1, P, J1); Q_SUB(d2_, O2, K2, P, J2); Q_SUB(d3_, O3, K3, P, J3); \
+        u32 q0_ = slut[d0_], q1_ = slut[d1_], q2_ = slut[d2_], q3_ = slut[d3_];                        \
+        Q_LT(b0_, O0, K0, P, J0); Q_LT(b1_, O1, K1, P, J1); Q_LT(b2_, O2, K2, P, J2); Q_LT(b3_, O3, K3, P, J3); \
+        Q_GT(c0_, q0_, NP, J0); Q_GT(c1_, q1_, NP, J1); Q_GT(c2_, q2_, NP, J2); Q_GT(c3_, q3_, NP, J3); \
+        Q_SEL(O0, K0, b0_, c0_, q0_, d0_); Q_SEL(O1, K1, b1_, c1_, q1_, d1_);                          \
+        Q_SEL(O2, K2, b2_, c2_, q2_, d2_); Q_SEL(O3, K3, b3_, c3_, q3_, d3_);                          \
+    } while (0)
+// dst.byte[KD] = (q.byte[KQ] + p.byte[J]) mod 256: the reconstruction of a freshly coded pixel
+#define Q_REC(dst, KD, q, KQ, p, J)                                                                    \
+    asm("v_add_u16_sdwa %0, %1, %2 dst_sel:BYTE_" #KD " dst_unused:UNUSED_PRESERVE src0_sel:BYTE_" #KQ   \
+        " src1_sel:BYTE_" #J                                                                           \
+        : "+v"(dst) : "v"(q), "v"(p))
+
 // ---------------------------------------------------------------------------------------------
 // tile bookkeeping
 // ---------------------------------------------------------------------------------------------
@@ -455,29 +491,43 @@ __device__ __forceinline__ void enc_level2_fast(u8 *buf, u8 *rbuf, const u8 *slu
         u32 P = ct;
         if (INTERP == kInterpCrossed)
             P = pred4_crossed(ct, cb, __builtin_amdgcn_alignbyte(c8, ct, 1), __builtin_amdgcn_alignbyte(l8, cb, 1));
-        u32 a[4] = {A.x, A.y, A.z, A.w}, bb[4] = {B.x, B.y, B.z, B.w};
-        u32 recA = 0, recB0 = 0, recB2 = 0;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const u32 p = (P >> (8 * j)) & 255u;
-            u32 q = quant1<IDENT>((a[j] >> 16) & 255u, p, slut);        // (x0+2, y0)
-            a[j] = (a[j] & 0xFF00FFFFu) | (q << 16);
-            recA |= ((p + q) & 255u) << (8 * j);
-            q = quant1<IDENT>(bb[j] & 255u, p, slut);                   // (x0,   y0+2)
-            u32 q2 = quant1<IDENT>((bb[j] >> 16) & 255u, p, slut);      // (x0+2, y0+2)
-            bb[j] = (bb[j] & 0xFF00FF00u) | q | (q2 << 16);
-            recB0 |= ((p + q) & 255u) << (8 * j);
-            recB2 |= ((p + q2) & 255u) << (8 * j);
+        u32 a0 = A.x, a1 = A.y, a2 = A.z, a3 = A.w, b0 = B.x, b1 = B.y, b2 = B.z, b3 = B.w;
+        v2u n0, n1;
+        if (IDENT) {
+            // identity table: residual = a - p, reconstruction = the original pixel
+            const u32 pA = __builtin_amdgcn_perm(P, P, 0x0c010c00u), pB = __builtin_amdgcn_perm(P, P, 0x0c030c02u);
+            n0.x = __builtin_amdgcn_perm(a0, ct, 0x0c010c00u) | __builtin_amdgcn_perm(a1, a0, 0x060c020cu);
+            n0.y = __builtin_amdgcn_perm(a0, ct, 0x0c030c02u) | __builtin_amdgcn_perm(a3, a2, 0x060c020cu);
+            n1.x = __builtin_amdgcn_perm(b1, b0, 0x06040200u);
+            n1.y = __builtin_amdgcn_perm(b3, b2, 0x06040200u);
+            const u32 m2 = 0x00FF0000u, m02 = 0x00FF00FFu;
+            a0 = (a0 & ~m2) | (sub4(a0, pA << 16) & m2);
+            a1 = (a1 & ~m2) | (sub4(a1, pA & m2) & m2);
+            a2 = (a2 & ~m2) | (sub4(a2, pB << 16) & m2);
+            a3 = (a3 & ~m2) | (sub4(a3, pB & m2) & m2);
+            const u32 p0 = (pA & 0xFFu) * 0x00010001u, p1 = ((pA >> 16) & 0xFFu) * 0x00010001u;
+            const u32 p2 = (pB & 0xFFu) * 0x00010001u, p3 = ((pB >> 16) & 0xFFu) * 0x00010001u;
+            b0 = (b0 & ~m02) | (sub4(b0, p0) & m02);
+            b1 = (b1 & ~m02) | (sub4(b1, p1) & m02);
+            b2 = (b2 & ~m02) | (sub4(b2, p2) & m02);
+            b3 = (b3 & ~m02) | (sub4(b3, p3) & m02);
+        } else {
+            const u32 NP = ~P;
+            Q_PIX4(slut, P, NP, a0, 2, 0, a1, 2, 1, a2, 2, 2, a3, 2, 3);     // (x0+2, y0)
+            Q_PIX4(slut, P, NP, b0, 0, 0, b1, 0, 1, b2, 0, 2, b3, 0, 3);     // (x0,   y0+2)
+            Q_PIX4(slut, P, NP, b0, 2, 0, b1, 2, 1, b2, 2, 2, b3, 2, 3);     // (x0+2, y0+2)
+            // lattice row 2g: corners stay, odd slots get the (x0+2, y0) reconstructions; row 2g+1: all new
+            n0.x = __builtin_amdgcn_perm(ct, ct, 0x0c010c00u);
+            n0.y = __builtin_amdgcn_perm(ct, ct, 0x0c030c02u);
+            n1.x = 0;
+            n1.y = 0;
+            Q_REC(n0.x, 1, a0, 2, P, 0); Q_REC(n0.x, 3, a1, 2, P, 1); Q_REC(n0.y, 1, a2, 2, P, 2); Q_REC(n0.y, 3, a3, 2, P, 3);
+            Q_REC(n1.x, 0, b0, 0, P, 0); Q_REC(n1.x, 1, b0, 2, P, 0); Q_REC(n1.x, 2, b1, 0, P, 1); Q_REC(n1.x, 3, b1, 2, P, 1);
+            Q_REC(n1.y, 0, b2, 0, P, 2); Q_REC(n1.y, 1, b2, 2, P, 2); Q_REC(n1.y, 2, b3, 0, P, 3); Q_REC(n1.y, 3, b3, 2, P, 3);
         }
-        v4u An = {a[0], a[1], a[2], a[3]}, Bn = {bb[0], bb[1], bb[2], bb[3]};
+        v4u An = {a0, a1, a2, a3}, Bn = {b0, b1, b2, b3};
         *reinterpret_cast<v4u *>(r0) = An;
         *reinterpret_cast<v4u *>(r0 + 2 * S) = Bn;
-        // lattice row 2g: corners stay, odd slots get the (x0+2, y0) reconstructions; row 2g+1: all new
-        v2u n0, n1;
-        n0.x = __builtin_amdgcn_perm(recA, ct, 0x05010400u);
-        n0.y = __builtin_amdgcn_perm(recA, ct, 0x07030602u);
-        n1.x = __builtin_amdgcn_perm(recB2, recB0, 0x05010400u);
-        n1.y = __builtin_amdgcn_perm(recB2, recB0, 0x07030602u);
         *reinterpret_cast<v2u *>(q0) = n0;
         *reinterpret_cast<v2u *>(q0 + S2) = n1;
     }
@@ -498,14 +548,25 @@ __device__ __forceinline__ void enc_fine_fast(const u8 *buf, const u8 *rbuf, con
         u32 c8 = c0[8], f8 = c0[S2 + 8];
         u32 P0, P1;
         pred8<INTERP>(c, c8, fl, f8, P0, P1);
-        u32 pp0 = __builtin_amdgcn_perm(P0, P0, 0x01010000u), pp1 = __builtin_amdgcn_perm(P0, P0, 0x03030202u);
-        u32 pp2 = __builtin_amdgcn_perm(P1, P1, 0x01010000u), pp3 = __builtin_amdgcn_perm(P1, P1, 0x03030202u);
-        u32 a0 = __builtin_amdgcn_perm(E.y, E.x, 0x07050301u), a1 = __builtin_amdgcn_perm(E.w, E.z, 0x07050301u);
-        u32 q0 = quant4<IDENT>(a0, P0, slut), q1 = quant4<IDENT>(a1, P1, slut);
-        v4u o0 = {__builtin_amdgcn_perm(q0, E.x, 0x05020400u), __builtin_amdgcn_perm(q0, E.y, 0x07020600u),
-                  __builtin_amdgcn_perm(q1, E.z, 0x05020400u), __builtin_amdgcn_perm(q1, E.w, 0x07020600u)};
-        v4u o1 = {quant4<IDENT>(O.x, pp0, slut), quant4<IDENT>(O.y, pp1, slut), quant4<IDENT>(O.z, pp2, slut),
-                  quant4<IDENT>(O.w, pp3, slut)};
+        u32 e0 = E.x, e1 = E.y, e2 = E.z, e3 = E.w, g0 = O.x, g1 = O.y, g2 = O.z, g3 = O.w;
+        if (IDENT) {
+            const u32 odd = 0xFF00FF00u;
+            const u32 pp0 = __builtin_amdgcn_perm(P0, P0, 0x01010000u), pp1 = __builtin_amdgcn_perm(P0, P0, 0x03030202u);
+            const u32 pp2 = __builtin_amdgcn_perm(P1, P1, 0x01010000u), pp3 = __builtin_amdgcn_perm(P1, P1, 0x03030202u);
+            e0 = sub4(e0, pp0 & odd); e1 = sub4(e1, pp1 & odd); e2 = sub4(e2, pp2 & odd); e3 = sub4(e3, pp3 & odd);
+            g0 = sub4(g0, pp0); g1 = sub4(g1, pp1); g2 = sub4(g2, pp2); g3 = sub4(g3, pp3);
+        } else {
+            const u32 N0 = ~P0, N1 = ~P1;
+            // row y: only the odd columns are new (cell j of the lane = byte j of P0, or byte j-4 of P1)
+            Q_PIX4(slut, P0, N0, e0, 1, 0, e0, 3, 1, e1, 1, 2, e1, 3, 3);
+            Q_PIX4(slut, P1, N1, e2, 1, 0, e2, 3, 1, e3, 1, 2, e3, 3, 3);
+            // row y+1: every column
+            Q_PIX4(slut, P0, N0, g0, 0, 0, g0, 1, 0, g0, 2, 1, g0, 3, 1);
+            Q_PIX4(slut, P0, N0, g1, 0, 2, g1, 1, 2, g1, 2, 3, g1, 3, 3);
+            Q_PIX4(slut, P1, N1, g2, 0, 0, g2, 1, 0, g2, 2, 1, g2, 3, 1);
+            Q_PIX4(slut, P1, N1, g3, 0, 2, g3, 1, 2, g3, 2, 3, g3, 3, 3);
+        }
+        v4u o0 = {e0, e1, e2, e3}, o1 = {g0, g1, g2, g3};
         __builtin_amdgcn_raw_buffer_store_b128(o0, b.rd, voff, 0, 0);
         __builtin_amdgcn_raw_buffer_store_b128(o1, b.rd, voff, b.W, 0);
     }
