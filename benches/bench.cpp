@@ -1,0 +1,115 @@
+// C++ counterpart of the reference's criterion harness (benches/bench.rs): the same cases on the same
+// 1920x1080 `(x*y) as u8` image at levels = 4, throughput in bytes of image per second
+// (`Throughput::Bytes(width*height)`, benches/bench.rs:33-36).  Each codec case is timed twice:
+//   host   -- through hgi_encode_u8 / hgi_decode_u8 (host pointers; PCIe transfers included), the
+//             drop-in equivalent of `encoder.encode(image)`;
+//   device -- through the *_dev entry points on device-resident buffers (what the roofline numbers use).
+// `serialization` / `compression` need the .hgi archive writer and are not here yet.
+//   build: hipcc -O2 -std=c++17 -Iinclude benches/bench.cpp -Lrustyhgi_amd -lhgi_hip -Wl,-rpath,$PWD/rustyhgi_amd -o bench_cpp
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <chrono>
+#include <cstdio>
+#include <cstring>
+#include <vector>
+
+#include "hgi.hpp"
+
+using namespace hgi;
+using clk = std::chrono::steady_clock;
+
+static GrayImage get_test_image(uint32_t width, uint32_t height)   // benches/bench.rs:15-31
+{
+    GrayImage img(width, height);
+    for (uint32_t y = 0; y < height; ++y)
+        for (uint32_t x = 0; x < width; ++x) img(x, y) = static_cast<uint8_t>(x * y);
+    return img;
+}
+
+template <class F>
+static double median_seconds(int samples, F &&f)   // criterion: sample_size(25), benches/bench.rs:156
+{
+    std::vector<double> t;
+    f();
+    for (int i = 0; i < samples; ++i) {
+        auto t0 = clk::now();
+        f();
+        t.push_back(std::chrono::duration<double>(clk::now() - t0).count());
+    }
+    std::sort(t.begin(), t.end());
+    return t[t.size() / 2];
+}
+
+static void report(const char *name, const char *mode, double sec, size_t bytes)
+{
+    std::printf("%-26s %-7s %10.3f us   %9.3f GiB/s\n", name, mode, sec * 1e6, bytes / sec / (1024.0 * 1024 * 1024));
+}
+
+template <class I, class Q>
+static void bench_encode(const char *name, Q quantizator, const GrayImage &image, size_t levels, void *d_in, void *d_out)
+{
+    Context &ctx = Context::global();
+    Encoder<I, Q> encoder(I{}, quantizator, levels);
+    const size_t size = image.data.size();
+    report(name, "host", median_seconds(25, [&] { (void)encoder.encode(image); }), size);
+    auto table = quantizator::tabulate(quantizator);
+    const int reps = 20;
+    double sec = median_seconds(25, [&] {
+        for (int r = 0; r < reps; ++r)
+            check(hgi_encode_u8_dev(ctx.get(), d_in, image.width, image.height, (uint32_t)levels, I::kernel_id,
+                                    table.data(), d_out, 1, size));
+        check(hgi_sync(ctx.get()));
+    });
+    report(name, "device", sec / reps, size);
+}
+
+int main()
+{
+    const uint32_t width = 1920, height = 1080;
+    const size_t size = size_t(width) * height, levels = 4;
+    GrayImage image = get_test_image(width, height);
+    Context &ctx = Context::global();
+    void *d_a = nullptr, *d_b = nullptr;
+    if (hipMalloc(&d_a, size) != hipSuccess || hipMalloc(&d_b, size) != hipSuccess) return 2;
+    (void)hipMemcpy(d_a, image.data.data(), size, hipMemcpyHostToDevice);
+    check(hgi_ctx_reserve(ctx.get(), width, height, (uint32_t)levels, 1));
+
+    {   // `memory` (benches/bench.rs:38-52): copy_nonoverlapping of one frame
+        std::vector<uint8_t> v(size), mem(size);
+        for (size_t i = 0; i < size; ++i) v[i] = (uint8_t)i;
+        report("memory", "host", median_seconds(25, [&] { std::memcpy(mem.data(), v.data(), size); }), size);
+        const int reps = 50;
+        double sec = median_seconds(25, [&] {
+            for (int r = 0; r < reps; ++r) check(hgi_copy_u8_dev(ctx.get(), d_a, d_b, size));
+            check(hgi_sync(ctx.get()));
+        });
+        report("memory", "device", sec / reps, size);
+    }
+    using namespace quantizator;
+    using namespace interpolator;
+    bench_encode<LeftTop>("left_top_nop_encode", NoOp{}, image, levels, d_a, d_b);                                  // :54-63
+    bench_encode<LeftTop>("left_top_quanted_encode", Linear::from(QuantizationLevel::Lossless), image, levels, d_a, d_b);  // :65-74
+    bench_encode<Crossed>("crossed_nop_encode", NoOp{}, image, levels, d_a, d_b);                                   // :76-85
+    bench_encode<Crossed>("crossed_quanted_encode", Linear::from(QuantizationLevel::Lossless), image, levels, d_a, d_b);   // :87-96
+    {   // `decode` (benches/bench.rs:98-110)
+        Encoder<Crossed, Linear> encoder(Crossed{}, Linear::from(QuantizationLevel::Lossless), levels);
+        Grid grid = encoder.encode(image);
+        Decoder<Crossed> decoder(Crossed{});
+        report("decode", "host", median_seconds(25, [&] { (void)decoder.decode({width, height}, levels, grid); }), size);
+        (void)hipMemcpy(d_a, grid.buffer.data(), size, hipMemcpyHostToDevice);
+        const int reps = 20;
+        double sec = median_seconds(25, [&] {
+            for (int r = 0; r < reps; ++r)
+                check(hgi_decode_u8_dev(ctx.get(), d_a, width, height, (uint32_t)levels, HGI_INTERP_CROSSED, d_b, 1, size));
+            check(hgi_sync(ctx.get()));
+        });
+        report("decode", "device", sec / reps, size);
+        GrayImage back(width, height);
+        (void)hipMemcpy(back.data.data(), d_b, size, hipMemcpyDeviceToHost);
+        std::printf("lossless round trip exact: %s\n", back == image ? "yes" : "NO");
+    }
+    (void)hipFree(d_a);
+    (void)hipFree(d_b);
+    return 0;
+}

@@ -9,7 +9,7 @@ import os
 import sys
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libhgi_hip.so")
+LIB_PATH = os.environ.get("HGI_LIB_PATH") or os.path.join(_HERE, "libhgi_hip.so")
 
 OK, EINVAL, ENOMEM, EDEVICE, EUNSUPPORTED = 0, 1, 2, 3, 4
 PATH_AUTO, PATH_LEVELWISE, PATH_FUSED = 0, 1, 2

@@ -15,11 +15,19 @@
 //     Level sub == 2 (19 %): four cells per lane, packed v_lerp_u8 predictor, 16-B LDS accesses.
 //     Level sub == 1 (75 %): 16 px x 2 rows per lane from LDS through packed-u8 VALU arithmetic
 //     straight to 16-B buffer stores.
-//   * Interior tiles (tile body inside the image) take a check-free path built on buffer loads whose
-//     hardware range check returns 0 beyond the frame -- exactly the reference's out-of-image rule
-//     (src/interpolator.rs:75-82).  Ragged tiles and unaligned widths take the generic path below.
+//   * Interior tiles (tile body inside the image) run in PERSISTENT waves: the next tile's body and
+//     halo are loaded into registers right before the current tile is computed out of LDS, so every
+//     wave keeps ~9 KB of HBM reads in flight during its whole compute phase.  Buffer loads with the
+//     hardware range check return 0 beyond the frame -- exactly the reference's out-of-image rule
+//     (src/interpolator.rs:75-82).  Ragged tiles and unaligned widths go to a separate, fully checked
+//     per-tile kernel (k_*_edge).
 //
 // All arithmetic is u8/integer; there is no MFMA-shaped work on this path.
+#include <stdio.h>
+#include <stdlib.h>
+
+#include <mutex>
+
 #include "hgi_dev.h"
 
 namespace hgi {
@@ -32,17 +40,33 @@ constexpr int TH = kTileH;
 constexpr int NL = kThreads;       // lanes
 constexpr int CH = TW / 16;        // 16-B chunks per tile row
 constexpr int LCH = 3;             // log2(CH)
-constexpr int HR = 8;              // reserved halo rows / columns (>= kFusedMaxLevels)
-constexpr int S = TW + 16;         // LDS pitch, full-resolution plane (halo columns live at TW + idx)
-constexpr int R = TH + HR;         // LDS rows (halo rows live at TH + idx)
-constexpr int S2 = TW / 2 + 16;    // LDS pitch, half-resolution plane (encode: reconstruction lattice)
+constexpr int HR = kFusedMaxLevels;   // halo rows / columns a tile can need (offsets 0,4,8,16,32,64)
+// LDS layout (bank-conflict model and measurements: DESIGN.md "LDS layout").
+//   full-resolution plane: R rows (halo rows live at TH + idx) of pitch S.  S = 160 B makes rows that
+//   are 4 apart differ by 32 banks, which is what keeps the 16-B accesses of the two packed levels
+//   conflict-free (their lanes are mapped to rows 4 apart within each half-wave);
+//   halo COLUMNS live transposed behind it: hcol[idx * HP + row], so that the lanes of a halo cell
+//   pass (one lane per row) touch consecutive bytes instead of one bank.
+constexpr int S = TW + 32;
+constexpr int R = TH + HR;
+constexpr int HP = 80;             // >= R
+constexpr int HCOL = R * S;        // byte offset of the transposed halo columns
+constexpr int BUF_BYTES = HCOL + HR * HP;
+//   half-resolution plane (encode: reconstruction of the even/even lattice), same scheme
+constexpr int S2 = TW / 2 + 32;
 constexpr int R2 = TH / 2 + HR;
+constexpr int HP2 = 48;            // >= R2
+constexpr int RCOL = R2 * S2;
+constexpr int RBUF_BYTES = RCOL + HR * HP2;
 
 static_assert(NL == 64 && CH == (1 << LCH) && (TH & (TH - 1)) == 0 && (1 << kFusedMaxLevels) <= TH, "tile geometry");
-static_assert(S % 16 == 0 && S2 % 8 == 0 && (R2 * S2) % 16 == 0, "LDS pitches keep vector alignment");
+static_assert(S % 16 == 0 && S2 % 8 == 0 && HCOL % 16 == 0 && RCOL % 16 == 0 && RBUF_BYTES % 16 == 0 && HP >= R &&
+                  HP2 >= R2,
+              "LDS pitches keep vector alignment");
 
 typedef u32 v4u __attribute__((ext_vector_type(4)));
 typedef u32 v2u __attribute__((ext_vector_type(2)));
+typedef u32 v3u __attribute__((ext_vector_type(3)));
 
 // dst.byte[K] = (dst.byte[K] + src.byte[J]) mod 256, other bytes of dst preserved (one SDWA VALU op)
 #define HGI_ADDB(dst, K, src, J)                                                                    \
@@ -95,32 +119,67 @@ typedef unsigned long long lanemask;
 // rows/columns are stored compactly at index hmap(offset).
 __device__ __forceinline__ int hmap(int off) { return off ? 30 - __clz(off) : 0; }   // 4->1, 8->2 ...
 __device__ __forceinline__ int hoff(int idx) { return idx ? 2 << idx : 0; }           // 1->4, 2->8 ...
-__device__ __forceinline__ int lcol(int x) { return x < TW ? x : TW + hmap(x - TW); }
 __device__ __forceinline__ int lrow(int y) { return y < TH ? y : TH + hmap(y - TH); }
-__device__ __forceinline__ int lcol2(int x) { return x < TW ? x >> 1 : TW / 2 + hmap(x - TW); }
 __device__ __forceinline__ int lrow2(int y) { return y < TH ? y >> 1 : TH / 2 + hmap(y - TH); }
+// byte offset of pixel (x, y) of the tile (halo included) in the full- / half-resolution plane
+__device__ __forceinline__ int laddr(int x, int y) { return x < TW ? lrow(y) * S + x : HCOL + hmap(x - TW) * HP + lrow(y); }
+__device__ __forceinline__ int laddr2(int x, int y)
+{
+    return x < TW ? lrow2(y) * S2 + (x >> 1) : RCOL + hmap(x - TW) * HP2 + lrow2(y);
+}
+// value of lane + 1 (within rows of 16 lanes): the first dword of the next 16-B chunk of the same row
+__device__ __forceinline__ u32 from_next_lane(u32 v) { return (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x101, 0xF, 0xF, true); }
 
 struct Tile {
     u32 frame, X0, Y0;
 };
 
-// XCD-aware block -> tile map.  Workgroups are dealt round-robin over the 8 XCDs (b % 8), so giving
-// XCD x the x-th contiguous eighth of the row-major tile list makes x-neighbours (which share halo
-// lines) land in the same XCD's L2.  Speed only, never correctness.
-__device__ __forceinline__ Tile tile_of_block(u32 ntiles, u32 tiles_x, u32 tiles_y)
+// Persistent waves pull tiles from a work queue: one counter per XCD-range of the row-major tile
+// list (workgroups are dealt round-robin over the 8 XCDs, so b % 8 labels the XCD a block runs on;
+// neighbours in the list are neighbours in the image, so the halo lines they share meet in that
+// XCD's L2).  A block drains its home range first and then steals from the other ranges, so the
+// launch ends within one tile time of the last pull whatever the placement of the blocks.  Every
+// pull is one returning agent-scope atomic add by lane 0; each counter sees exactly
+// (tiles in range + grid size) pulls per launch.  Speed only, never correctness: any block may
+// process any tile.
+constexpr u32 kNoTile = 0xFFFFFFFFu;
+constexpr u32 kQueueStrideWords = 32;   // one 128-B line per counter
+
+struct Queue {
+    u32 *ctr;        // 8 counters, zeroed before the launch (nullptr: static one-tile-per-block mode)
+    u32 ntiles;
+    u32 home;        // range being drained: (blockIdx.x + tries) & 7
+    u32 tries;       // ranges exhausted so far
+};
+
+__device__ __forceinline__ u32 range_first(u32 ntiles, u32 x) { return x * (ntiles >> 3) + (x < (ntiles & 7u) ? x : (ntiles & 7u)); }
+__device__ __forceinline__ u32 range_count(u32 ntiles, u32 x) { return (ntiles >> 3) + (x < (ntiles & 7u) ? 1u : 0u); }
+
+// raw ticket from the range currently being drained (asynchronous: consumed one tile later)
+__device__ __forceinline__ u32 queue_pull(const Queue &q)
 {
-    u32 b = blockIdx.x;
-    u32 q = ntiles >> 3, r = ntiles & 7u, xcd = b & 7u, i = b >> 3;
-    u32 t = xcd * q + (xcd < r ? xcd : r) + i;
-    u32 tpf = tiles_x * tiles_y;
-    Tile tl;
-    tl.frame = t / tpf;
-    u32 tt = t - tl.frame * tpf;
-    u32 ty = tt / tiles_x;
-    tl.X0 = (tt - ty * tiles_x) * TW;
-    tl.Y0 = ty * TH;
-    return tl;
+    u32 v = 0;
+    if (threadIdx.x == 0)
+        v = __hip_atomic_fetch_add(q.ctr + q.home * kQueueStrideWords, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return __builtin_amdgcn_readfirstlane(v);
 }
+
+// ticket -> tile index; moves on to the next range (synchronous pulls) when the current one is empty
+__device__ __forceinline__ u32 queue_resolve(Queue &q, u32 ticket)
+{
+    for (;;) {
+        if (ticket < range_count(q.ntiles, q.home)) return range_first(q.ntiles, q.home) + ticket;
+        if (++q.tries >= 8u) return kNoTile;
+        q.home = (q.home + 1u) & 7u;
+        ticket = queue_pull(q);
+    }
+}
+
+// Compile-time ordering point for the wave's LDS traffic.  A wave's LDS instructions execute in
+// order, so a ds_read issued after a ds_write sees it without any wait; the compiler only has to be
+// kept from moving accesses across (it cannot see that lanes exchange data).  Unlike
+// __syncthreads() this does NOT drain vmcnt: the next tile's prefetch stays in flight.
+#define LDS_ORDER() asm volatile("" ::: "memory")
 
 // =============================================================================================
 // GENERIC PATH (ragged tiles, unaligned widths): every access checked against the image
@@ -170,14 +229,14 @@ __device__ __noinline__ void stage_tile_generic(u8 *buf, const u8 *__restrict__ 
     }
     // halo columns TW + {0,4,8,..} (and the halo x halo corner block): byte gathers.  Column offset
     // `off` is only ever touched on rows = 0 (mod max(off, 2)).
-    for (int i = lane; i < HR * (TH + nh); i += NL) {
-        int hc = i & (HR - 1), rr = i >> 3;
+    for (int i = lane; i < 8 * (TH + nh); i += NL) {
+        int hc = i & 7, rr = i >> 3;
         if (hc >= nh) continue;
         int off = hoff(hc);
         int y = rr < TH ? rr : TH + hoff(rr - TH);
         if (rr < TH && (y & ((off ? off : 2) - 1))) continue;
         u32 gx = tl.X0 + TW + off, gy = tl.Y0 + y;
-        buf[rr * S + TW + hc] = (gx < W && gy < H) ? fr[(size_t)gy * W + gx] : (u8)0;
+        buf[HCOL + hc * HP + rr] = (gx < W && gy < H) ? fr[(size_t)gy * W + gx] : (u8)0;
     }
 }
 
@@ -195,14 +254,14 @@ __device__ __forceinline__ void dec_halo_cells(u8 *buf, int s, Tile tl, u32 W, u
         int x0 = j <= ncy ? TW : (j - ncy - 1) << lstep;
         int y0 = j <= ncy ? j << lstep : TH;
         if (tl.X0 + x0 >= W || tl.Y0 + y0 >= H) continue;
-        int r0 = lrow(y0) * S, r1 = lrow(y0 + step) * S, c0 = lcol(x0), c1 = lcol(x0 + step);
-        u32 p = pred1<INTERP>(buf[r0 + c0], buf[r1 + c0], buf[r0 + c1], buf[r1 + c1]);
+        u32 p = pred1<INTERP>(buf[laddr(x0, y0)], buf[laddr(x0, y0 + step)], buf[laddr(x0 + step, y0)],
+                              buf[laddr(x0 + step, y0 + step)]);
         bool xin = x0 + s <= TW + lim && tl.X0 + x0 + s < W;
         bool yin = y0 + s <= TH + lim && tl.Y0 + y0 + s < H;
-        int rs = lrow(y0 + s) * S, cs = lcol(x0 + s);
-        if (xin) buf[r0 + cs] = (u8)(buf[r0 + cs] + p);
-        if (yin) buf[rs + c0] = (u8)(buf[rs + c0] + p);
-        if (xin && yin) buf[rs + cs] = (u8)(buf[rs + cs] + p);
+        const int as0 = laddr(x0 + s, y0), a0s = laddr(x0, y0 + s), ass = laddr(x0 + s, y0 + s);
+        if (xin) buf[as0] = (u8)(buf[as0] + p);
+        if (yin) buf[a0s] = (u8)(buf[a0s] + p);
+        if (xin && yin) buf[ass] = (u8)(buf[ass] + p);
     }
 }
 
@@ -216,26 +275,25 @@ __device__ __forceinline__ void enc_halo_cells(u8 *buf, u8 *rbuf, const u8 *slut
         int x0 = j <= ncy ? TW : (j - ncy - 1) << lstep;
         int y0 = j <= ncy ? j << lstep : TH;
         if (tl.X0 + x0 >= W || tl.Y0 + y0 >= H) continue;
-        int q0 = lrow2(y0) * S2, q1 = lrow2(y0 + step) * S2, d0 = lcol2(x0), d1 = lcol2(x0 + step);
-        u32 p = pred1<INTERP>(rbuf[q0 + d0], rbuf[q1 + d0], rbuf[q0 + d1], rbuf[q1 + d1]);
+        u32 p = pred1<INTERP>(rbuf[laddr2(x0, y0)], rbuf[laddr2(x0, y0 + step)], rbuf[laddr2(x0 + step, y0)],
+                              rbuf[laddr2(x0 + step, y0 + step)]);
         bool xin = x0 + s <= TW + lim && tl.X0 + x0 + s < W;
         bool yin = y0 + s <= TH + lim && tl.Y0 + y0 + s < H;
-        int r0 = lrow(y0) * S, rs = lrow(y0 + s) * S, c0 = lcol(x0), cs = lcol(x0 + s);
-        int qs = lrow2(y0 + s) * S2, ds = lcol2(x0 + s);
+        const int as0 = laddr(x0 + s, y0), a0s = laddr(x0, y0 + s), ass = laddr(x0 + s, y0 + s);
         if (xin) {
-            u32 q = quant1<IDENT>(buf[r0 + cs], p, slut);
-            buf[r0 + cs] = (u8)q;
-            rbuf[q0 + ds] = (u8)(p + q);
+            u32 q = quant1<IDENT>(buf[as0], p, slut);
+            buf[as0] = (u8)q;
+            rbuf[laddr2(x0 + s, y0)] = (u8)(p + q);
         }
         if (yin) {
-            u32 q = quant1<IDENT>(buf[rs + c0], p, slut);
-            buf[rs + c0] = (u8)q;
-            rbuf[qs + d0] = (u8)(p + q);
+            u32 q = quant1<IDENT>(buf[a0s], p, slut);
+            buf[a0s] = (u8)q;
+            rbuf[laddr2(x0, y0 + s)] = (u8)(p + q);
         }
         if (xin && yin) {
-            u32 q = quant1<IDENT>(buf[rs + cs], p, slut);
-            buf[rs + cs] = (u8)q;
-            rbuf[qs + ds] = (u8)(p + q);
+            u32 q = quant1<IDENT>(buf[ass], p, slut);
+            buf[ass] = (u8)q;
+            rbuf[laddr2(x0 + s, y0 + s)] = (u8)(p + q);
         }
     }
 }
@@ -251,7 +309,10 @@ __device__ __forceinline__ void dec_cells(u8 *buf, int s, Tile tl, u32 W, u32 H)
         int x0 = (i & (ncx - 1)) << lstep, y0 = (i >> lncx) << lstep;
         if (CHECK && (tl.X0 + x0 >= W || tl.Y0 + y0 >= H)) continue;
         u8 *c = buf + y0 * S + x0;
-        u32 p = pred1<INTERP>(c[0], c[step * S], c[step], c[step * S + step]);
+        // right-hand corners of the last cell column are halo column 0 (transposed); y0 + step <= TH is a natural row
+        const u8 *cr = x0 + step < TW ? c + step : buf + HCOL + y0;
+        const int dn = x0 + step < TW ? step * S : step;
+        u32 p = pred1<INTERP>(c[0], c[step * S], cr[0], cr[dn]);
         bool xin = !CHECK || tl.X0 + x0 + s < W, yin = !CHECK || tl.Y0 + y0 + s < H;
         if (xin) c[s] = (u8)(c[s] + p);
         if (yin) c[s * S] = (u8)(c[s * S] + p);
@@ -272,7 +333,9 @@ __device__ __forceinline__ void enc_cells(u8 *buf, u8 *rbuf, const u8 *slut, int
         if (CHECK && (tl.X0 + x0 >= W || tl.Y0 + y0 >= H)) continue;
         u8 *c = buf + y0 * S + x0;
         u8 *rc = rbuf + (y0 >> 1) * S2 + (x0 >> 1);
-        u32 p = pred1<INTERP>(rc[0], rc[s * S2], rc[s], rc[s * S2 + s]);
+        const u8 *rr = x0 + step < TW ? rc + s : rbuf + RCOL + (y0 >> 1);
+        const int dn = x0 + step < TW ? s * S2 : s;
+        u32 p = pred1<INTERP>(rc[0], rc[s * S2], rr[0], rr[dn]);
         bool xin = !CHECK || tl.X0 + x0 + s < W, yin = !CHECK || tl.Y0 + y0 + s < H;
         if (xin) {
             u32 q = quant1<IDENT>(c[s], p, slut);
@@ -304,7 +367,7 @@ __device__ __noinline__ void dec_fine_generic(const u8 *buf, u8 *__restrict__ ou
         uint4 E = *reinterpret_cast<const uint4 *>(r0);
         uint4 O = *reinterpret_cast<const uint4 *>(r0 + S);
         uint4 F = *reinterpret_cast<const uint4 *>(r0 + 2 * S);
-        u32 e16 = r0[16], f16 = r0[2 * S + 16];
+        u32 e16 = x + 16 < TW ? r0[16] : buf[HCOL + y], f16 = x + 16 < TW ? r0[2 * S + 16] : buf[HCOL + y + 2];
         uint2 c, fl;
         c.x = __builtin_amdgcn_perm(E.y, E.x, 0x06040200u);
         c.y = __builtin_amdgcn_perm(E.w, E.z, 0x06040200u);
@@ -336,7 +399,7 @@ __device__ __noinline__ void enc_fine_generic(const u8 *buf, const u8 *rbuf, con
         uint4 O = *reinterpret_cast<const uint4 *>(r0 + S);
         uint2 c = *reinterpret_cast<const uint2 *>(c0);
         uint2 fl = *reinterpret_cast<const uint2 *>(c0 + S2);
-        u32 c8 = c0[8], f8 = c0[S2 + 8];
+        u32 c8 = x + 16 < TW ? c0[8] : rbuf[RCOL + (y >> 1)], f8 = x + 16 < TW ? c0[S2 + 8] : rbuf[RCOL + (y >> 1) + 1];
         u32 P0, P1;
         pred8<INTERP>(c, c8, fl, f8, P0, P1);
         u32 pp0 = __builtin_amdgcn_perm(P0, P0, 0x01010000u), pp1 = __builtin_amdgcn_perm(P0, P0, 0x03030202u);
@@ -364,43 +427,55 @@ struct Buf {
     u32 W, base;                 // base = Y0 * W + X0
 };
 
-// Tile body: 8 x 16-B loads per lane, all in flight before the first LDS write; halo rows as full
-// lines; halo columns by one lane per (even) row: one 16-B load holds offsets 0/4/8, single dwords
-// supply offsets 16/32/64.  Rows below the image return 0 from the buffer range check; columns right
-// of the image are masked with wave-uniform tests.
-__device__ __forceinline__ void stage_tile_fast(u8 *buf, const Buf &b, Tile tl, int k, int nh)
+// Everything a tile stages, held in registers between issue and commit (43 VGPRs): the next
+// tile's loads are issued right after the current tile's commit and stay in flight through the
+// whole compute phase of the current tile.
+struct Stage {
+    v4u v[TH / 8];      // tile body: 8 x 16 B per lane (8 full 128-B lines per wave instruction)
+    v4u hv;             // halo rows TH + {0,4,8,..}: full lines
+    v3u x0;             // halo columns: one lane per (even) row; this 12-B load holds offsets 0/4/8
+    u32 d16, d32, d64;  // ... and single dwords supply offsets 16/32/64
+};
+
+// Rows below the image return 0 from the buffer range check; columns right of the image are masked
+// with wave-uniform tests.
+__device__ __forceinline__ void stage_issue(Stage &st, const Buf &b, Tile tl, int k, int nh)
 {
     const int lane = threadIdx.x, c = lane & (CH - 1), r = lane >> LCH;
-    const u32 W = b.W;
+    const u32 W = __builtin_amdgcn_readfirstlane(b.W);   // soffset operands must be provably uniform
     const u32 voff = b.base + r * W + 16 * c;
-    v4u v[TH / 8];
 #pragma unroll
-    for (int j = 0; j < TH / 8; ++j) v[j] = __builtin_amdgcn_raw_buffer_load_b128(b.rs, voff, j * 8 * W, 0);
-    const bool hrow = lane < nh * CH;
-    v4u hv = {0, 0, 0, 0};
-    if (hrow) hv = __builtin_amdgcn_raw_buffer_load_b128(b.rs, b.base + (TH + hoff(r)) * W + 16 * c, 0, 0);
-    const bool xl = lane < TH / 2 + nh;
+    for (int j = 0; j < TH / 8; ++j) st.v[j] = __builtin_amdgcn_raw_buffer_load_b128(b.rs, voff, j * 8 * W, 0);
+    st.hv = v4u{0, 0, 0, 0};
+    if (lane < nh * CH) st.hv = __builtin_amdgcn_raw_buffer_load_b128(b.rs, b.base + (TH + hoff(r)) * W + 16 * c, 0, 0);
     const int hy = lane < TH / 2 ? 2 * lane : TH + hoff(lane - TH / 2);
     const u32 xo = b.base + hy * W + TW;
     const u32 xr = tl.X0 + TW;              // first column right of the tile
-    v4u x0 = {0, 0, 0, 0};
-    u32 d16 = 0, d32 = 0, d64 = 0;
-    if (xl) {
-        if (xr < W) x0 = __builtin_amdgcn_raw_buffer_load_b128(b.rs, xo, 0, 0);
-        if (k >= 4 && xr + 16 < W) d16 = __builtin_amdgcn_raw_buffer_load_b32(b.rs, xo + 16, 0, 0);
-        if (k >= 5 && xr + 32 < W) d32 = __builtin_amdgcn_raw_buffer_load_b32(b.rs, xo + 32, 0, 0);
-        if (k >= 6 && xr + 64 < W) d64 = __builtin_amdgcn_raw_buffer_load_b32(b.rs, xo + 64, 0, 0);
+    st.x0 = v3u{0, 0, 0};
+    st.d16 = st.d32 = st.d64 = 0;
+    if (lane < TH / 2 + nh) {
+        if (xr < W) st.x0 = __builtin_amdgcn_raw_buffer_load_b96(b.rs, xo, 0, 0);
+        if (k >= 4 && xr + 16 < W) st.d16 = __builtin_amdgcn_raw_buffer_load_b32(b.rs, xo + 16, 0, 0);
+        if (k >= 5 && xr + 32 < W) st.d32 = __builtin_amdgcn_raw_buffer_load_b32(b.rs, xo + 32, 0, 0);
+        if (k >= 6 && xr + 64 < W) st.d64 = __builtin_amdgcn_raw_buffer_load_b32(b.rs, xo + 64, 0, 0);
     }
+}
+
+__device__ __forceinline__ void stage_commit(u8 *buf, const Stage &st, int nh)
+{
+    const int lane = threadIdx.x, c = lane & (CH - 1), r = lane >> LCH;
 #pragma unroll
-    for (int j = 0; j < TH / 8; ++j) *reinterpret_cast<v4u *>(buf + (r + 8 * j) * S + 16 * c) = v[j];
-    if (hrow) *reinterpret_cast<v4u *>(buf + (TH + r) * S + 16 * c) = hv;
-    if (xl) {
-        // halo column slots TW + {0..5} <- offsets {0, 4, 8, 16, 32, 64}
-        v2u w;
-        w.x = __builtin_amdgcn_perm(x0.y, x0.x, 0x0c0c0400u) | __builtin_amdgcn_perm(d16, x0.z, 0x04000c0cu);
-        w.y = __builtin_amdgcn_perm(d64, d32, 0x0c0c0400u);
-        const int rr = lane < TH / 2 ? 2 * lane : TH + (lane - TH / 2);
-        *reinterpret_cast<v2u *>(buf + rr * S + TW) = w;
+    for (int j = 0; j < TH / 8; ++j) *reinterpret_cast<v4u *>(buf + (r + 8 * j) * S + 16 * c) = st.v[j];
+    if (lane < nh * CH) *reinterpret_cast<v4u *>(buf + (TH + r) * S + 16 * c) = st.hv;
+    if (lane < TH / 2 + nh) {
+        // transposed halo columns: slot {0..5} <- offsets {0, 4, 8, 16, 32, 64}, one byte per row
+        u8 *h = buf + HCOL + (lane < TH / 2 ? 2 * lane : TH + (lane - TH / 2));
+        h[0 * HP] = (u8)st.x0.x;
+        h[1 * HP] = (u8)st.x0.y;
+        h[2 * HP] = (u8)st.x0.z;
+        h[3 * HP] = (u8)st.d16;
+        h[4 * HP] = (u8)st.d32;
+        h[5 * HP] = (u8)st.d64;
     }
 }
 
@@ -421,7 +496,13 @@ __device__ __forceinline__ void dec_level2_fast(u8 *buf)
         v4u A = *reinterpret_cast<const v4u *>(r0);
         v4u B = *reinterpret_cast<const v4u *>(r0 + 2 * S);
         v4u C = *reinterpret_cast<const v4u *>(r0 + 4 * S);
-        u32 a16 = r0[16], c16 = r0[4 * S + 16];
+        // ninth corner of each row: first byte of the next chunk = lane + 1, or the halo column
+        const int y0 = 4 * (i >> LCH);
+        const bool last = (i & (CH - 1)) == CH - 1;
+        u32 a16 = from_next_lane(A.x), c16 = from_next_lane(C.x);
+        const u32 ha = buf[HCOL + y0], hc = buf[HCOL + y0 + 4];
+        a16 = last ? ha : a16;
+        c16 = last ? hc : c16;
         u32 ct = gather_b0(A), cb = gather_b0(C);
         u32 P = ct;
         if (INTERP == kInterpCrossed)
@@ -441,14 +522,22 @@ template <int INTERP>
 __device__ __forceinline__ void dec_fine_fast(const u8 *buf, const Buf &b)
 {
     const int lane = threadIdx.x;
-    const u8 *r0 = buf + 2 * (lane >> LCH) * S + 16 * (lane & (CH - 1));
-    u32 voff = b.base + 2 * (lane >> LCH) * b.W + 16 * (lane & (CH - 1));
+    // octets of a half-wave take row pairs 0,2,4,6 / 1,3,5,7: rows 4 apart = 32 banks apart (S = 160)
+    const int rp0 = 2 * ((lane >> LCH) & 3) + (lane >> 5);
+    const bool last = (lane & (CH - 1)) == CH - 1;
+    const u8 *r0 = buf + 2 * rp0 * S + 16 * (lane & (CH - 1));
+    const u8 *h0 = buf + HCOL + 2 * rp0;
+    u32 voff = b.base + 2 * rp0 * b.W + 16 * (lane & (CH - 1));
 #pragma unroll 2
-    for (int it = 0; it < (TH / 2) * CH / NL; ++it, r0 += 2 * (NL / CH) * S, voff += 2 * (NL / CH) * b.W) {
+    for (int it = 0; it < (TH / 2) * CH / NL; ++it, r0 += 2 * (NL / CH) * S, h0 += 2 * (NL / CH), voff += 2 * (NL / CH) * b.W) {
         v4u E = *reinterpret_cast<const v4u *>(r0);
         v4u O = *reinterpret_cast<const v4u *>(r0 + S);
         v4u F = *reinterpret_cast<const v4u *>(r0 + 2 * S);
-        u32 e16 = r0[16], f16 = r0[2 * S + 16];
+        // ninth corner of each lattice row: first byte of the next chunk = lane + 1, or the halo column
+        u32 e16 = from_next_lane(E.x), f16 = from_next_lane(F.x);
+        const u32 he = h0[0], hf = h0[2];
+        e16 = last ? he : e16;
+        f16 = last ? hf : f16;
         uint2 c, fl;
         c.x = __builtin_amdgcn_perm(E.y, E.x, 0x06040200u);
         c.y = __builtin_amdgcn_perm(E.w, E.z, 0x06040200u);
@@ -467,7 +556,7 @@ __device__ __forceinline__ void dec_fine_fast(const u8 *buf, const Buf &b)
         HGI_ADDB(o3, 0, P1, 2); HGI_ADDB(o3, 1, P1, 2); HGI_ADDB(o3, 2, P1, 3); HGI_ADDB(o3, 3, P1, 3);
         v4u r0v = {e0, e1, e2, e3}, r1v = {o0, o1, o2, o3};
         __builtin_amdgcn_raw_buffer_store_b128(r0v, b.rd, voff, 0, 0);
-        __builtin_amdgcn_raw_buffer_store_b128(r1v, b.rd, voff, b.W, 0);
+        __builtin_amdgcn_raw_buffer_store_b128(r1v, b.rd, voff, __builtin_amdgcn_readfirstlane(b.W), 0);
     }
 }
 
@@ -486,7 +575,11 @@ __device__ __forceinline__ void enc_level2_fast(u8 *buf, u8 *rbuf, const u8 *slu
         v4u B = *reinterpret_cast<const v4u *>(r0 + 2 * S);
         v2u cu = *reinterpret_cast<const v2u *>(q0);
         v2u cl = *reinterpret_cast<const v2u *>(q0 + 2 * S2);
-        u32 c8 = q0[8], l8 = q0[2 * S2 + 8];
+        const bool last = c == CH - 1;
+        u32 c8 = from_next_lane(cu.x), l8 = from_next_lane(cl.x);
+        const u32 hu = rbuf[RCOL + 2 * g], hl = rbuf[RCOL + 2 * g + 2];
+        c8 = last ? hu : c8;
+        l8 = last ? hl : l8;
         u32 ct = __builtin_amdgcn_perm(cu.y, cu.x, 0x06040200u), cb = __builtin_amdgcn_perm(cl.y, cl.x, 0x06040200u);
         u32 P = ct;
         if (INTERP == kInterpCrossed)
@@ -537,15 +630,23 @@ template <int INTERP, bool IDENT>
 __device__ __forceinline__ void enc_fine_fast(const u8 *buf, const u8 *rbuf, const u8 *slut, const Buf &b)
 {
     const int lane = threadIdx.x;
-    const u8 *r0 = buf + 2 * (lane >> LCH) * S + 16 * (lane & (CH - 1));
-    const u8 *c0 = rbuf + (lane >> LCH) * S2 + 8 * (lane & (CH - 1));
-    u32 voff = b.base + 2 * (lane >> LCH) * b.W + 16 * (lane & (CH - 1));
-    for (int it = 0; it < (TH / 2) * CH / NL; ++it, r0 += 2 * (NL / CH) * S, c0 += (NL / CH) * S2, voff += 2 * (NL / CH) * b.W) {
+    const int rp0 = 2 * ((lane >> LCH) & 3) + (lane >> 5);   // as in dec_fine_fast
+    const bool last = (lane & (CH - 1)) == CH - 1;
+    const u8 *r0 = buf + 2 * rp0 * S + 16 * (lane & (CH - 1));
+    const u8 *c0 = rbuf + rp0 * S2 + 8 * (lane & (CH - 1));
+    const u8 *h0 = rbuf + RCOL + rp0;
+    u32 voff = b.base + 2 * rp0 * b.W + 16 * (lane & (CH - 1));
+#pragma unroll 1
+    for (int it = 0; it < (TH / 2) * CH / NL;
+         ++it, r0 += 2 * (NL / CH) * S, c0 += (NL / CH) * S2, h0 += NL / CH, voff += 2 * (NL / CH) * b.W) {
         v4u E = *reinterpret_cast<const v4u *>(r0);
         v4u O = *reinterpret_cast<const v4u *>(r0 + S);
         uint2 c = *reinterpret_cast<const uint2 *>(c0);
         uint2 fl = *reinterpret_cast<const uint2 *>(c0 + S2);
-        u32 c8 = c0[8], f8 = c0[S2 + 8];
+        u32 c8 = from_next_lane(c.x), f8 = from_next_lane(fl.x);
+        const u32 hc = h0[0], hf = h0[1];
+        c8 = last ? hc : c8;
+        f8 = last ? hf : f8;
         u32 P0, P1;
         pred8<INTERP>(c, c8, fl, f8, P0, P1);
         u32 e0 = E.x, e1 = E.y, e2 = E.z, e3 = E.w, g0 = O.x, g1 = O.y, g2 = O.z, g3 = O.w;
@@ -568,194 +669,457 @@ __device__ __forceinline__ void enc_fine_fast(const u8 *buf, const u8 *rbuf, con
         }
         v4u o0 = {e0, e1, e2, e3}, o1 = {g0, g1, g2, g3};
         __builtin_amdgcn_raw_buffer_store_b128(o0, b.rd, voff, 0, 0);
-        __builtin_amdgcn_raw_buffer_store_b128(o1, b.rd, voff, b.W, 0);
+        __builtin_amdgcn_raw_buffer_store_b128(o1, b.rd, voff, __builtin_amdgcn_readfirstlane(b.W), 0);
     }
+}
+
+// Descriptors are built from values forced wave-uniform (readfirstlane): once they are loop-carried
+// the compiler can no longer prove it, and would wrap every buffer access in a waterfall loop.
+__device__ __forceinline__ u8 *uniform_ptr(const u8 *p)
+{
+    const u64 a = reinterpret_cast<u64>(p);
+    const u32 lo = __builtin_amdgcn_readfirstlane((u32)a), hi = __builtin_amdgcn_readfirstlane((u32)(a >> 32));
+    return reinterpret_cast<u8 *>(((u64)hi << 32) | lo);
 }
 
 __device__ __forceinline__ Buf make_buf(const u8 *fr, u8 *out, u32 W, u32 H, Tile tl)
 {
     Buf b;
     const u32 bytes = W * H;   // the host only selects the fast path when this (plus the halo) fits 32 bits
-    b.rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<u8 *>(fr), 0, bytes, 0x00020000);
-    b.rd = __builtin_amdgcn_make_buffer_rsrc(out, 0, bytes, 0x00020000);
+    b.rs = __builtin_amdgcn_make_buffer_rsrc(uniform_ptr(fr), 0, bytes, 0x00020000);
+    b.rd = __builtin_amdgcn_make_buffer_rsrc(uniform_ptr(out), 0, bytes, 0x00020000);
     b.W = W;
-    b.base = tl.Y0 * W + tl.X0;
+    b.base = __builtin_amdgcn_readfirstlane(tl.Y0 * W + tl.X0);
     return b;
 }
 
 // ---------------------------------------------------------------------------------------------
 // kernels
 // ---------------------------------------------------------------------------------------------
-// flags bit 0: rows are 16-B aligned (width % 16 == 0, aligned pointers and frame stride)
-//       bit 1: 32-bit buffer offsets are safe for this frame size (fast path allowed)
-template <int INTERP, bool SEEDED>
-__global__ __launch_bounds__(NL) void k_dec_fused(const u8 *__restrict__ src, u8 *__restrict__ dst, Frames f, u32 k,
-                                                  Seeds sd, u32 tiles_x, u32 tiles_y, u32 ntiles, u32 flags)
+// Tile lists.  `full_x` x `full_y` tiles per frame lie entirely inside the image: the fast kernels walk
+// those; the edge kernels take the rest (right column first, then the bottom rows).
+struct TileGrid {
+    u32 tiles_x, tiles_y;   // all tiles of a frame
+    u32 full_x, full_y;     // tiles whose 128x64 body is inside the image (0 x 0 when the fast path is off)
+    u32 nfast, nedge;       // totals over the batch
+};
+
+__device__ __forceinline__ Tile fast_tile(u32 t, const TileGrid &g)
 {
-    __shared__ __attribute__((aligned(16))) u8 buf[R * S];
-    const int lane = threadIdx.x;
-    const Tile tl = tile_of_block(ntiles, tiles_x, tiles_y);
+    t = __builtin_amdgcn_readfirstlane(t);
+    const u32 tpf = g.full_x * g.full_y;
+    Tile tl;
+    tl.frame = t / tpf;
+    const u32 tt = t - tl.frame * tpf, ty = tt / g.full_x;
+    tl.X0 = (tt - ty * g.full_x) * TW;
+    tl.Y0 = ty * TH;
+    return tl;
+}
+
+__device__ __forceinline__ Tile edge_tile(u32 e, const TileGrid &g)
+{
+    const u32 right = (g.tiles_x - g.full_x) * g.tiles_y;          // tiles with tx >= full_x
+    const u32 epf = right + g.full_x * (g.tiles_y - g.full_y);     // + tiles with ty >= full_y, tx < full_x
+    Tile tl;
+    tl.frame = e / epf;
+    u32 i = e - tl.frame * epf, tx, ty;
+    if (i < right) {
+        const u32 w = g.tiles_x - g.full_x;
+        ty = i / w;
+        tx = g.full_x + (i - ty * w);
+    } else {
+        i -= right;
+        ty = g.full_y + i / g.full_x;
+        tx = i % g.full_x;
+    }
+    tl.X0 = tx * TW;
+    tl.Y0 = ty * TH;
+    return tl;
+}
+
+struct TileCtx {
+    Tile tl;
+    Buf b;
+};
+
+__device__ __forceinline__ TileCtx fast_ctx(u32 t, const u8 *src, u8 *dst, const Frames &f, const TileGrid &g)
+{
+    TileCtx c;
+    c.tl = fast_tile(t, g);
+    c.b = make_buf(src + (size_t)c.tl.frame * f.frame_stride, dst + (size_t)c.tl.frame * f.frame_stride, f.width,
+                   f.height, c.tl);
+    return c;
+}
+
+// ---- decode ---------------------------------------------------------------------------------------
+template <int INTERP, bool SEEDED>
+__device__ __forceinline__ void dec_seed(u8 *buf, const Seeds &sd, Tile tl, u32 k)
+{
+    if (!SEEDED) return;
+    // lattice points = 0 (mod 2^k) come from the already decoded coarser pyramid
+    const int ext = k >= 2 ? 2 : 1;   // offset 2^k beyond the tile is only ever read for k >= 2
+    const int nbx = (TW >> k) + ext, nby = (TH >> k) + ext;
+    const u8 *sp = sd.rec + (size_t)tl.frame * sd.stride;
+    for (int i = threadIdx.x; i < nbx * nby; i += NL) {
+        int by = i / nbx, bx = i - by * nbx;
+        u32 sx = (tl.X0 >> k) + bx, sy = (tl.Y0 >> k) + by;
+        u8 v = (sx < sd.sw && sy < sd.sh) ? sp[(size_t)sy * sd.sw + sx] : (u8)0;
+        buf[laddr(bx << k, by << k)] = v;
+    }
+    LDS_ORDER();
+}
+
+// One tile of the fast path, out of LDS: levels sub = 2^(k-1) .. 2 in place, then the finest level to HBM.
+template <int INTERP, bool SEEDED>
+__device__ __forceinline__ void dec_tile_fast(u8 *buf, const TileCtx &cur, const Seeds &sd, u32 k, u32 W, u32 H)
+{
+    dec_seed<INTERP, SEEDED>(buf, sd, cur.tl, k);
+    for (int s = 1 << (k - 1); s >= 2; s >>= 1) {
+        if (s == 2)
+            dec_level2_fast<INTERP>(buf);
+        else
+            dec_cells<INTERP, false>(buf, s, cur.tl, W, H);
+        dec_halo_cells<INTERP>(buf, s, cur.tl, W, H);
+        LDS_ORDER();
+    }
+    dec_fine_fast<INTERP>(buf, cur.b);
+}
+
+// PERSIST = false (default): one block per tile, XCD-contiguous order; fresh waves keep the CU's
+// phases naturally staggered.  PERSIST = true: resident waves pull tiles from the work queue and
+// prefetch the next tile into registers while computing the current one (measured, not faster on
+// MI355X for this kernel: DESIGN.md "Scheduling").
+template <int INTERP, bool SEEDED, bool PERSIST>
+__global__ __launch_bounds__(NL) void k_dec_fast(const u8 *__restrict__ src, u8 *__restrict__ dst, Frames f, u32 k,
+                                                 Seeds sd, TileGrid g, u32 *queue)
+{
+    __shared__ __attribute__((aligned(16))) u8 buf[BUF_BYTES];
+    const u32 W = f.width, H = f.height;
+    const int nh = k >= 2 ? (int)k : 1;
+    if (!PERSIST) {
+        TileCtx cur = fast_ctx(range_first(g.nfast, blockIdx.x & 7u) + (blockIdx.x >> 3), src, dst, f, g);
+        Stage st;
+        stage_issue(st, cur.b, cur.tl, (int)k, nh);
+        stage_commit(buf, st, nh);
+        LDS_ORDER();
+        dec_tile_fast<INTERP, SEEDED>(buf, cur, sd, k, W, H);
+        return;
+    }
+    Queue q = {queue, g.nfast, blockIdx.x & 7u, 0u};
+    u32 t = queue_resolve(q, queue_pull(q));
+    if (t == kNoTile) return;
+    u32 ticket = queue_pull(q);
+    TileCtx cur = fast_ctx(t, src, dst, f, g);
+    {
+        Stage st;
+        stage_issue(st, cur.b, cur.tl, (int)k, nh);
+        stage_commit(buf, st, nh);
+    }
+    for (;;) {
+        // straight line per tile: issue(next) -> compute(current) -> commit(next).  The loads are older
+        // than this tile's stores, so the wait in commit never has to drain a store.
+        const u32 tn = queue_resolve(q, ticket);
+        const bool more = tn != kNoTile;
+        TileCtx nxt = cur;
+        Stage st;
+        if (more) {
+            nxt = fast_ctx(tn, src, dst, f, g);
+            stage_issue(st, nxt.b, nxt.tl, (int)k, nh);
+            ticket = queue_pull(q);   // consumed one tile later: its latency hides under this tile
+        }
+        LDS_ORDER();
+        dec_tile_fast<INTERP, SEEDED>(buf, cur, sd, k, W, H);
+        LDS_ORDER();   // the commit below overwrites what the fine level just read
+        if (!more) break;
+        stage_commit(buf, st, nh);
+        cur = nxt;
+    }
+}
+
+template <int INTERP, bool SEEDED>
+__global__ __launch_bounds__(NL) void k_dec_edge(const u8 *__restrict__ src, u8 *__restrict__ dst, Frames f, u32 k,
+                                                 Seeds sd, TileGrid g, u32 aligned)
+{
+    __shared__ __attribute__((aligned(16))) u8 buf[BUF_BYTES];
+    const Tile tl = edge_tile(blockIdx.x, g);
     const u32 W = f.width, H = f.height;
     const u8 *fr = src + (size_t)tl.frame * f.frame_stride;
     u8 *out = dst + (size_t)tl.frame * f.frame_stride;
     const int nh = k >= 2 ? (int)k : 1;
-    const bool aligned = (flags & 1u) != 0;
-    const bool fast = flags == 3u && tl.X0 + TW <= W && tl.Y0 + TH <= H;
-    const Buf b = make_buf(fr, out, W, H, tl);
-
-    if (fast)
-        stage_tile_fast(buf, b, tl, (int)k, nh);
-    else
-        stage_tile_generic(buf, fr, W, H, tl, nh, aligned);
-    __syncthreads();   // one wave per workgroup: an LDS-ordering point, not a hardware barrier
-    if (SEEDED) {
-        // lattice points = 0 (mod 2^k) come from the already decoded coarser pyramid
-        const int ext = k >= 2 ? 2 : 1;   // offset 2^k beyond the tile is only ever read for k >= 2
-        const int nbx = (TW >> k) + ext, nby = (TH >> k) + ext;
-        const u8 *sp = sd.rec + (size_t)tl.frame * sd.stride;
-        for (int i = lane; i < nbx * nby; i += NL) {
-            int by = i / nbx, bx = i - by * nbx;
-            u32 sx = (tl.X0 >> k) + bx, sy = (tl.Y0 >> k) + by;
-            u8 v = (sx < sd.sw && sy < sd.sh) ? sp[(size_t)sy * sd.sw + sx] : (u8)0;
-            buf[lrow(by << k) * S + lcol(bx << k)] = v;
-        }
-        __syncthreads();
-    }
+    stage_tile_generic(buf, fr, W, H, tl, nh, aligned != 0);
+    LDS_ORDER();
+    dec_seed<INTERP, SEEDED>(buf, sd, tl, k);
     for (int s = 1 << (k - 1); s >= 2; s >>= 1) {
-        if (fast) {
-            if (s == 2)
-                dec_level2_fast<INTERP>(buf);
-            else
-                dec_cells<INTERP, false>(buf, s, tl, W, H);
-        } else {
-            dec_cells<INTERP, true>(buf, s, tl, W, H);
-        }
+        dec_cells<INTERP, true>(buf, s, tl, W, H);
         dec_halo_cells<INTERP>(buf, s, tl, W, H);
-        __syncthreads();
+        LDS_ORDER();
     }
-    if (fast)
-        dec_fine_fast<INTERP>(buf, b);
-    else
-        dec_fine_generic<INTERP>(buf, out, tl, W, H, aligned);
+    dec_fine_generic<INTERP>(buf, out, tl, W, H, aligned != 0);
+}
+
+// ---- encode ---------------------------------------------------------------------------------------
+// lattice points = 0 (mod 2^k): reconstruction == original (src/encoder.rs:26-37), or the coarser
+// pyramid's reconstruction + residuals when this launch is the lower part of a deeper pyramid.
+template <bool SEEDED>
+__device__ __forceinline__ void enc_seed(u8 *buf, u8 *rbuf, const Seeds &sd, Tile tl, u32 k)
+{
+    const int ext = k >= 2 ? 2 : 1;
+    const int nbx = (TW >> k) + ext, nby = (TH >> k) + ext;
+    const u8 *sr = SEEDED ? sd.rec + (size_t)tl.frame * sd.stride : nullptr;
+    const u8 *sq = SEEDED ? sd.q + (size_t)tl.frame * sd.stride : nullptr;
+    for (int i = threadIdx.x; i < nbx * nby; i += NL) {
+        int by = i / nbx, bx = i - by * nbx;
+        int li = laddr(bx << k, by << k);
+        u8 rv = buf[li];
+        if (SEEDED) {
+            u32 sx = (tl.X0 >> k) + bx, sy = (tl.Y0 >> k) + by;
+            bool in = sx < sd.sw && sy < sd.sh;
+            rv = in ? sr[(size_t)sy * sd.sw + sx] : (u8)0;
+            buf[li] = in ? sq[(size_t)sy * sd.sw + sx] : (u8)0;
+        }
+        rbuf[laddr2(bx << k, by << k)] = rv;
+    }
+    LDS_ORDER();
+}
+
+// lattice points outside the image must read as 0 (src/interpolator.rs:75-82) and are never written
+__device__ __forceinline__ void clear_lattice(u8 *rbuf)
+{
+    for (int i = threadIdx.x; i < RBUF_BYTES / 16; i += NL) reinterpret_cast<uint4 *>(rbuf)[i] = make_uint4(0, 0, 0, 0);
 }
 
 template <int INTERP, bool IDENT, bool SEEDED>
-__global__ __launch_bounds__(NL) void k_enc_fused(const u8 *__restrict__ src, u8 *__restrict__ dst, Frames f, u32 k,
-                                                  Lut256 lut, Seeds sd, u32 tiles_x, u32 tiles_y, u32 ntiles,
-                                                  u32 flags)
+__device__ __forceinline__ void enc_tile_fast(u8 *buf, u8 *rbuf, const u8 *slut, const TileCtx &cur, const Seeds &sd, u32 k,
+                                              u32 W, u32 H)
 {
-    __shared__ __attribute__((aligned(16))) u8 buf[R * S];
-    __shared__ __attribute__((aligned(16))) u8 rbuf[R2 * S2];
+    enc_seed<SEEDED>(buf, rbuf, sd, cur.tl, k);
+    for (int s = 1 << (k - 1); s >= 2; s >>= 1) {
+        if (s == 2)
+            enc_level2_fast<INTERP, IDENT>(buf, rbuf, slut);
+        else
+            enc_cells<INTERP, IDENT, false>(buf, rbuf, slut, s, cur.tl, W, H);
+        enc_halo_cells<INTERP, IDENT>(buf, rbuf, slut, s, cur.tl, W, H);
+        LDS_ORDER();
+    }
+    enc_fine_fast<INTERP, IDENT>(buf, rbuf, slut, cur.b);
+}
+
+template <int INTERP, bool IDENT, bool SEEDED, bool PERSIST>
+__global__ __launch_bounds__(NL) void k_enc_fast(const u8 *__restrict__ src, u8 *__restrict__ dst, Frames f, u32 k,
+                                                 Lut256 lut, Seeds sd, TileGrid g, u32 *queue)
+{
+    __shared__ __attribute__((aligned(16))) u8 buf[BUF_BYTES];
+    __shared__ __attribute__((aligned(16))) u8 rbuf[RBUF_BYTES];
     __shared__ __attribute__((aligned(16))) u8 slut[256];
-    const int lane = threadIdx.x;
-    const Tile tl = tile_of_block(ntiles, tiles_x, tiles_y);
+    const u32 W = f.width, H = f.height;
+    const int nh = k >= 2 ? (int)k : 1;
+    if (!IDENT) reinterpret_cast<u32 *>(slut)[threadIdx.x] = lut.w[threadIdx.x];
+    if (!PERSIST) {
+        TileCtx cur = fast_ctx(range_first(g.nfast, blockIdx.x & 7u) + (blockIdx.x >> 3), src, dst, f, g);
+        Stage st;
+        stage_issue(st, cur.b, cur.tl, (int)k, nh);
+        clear_lattice(rbuf);
+        stage_commit(buf, st, nh);
+        LDS_ORDER();
+        enc_tile_fast<INTERP, IDENT, SEEDED>(buf, rbuf, slut, cur, sd, k, W, H);
+        return;
+    }
+    Queue q = {queue, g.nfast, blockIdx.x & 7u, 0u};
+    u32 t = queue_resolve(q, queue_pull(q));
+    if (t == kNoTile) return;
+    u32 ticket = queue_pull(q);
+    TileCtx cur = fast_ctx(t, src, dst, f, g);
+    {
+        Stage st;
+        stage_issue(st, cur.b, cur.tl, (int)k, nh);
+        stage_commit(buf, st, nh);
+    }
+    for (;;) {
+        const u32 tn = queue_resolve(q, ticket);
+        const bool more = tn != kNoTile;
+        TileCtx nxt = cur;
+        Stage st;
+        if (more) {
+            nxt = fast_ctx(tn, src, dst, f, g);
+            stage_issue(st, nxt.b, nxt.tl, (int)k, nh);
+            ticket = queue_pull(q);
+        }
+        clear_lattice(rbuf);
+        LDS_ORDER();
+        enc_tile_fast<INTERP, IDENT, SEEDED>(buf, rbuf, slut, cur, sd, k, W, H);
+        LDS_ORDER();
+        if (!more) break;
+        stage_commit(buf, st, nh);
+        cur = nxt;
+    }
+}
+
+template <int INTERP, bool IDENT, bool SEEDED>
+__global__ __launch_bounds__(NL) void k_enc_edge(const u8 *__restrict__ src, u8 *__restrict__ dst, Frames f, u32 k,
+                                                 Lut256 lut, Seeds sd, TileGrid g, u32 aligned)
+{
+    __shared__ __attribute__((aligned(16))) u8 buf[BUF_BYTES];
+    __shared__ __attribute__((aligned(16))) u8 rbuf[RBUF_BYTES];
+    __shared__ __attribute__((aligned(16))) u8 slut[256];
+    const Tile tl = edge_tile(blockIdx.x, g);
     const u32 W = f.width, H = f.height;
     const u8 *fr = src + (size_t)tl.frame * f.frame_stride;
     u8 *out = dst + (size_t)tl.frame * f.frame_stride;
     const int nh = k >= 2 ? (int)k : 1;
-    const bool aligned = (flags & 1u) != 0;
-    const bool fast = flags == 3u && tl.X0 + TW <= W && tl.Y0 + TH <= H;
-    const Buf b = make_buf(fr, out, W, H, tl);
-
-    if (!IDENT) reinterpret_cast<u32 *>(slut)[lane] = lut.w[lane];
-    // lattice points outside the image must read as 0 (src/interpolator.rs:75-82) and are never written
-    for (int i = lane; i < R2 * S2 / 16; i += NL) reinterpret_cast<uint4 *>(rbuf)[i] = make_uint4(0, 0, 0, 0);
-    if (fast)
-        stage_tile_fast(buf, b, tl, (int)k, nh);
-    else
-        stage_tile_generic(buf, fr, W, H, tl, nh, aligned);
-    __syncthreads();
-    {
-        // lattice points = 0 (mod 2^k): reconstruction == original (src/encoder.rs:26-37), or the
-        // coarser pyramid's reconstruction + residuals when this launch is the lower part of a
-        // deeper pyramid.
-        const int ext = k >= 2 ? 2 : 1;
-        const int nbx = (TW >> k) + ext, nby = (TH >> k) + ext;
-        const u8 *sr = SEEDED ? sd.rec + (size_t)tl.frame * sd.stride : nullptr;
-        const u8 *sq = SEEDED ? sd.q + (size_t)tl.frame * sd.stride : nullptr;
-        for (int i = lane; i < nbx * nby; i += NL) {
-            int by = i / nbx, bx = i - by * nbx;
-            int li = lrow(by << k) * S + lcol(bx << k);
-            u8 rv = buf[li];
-            if (SEEDED) {
-                u32 sx = (tl.X0 >> k) + bx, sy = (tl.Y0 >> k) + by;
-                bool in = sx < sd.sw && sy < sd.sh;
-                rv = in ? sr[(size_t)sy * sd.sw + sx] : (u8)0;
-                buf[li] = in ? sq[(size_t)sy * sd.sw + sx] : (u8)0;
-            }
-            rbuf[lrow2(by << k) * S2 + lcol2(bx << k)] = rv;
-        }
-    }
-    __syncthreads();
+    if (!IDENT) reinterpret_cast<u32 *>(slut)[threadIdx.x] = lut.w[threadIdx.x];
+    clear_lattice(rbuf);
+    stage_tile_generic(buf, fr, W, H, tl, nh, aligned != 0);
+    LDS_ORDER();
+    enc_seed<SEEDED>(buf, rbuf, sd, tl, k);
     for (int s = 1 << (k - 1); s >= 2; s >>= 1) {
-        if (fast) {
-            if (s == 2)
-                enc_level2_fast<INTERP, IDENT>(buf, rbuf, slut);
-            else
-                enc_cells<INTERP, IDENT, false>(buf, rbuf, slut, s, tl, W, H);
-        } else {
-            enc_cells<INTERP, IDENT, true>(buf, rbuf, slut, s, tl, W, H);
-        }
+        enc_cells<INTERP, IDENT, true>(buf, rbuf, slut, s, tl, W, H);
         enc_halo_cells<INTERP, IDENT>(buf, rbuf, slut, s, tl, W, H);
-        __syncthreads();
+        LDS_ORDER();
     }
-    if (fast)
-        enc_fine_fast<INTERP, IDENT>(buf, rbuf, slut, b);
-    else
-        enc_fine_generic<INTERP, IDENT>(buf, rbuf, slut, out, tl, W, H, aligned);
+    enc_fine_generic<INTERP, IDENT>(buf, rbuf, slut, out, tl, W, H, aligned != 0);
 }
 
-struct FusedGeom {
-    u32 tiles_x, tiles_y, ntiles, flags;
-    bool ok;
-};
+// Persistent grid: one wave per slot the kernel can occupy on the current device (LDS-limited),
+// never more blocks than tiles.  Cached per (device, kernel).
+u32 persistent_grid(const void *kernel, u32 ntiles)
+{
+    struct Entry {
+        int dev;
+        const void *kernel;
+        u32 slots;
+    };
+    static std::mutex mu;
+    static Entry cache[64];
+    static int n = 0;
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    std::lock_guard<std::mutex> lock(mu);
+    u32 slots = 0;
+    for (int i = 0; i < n; ++i)
+        if (cache[i].dev == dev && cache[i].kernel == kernel) slots = cache[i].slots;
+    if (slots == 0) {
+        int cus = 0, per_cu = 0;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||
+            hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, NL, 0) != hipSuccess || cus <= 0 ||
+            per_cu <= 0) {
+            cus = 256;
+            per_cu = 8;
+        }
+        if (const char *e = getenv("HGI_WAVES_PER_CU")) {   // tuning / debugging knob
+            int v = atoi(e);
+            if (getenv("HGI_DEBUG")) fprintf(stderr, "[hgi] occupancy API: %d waves/CU x %d CUs; override %d\n", per_cu, cus, v);
+            if (v > 0) per_cu = v;
+        }
+        slots = (u32)cus * (u32)per_cu;
+        if (n < 64) cache[n++] = Entry{dev, kernel, slots};
+    }
+    return ntiles < slots ? ntiles : slots;
+}
+
+constexpr size_t kQueueBytes = 8 * kQueueStrideWords * sizeof(u32);
 
 inline bool ptr16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
+struct FusedGeom {
+    TileGrid g;
+    u32 aligned;
+    bool ok;
+};
+
 FusedGeom fused_geom(const void *a, const void *b, const Frames &f)
 {
-    FusedGeom g;
+    FusedGeom r;
+    TileGrid &g = r.g;
     g.tiles_x = (f.width + TW - 1) / TW;
     g.tiles_y = (f.height + TH - 1) / TH;
-    u64 nt = (u64)g.tiles_x * g.tiles_y * f.batch;
-    g.ok = nt > 0 && nt < (1ull << 31);
-    g.ntiles = (u32)nt;
     const bool aligned = f.width % 16 == 0 && f.frame_stride % 16 == 0 && ptr16(a) && ptr16(b);
     // every 32-bit buffer offset the fast path forms: (Y0 + TH + 64) * W + X0 + TW + 64 + 16
     const bool fits32 = ((u64)f.height + 2 * TH + 64) * f.width + 1024 < (1ull << 32);
-    g.flags = (aligned ? 1u : 0u) | (aligned && fits32 ? 2u : 0u);
-    return g;
+    const bool fast = aligned && fits32;
+    g.full_x = fast ? f.width / TW : 0;
+    g.full_y = fast ? f.height / TH : 0;
+    if (g.full_x == 0 || g.full_y == 0) g.full_x = g.full_y = 0;
+    const u64 all = (u64)g.tiles_x * g.tiles_y * f.batch, nfast = (u64)g.full_x * g.full_y * f.batch;
+    r.ok = all > 0 && all < (1ull << 31);
+    g.nfast = (u32)nfast;
+    g.nedge = (u32)(all - nfast);
+    r.aligned = aligned ? 1u : 0u;
+    return r;
+}
+
+// Grid + queue of a fast launch: persistent (<= resident slots, tiles pulled from `queue`) when there
+// are more tiles than slots and a queue buffer is available, else one block per tile.
+struct FastLaunch {
+    u32 blocks;
+    u32 *queue;
+};
+
+// `persistent_kernel` non-null and more tiles than resident slots: persistent launch.
+FastLaunch plan_fast(const void *persistent_kernel, u32 ntiles, u32 *queue, hipStream_t s, hipError_t *err)
+{
+    FastLaunch fl = {ntiles, nullptr};
+    if (!queue || !persistent_kernel) return fl;
+    const u32 slots = persistent_grid(persistent_kernel, ntiles);
+    if (slots < ntiles) {
+        *err = hipMemsetAsync(queue, 0, kQueueBytes, s);
+        fl.blocks = slots;
+        fl.queue = queue;
+    }
+    return fl;
 }
 
 }  // namespace
 
 hipError_t launch_decode_fused(const uint8_t *grid, uint8_t *img, const Frames &f, uint32_t k, int interp,
-                               const Seeds *seeds, hipStream_t s)
+                               const Seeds *seeds, uint32_t *queue, hipStream_t s)
 {
-    FusedGeom g = fused_geom(grid, img, f);
-    if (!g.ok || k < 1 || k > (u32)kFusedMaxLevels) return hipErrorInvalidValue;
+    FusedGeom r = fused_geom(grid, img, f);
+    if (!r.ok || k < 1 || k > (u32)kFusedMaxLevels) return hipErrorInvalidValue;
+    const TileGrid &g = r.g;
     Seeds sd = seeds ? *seeds : Seeds{nullptr, nullptr, 0, 0, 0};
-    dim3 gr(g.ntiles), b(NL);
-#define HGI_DEC(I, SE) \
-    hipLaunchKernelGGL((k_dec_fused<I, SE>), gr, b, 0, s, grid, img, f, k, sd, g.tiles_x, g.tiles_y, g.ntiles, g.flags)
+    dim3 b(NL);
+    hipError_t qerr = hipSuccess;
+#define HGI_DEC(I, SE)                                                                                              \
+    do {                                                                                                            \
+        if (g.nfast) {                                                                                              \
+            FastLaunch fl = plan_fast(reinterpret_cast<const void *>(&k_dec_fast<I, SE, true>), g.nfast, queue, s, &qerr); \
+            if (fl.queue)                                                                                           \
+                hipLaunchKernelGGL((k_dec_fast<I, SE, true>), dim3(fl.blocks), b, 0, s, grid, img, f, k, sd, g, fl.queue); \
+            else                                                                                                    \
+                hipLaunchKernelGGL((k_dec_fast<I, SE, false>), dim3(g.nfast), b, 0, s, grid, img, f, k, sd, g, nullptr); \
+        }                                                                                                           \
+        if (g.nedge) hipLaunchKernelGGL((k_dec_edge<I, SE>), dim3(g.nedge), b, 0, s, grid, img, f, k, sd, g, r.aligned); \
+    } while (0)
     if (interp == kInterpCrossed) {
         if (seeds) HGI_DEC(kInterpCrossed, true); else HGI_DEC(kInterpCrossed, false);
     } else {
         if (seeds) HGI_DEC(kInterpLeftTop, true); else HGI_DEC(kInterpLeftTop, false);
     }
 #undef HGI_DEC
-    return hipGetLastError();
+    return qerr != hipSuccess ? qerr : hipGetLastError();
 }
 
 hipError_t launch_encode_fused(const uint8_t *img, uint8_t *grid, const Frames &f, uint32_t k, int interp,
-                               const Lut256 &lut, bool ident, const Seeds *seeds, hipStream_t s)
+                               const Lut256 &lut, bool ident, const Seeds *seeds, uint32_t *queue, hipStream_t s)
 {
-    FusedGeom g = fused_geom(img, grid, f);
-    if (!g.ok || k < 1 || k > (u32)kFusedMaxLevels) return hipErrorInvalidValue;
+    FusedGeom r = fused_geom(img, grid, f);
+    if (!r.ok || k < 1 || k > (u32)kFusedMaxLevels) return hipErrorInvalidValue;
+    const TileGrid &g = r.g;
     Seeds sd = seeds ? *seeds : Seeds{nullptr, nullptr, 0, 0, 0};
-    dim3 gr(g.ntiles), b(NL);
-#define HGI_ENC(I, ID, SE) \
-    hipLaunchKernelGGL((k_enc_fused<I, ID, SE>), gr, b, 0, s, img, grid, f, k, lut, sd, g.tiles_x, g.tiles_y, g.ntiles, g.flags)
+    dim3 b(NL);
+    hipError_t qerr = hipSuccess;
+#define HGI_ENC(I, ID, SE)                                                                                          \
+    do {                                                                                                            \
+        if (g.nfast) {                                                                                              \
+            FastLaunch fl = plan_fast(reinterpret_cast<const void *>(&k_enc_fast<I, ID, SE, true>), g.nfast, queue, s, &qerr); \
+            if (fl.queue)                                                                                           \
+                hipLaunchKernelGGL((k_enc_fast<I, ID, SE, true>), dim3(fl.blocks), b, 0, s, img, grid, f, k, lut, sd, g, fl.queue); \
+            else                                                                                                    \
+                hipLaunchKernelGGL((k_enc_fast<I, ID, SE, false>), dim3(g.nfast), b, 0, s, img, grid, f, k, lut, sd, g, nullptr); \
+        }                                                                                                           \
+        if (g.nedge)                                                                                                \
+            hipLaunchKernelGGL((k_enc_edge<I, ID, SE>), dim3(g.nedge), b, 0, s, img, grid, f, k, lut, sd, g, r.aligned); \
+    } while (0)
 #define HGI_ENC_I(I)                                                          \
     do {                                                                      \
         if (ident) { if (seeds) HGI_ENC(I, true, true); else HGI_ENC(I, true, false); } \
@@ -764,7 +1128,7 @@ hipError_t launch_encode_fused(const uint8_t *img, uint8_t *grid, const Frames &
     if (interp == kInterpCrossed) HGI_ENC_I(kInterpCrossed); else HGI_ENC_I(kInterpLeftTop);
 #undef HGI_ENC_I
 #undef HGI_ENC
-    return hipGetLastError();
+    return qerr != hipSuccess ? qerr : hipGetLastError();
 }
 
 }  // namespace hgi

@@ -259,3 +259,18 @@ def test_error_paths_on_device(ctxs):
     assert L.hgi_decode_u8(ctx.handle, None, 8, 8, 2, 1, out.ctypes.data) == _ffi.EINVAL
     bad = ctypes.c_void_p()
     assert L.hgi_ctx_create(99, ctypes.byref(bad)) == _ffi.EDEVICE
+
+
+def test_cpp_mirror_lib_rs_port(H):
+    """The C++ host mirror (include/hgi.hpp): a port of the reference's own unit tests (src/lib.rs:45-125)
+    compiled against libhgi_hip.so and run here."""
+    import os
+    import subprocess
+    from conftest import ROOT
+    exe = os.path.join(ROOT, "tests", "cpp", "_test_lib")
+    subprocess.check_call(["g++", "-O1", "-std=c++17", "-I", os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "tests", "cpp", "test_lib.cpp"), "-L", os.path.join(ROOT, "rustyhgi_amd"),
+                           "-lhgi_hip", "-Wl,-rpath," + os.path.join(ROOT, "rustyhgi_amd"), "-o", exe])
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "ok:" in out.stdout
