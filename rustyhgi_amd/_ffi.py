@@ -99,9 +99,9 @@ class Context:
         self.handle, self.device = h, int(device)
 
     def close(self):
-        if getattr(self, "handle", None):
-            lib().hgi_ctx_destroy(self.handle)
-            self.handle = None
+        if getattr(self, "handle", None) and _lib is not None:
+            _lib.hgi_ctx_destroy(self.handle)
+        self.handle = None
 
     __del__ = close
 

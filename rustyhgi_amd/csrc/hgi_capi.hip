@@ -49,7 +49,6 @@ struct hgi_ctx {
     uint8_t *ws;
     size_t ws_bytes, ws_used;
     hipEvent_t ev0, ev1;
-    uint32_t *queue;   // work counters of the persistent fused kernels
 };
 
 namespace {
@@ -156,9 +155,9 @@ hgi_status encode_impl(hgi_ctx *c, const uint8_t *img, uint32_t w, uint32_t h, u
         HGI_TRY(encode_impl(c, sub_img, g.sw, g.sh, levels - k, interp, lut, sub_grid, batch, g.stride));
         HGI_TRY(decode_impl(c, sub_grid, g.sw, g.sh, levels - k, interp, sub_rec, batch, g.stride));
         Seeds sd = {sub_rec, sub_grid, g.sw, g.sh, g.stride};
-        HIP_TRY(launch_encode_fused(img, grid, f, k, interp, l, is_identity(lut), &sd, c->queue, c->stream));
+        HIP_TRY(launch_encode_fused(img, grid, f, k, interp, l, is_identity(lut), &sd, c->stream));
     } else {
-        HIP_TRY(launch_encode_fused(img, grid, f, k, interp, l, is_identity(lut), nullptr, c->queue, c->stream));
+        HIP_TRY(launch_encode_fused(img, grid, f, k, interp, l, is_identity(lut), nullptr, c->stream));
     }
     return HGI_OK;
 }
@@ -187,9 +186,9 @@ hgi_status decode_impl(hgi_ctx *c, const uint8_t *grid, uint32_t w, uint32_t h, 
         HIP_TRY(launch_gather_lattice(grid, f, k, sub_grid, g.sw, g.sh, g.stride, c->stream));
         HGI_TRY(decode_impl(c, sub_grid, g.sw, g.sh, levels - k, interp, sub_rec, batch, g.stride));
         Seeds sd = {sub_rec, nullptr, g.sw, g.sh, g.stride};
-        HIP_TRY(launch_decode_fused(grid, img, f, k, interp, &sd, c->queue, c->stream));
+        HIP_TRY(launch_decode_fused(grid, img, f, k, interp, &sd, c->stream));
     } else {
-        HIP_TRY(launch_decode_fused(grid, img, f, k, interp, nullptr, c->queue, c->stream));
+        HIP_TRY(launch_decode_fused(grid, img, f, k, interp, nullptr, c->stream));
     }
     return HGI_OK;
 }
@@ -239,14 +238,6 @@ hgi_status hgi_ctx_create(int device, hgi_ctx **out)
         return fail(HGI_EDEVICE, "stream/event creation failed");
     }
     c->stream = c->own_stream;
-    c->queue = nullptr;
-    // Experimental scheduling of the fused kernels (persistent waves + work queue); off by default:
-    // one block per tile measured faster on MI355X (DESIGN.md "Scheduling").
-    const char *persist = getenv("HGI_PERSISTENT");
-    if (persist && atoi(persist) > 0 && hipMalloc(reinterpret_cast<void **>(&c->queue), kFusedQueueBytes) != hipSuccess) {
-        hgi_ctx_destroy(c);
-        return fail(HGI_ENOMEM, "work-queue allocation failed");
-    }
     *out = c;
     return HGI_OK;
 }
@@ -257,7 +248,6 @@ void hgi_ctx_destroy(hgi_ctx *c)
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
     if (c->ws) (void)hipFree(c->ws);
-    if (c->queue) (void)hipFree(c->queue);
     (void)hipEventDestroy(c->ev0);
     (void)hipEventDestroy(c->ev1);
     (void)hipStreamDestroy(c->own_stream);

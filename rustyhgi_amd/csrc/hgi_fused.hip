@@ -15,19 +15,12 @@
 //     Level sub == 2 (19 %): four cells per lane, packed v_lerp_u8 predictor, 16-B LDS accesses.
 //     Level sub == 1 (75 %): 16 px x 2 rows per lane from LDS through packed-u8 VALU arithmetic
 //     straight to 16-B buffer stores.
-//   * Interior tiles (tile body inside the image) run in PERSISTENT waves: the next tile's body and
-//     halo are loaded into registers right before the current tile is computed out of LDS, so every
-//     wave keeps ~9 KB of HBM reads in flight during its whole compute phase.  Buffer loads with the
-//     hardware range check return 0 beyond the frame -- exactly the reference's out-of-image rule
+//   * Interior tiles (tile body inside the image) take a check-free kernel built on buffer loads whose
+//     hardware range check returns 0 beyond the frame -- exactly the reference's out-of-image rule
 //     (src/interpolator.rs:75-82).  Ragged tiles and unaligned widths go to a separate, fully checked
-//     per-tile kernel (k_*_edge).
+//     per-tile kernel (k_*_edge) launched next to it.
 //
 // All arithmetic is u8/integer; there is no MFMA-shaped work on this path.
-#include <stdio.h>
-#include <stdlib.h>
-
-#include <mutex>
-
 #include "hgi_dev.h"
 
 namespace hgi {
@@ -41,28 +34,30 @@ constexpr int NL = kThreads;       // lanes
 constexpr int CH = TW / 16;        // 16-B chunks per tile row
 constexpr int LCH = 3;             // log2(CH)
 constexpr int HR = kFusedMaxLevels;   // halo rows / columns a tile can need (offsets 0,4,8,16,32,64)
-// LDS layout (bank-conflict model and measurements: DESIGN.md "LDS layout").
-//   full-resolution plane: R rows (halo rows live at TH + idx) of pitch S.  S = 160 B makes rows that
-//   are 4 apart differ by 32 banks, which is what keeps the 16-B accesses of the two packed levels
-//   conflict-free (their lanes are mapped to rows 4 apart within each half-wave);
-//   halo COLUMNS live transposed behind it: hcol[idx * HP + row], so that the lanes of a halo cell
-//   pass (one lane per row) touch consecutive bytes instead of one bank.
-constexpr int S = TW + 32;
-constexpr int R = TH + HR;
-constexpr int HP = 80;             // >= R
-constexpr int HCOL = R * S;        // byte offset of the transposed halo columns
-constexpr int BUF_BYTES = HCOL + HR * HP;
-//   half-resolution plane (encode: reconstruction of the even/even lattice), same scheme
-constexpr int S2 = TW / 2 + 32;
-constexpr int R2 = TH / 2 + HR;
-constexpr int HP2 = 48;            // >= R2
-constexpr int RCOL = R2 * S2;
-constexpr int RBUF_BYTES = RCOL + HR * HP2;
+// LDS layout (bank-conflict model and measurements: DESIGN.md "LDS layout").  LDS is dynamic: a tile
+// that needs nh halo rows allocates TH + nh rows, which is what sets the waves per CU.
+//   full-resolution plane: [halo columns, transposed][rows 0 .. TH + nh - 1, pitch S]
+//     `buf` points at row 0; the halo COLUMNS live in front of it at buf[HCOL + idx * HP + row], so
+//     that the lanes of a halo-cell pass (one lane per row) touch consecutive bytes instead of one
+//     bank, and so that every offset stays a compile-time constant whatever nh is.
+//   half-resolution plane (encode: reconstruction of the even/even lattice): same scheme.
+constexpr int S = TW + 16;
+constexpr int HP = 72;             // >= TH + HR
+constexpr int HCOL = -(HR * HP);   // the transposed halo columns sit in front of row 0
+constexpr int S2 = TW / 2 + 8;
+constexpr int HP2 = 40;            // >= TH / 2 + HR
+constexpr int RCOL = -(HR * HP2);
+
+__host__ __device__ constexpr int buf_bytes(int nh) { return HR * HP + (TH + nh) * S; }
+__host__ __device__ constexpr int rbuf_bytes(int nh) { return HR * HP2 + (TH / 2 + nh) * S2; }
 
 static_assert(NL == 64 && CH == (1 << LCH) && (TH & (TH - 1)) == 0 && (1 << kFusedMaxLevels) <= TH, "tile geometry");
-static_assert(S % 16 == 0 && S2 % 8 == 0 && HCOL % 16 == 0 && RCOL % 16 == 0 && RBUF_BYTES % 16 == 0 && HP >= R &&
-                  HP2 >= R2,
+// 16-B accesses on the full-resolution rows, 8-B accesses on the half-resolution rows
+static_assert(S % 16 == 0 && (HR * HP) % 16 == 0 && S2 % 8 == 0 && (HR * HP2) % 16 == 0 && HP >= TH + HR &&
+                  HP2 >= TH / 2 + HR && buf_bytes(1) % 16 == 0 && rbuf_bytes(1) % 8 == 0,
               "LDS pitches keep vector alignment");
+// k = 4 (the flagship configuration): 16 decode waves and 12 encode waves per CU fit the 160 KiB of LDS
+static_assert(16 * buf_bytes(4) <= 160 * 1024 && 12 * (buf_bytes(4) + rbuf_bytes(4) + 256) <= 160 * 1024, "LDS budget");
 
 typedef u32 v4u __attribute__((ext_vector_type(4)));
 typedef u32 v2u __attribute__((ext_vector_type(2)));
@@ -134,51 +129,16 @@ struct Tile {
     u32 frame, X0, Y0;
 };
 
-// Persistent waves pull tiles from a work queue: one counter per XCD-range of the row-major tile
-// list (workgroups are dealt round-robin over the 8 XCDs, so b % 8 labels the XCD a block runs on;
-// neighbours in the list are neighbours in the image, so the halo lines they share meet in that
-// XCD's L2).  A block drains its home range first and then steals from the other ranges, so the
-// launch ends within one tile time of the last pull whatever the placement of the blocks.  Every
-// pull is one returning agent-scope atomic add by lane 0; each counter sees exactly
-// (tiles in range + grid size) pulls per launch.  Speed only, never correctness: any block may
-// process any tile.
-constexpr u32 kNoTile = 0xFFFFFFFFu;
-constexpr u32 kQueueStrideWords = 32;   // one 128-B line per counter
-
-struct Queue {
-    u32 *ctr;        // 8 counters, zeroed before the launch (nullptr: static one-tile-per-block mode)
-    u32 ntiles;
-    u32 home;        // range being drained: (blockIdx.x + tries) & 7
-    u32 tries;       // ranges exhausted so far
-};
-
+// XCD-aware block -> tile map.  Workgroups are dealt round-robin over the 8 XCDs (b % 8 labels the XCD a
+// block runs on), so XCD x gets the x-th contiguous eighth of the row-major tile list: x-neighbours
+// (which share halo lines) and consecutive tile rows land in the same XCD's L2.  Speed only, never
+// correctness.
 __device__ __forceinline__ u32 range_first(u32 ntiles, u32 x) { return x * (ntiles >> 3) + (x < (ntiles & 7u) ? x : (ntiles & 7u)); }
-__device__ __forceinline__ u32 range_count(u32 ntiles, u32 x) { return (ntiles >> 3) + (x < (ntiles & 7u) ? 1u : 0u); }
-
-// raw ticket from the range currently being drained (asynchronous: consumed one tile later)
-__device__ __forceinline__ u32 queue_pull(const Queue &q)
-{
-    u32 v = 0;
-    if (threadIdx.x == 0)
-        v = __hip_atomic_fetch_add(q.ctr + q.home * kQueueStrideWords, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    return __builtin_amdgcn_readfirstlane(v);
-}
-
-// ticket -> tile index; moves on to the next range (synchronous pulls) when the current one is empty
-__device__ __forceinline__ u32 queue_resolve(Queue &q, u32 ticket)
-{
-    for (;;) {
-        if (ticket < range_count(q.ntiles, q.home)) return range_first(q.ntiles, q.home) + ticket;
-        if (++q.tries >= 8u) return kNoTile;
-        q.home = (q.home + 1u) & 7u;
-        ticket = queue_pull(q);
-    }
-}
 
 // Compile-time ordering point for the wave's LDS traffic.  A wave's LDS instructions execute in
 // order, so a ds_read issued after a ds_write sees it without any wait; the compiler only has to be
-// kept from moving accesses across (it cannot see that lanes exchange data).  Unlike
-// __syncthreads() this does NOT drain vmcnt: the next tile's prefetch stays in flight.
+// kept from moving accesses across (it cannot see that lanes exchange data).  No s_barrier, no
+// vmcnt drain: the workgroup is one wave.
 #define LDS_ORDER() asm volatile("" ::: "memory")
 
 // =============================================================================================
@@ -240,60 +200,112 @@ __device__ __noinline__ void stage_tile_generic(u8 *buf, const u8 *__restrict__ 
     }
 }
 
-// Halo cells of level `s`: column x0 == TW (cy = 0..ncy) and row y0 == TH (cx = 0..ncx-1).  They
-// recompute, bit-identically, what the right / lower neighbour tiles compute for themselves.  Level
-// `sub` halo pixels are needed up to offset sub (sub >= 4); at sub == 2 only those on the tile edge.
-// Used by BOTH paths (the halo may leave the image even when the tile body does not).
+// Halo cells of level `s`: the cell column x0 == TW (rows y0 = 0, step, .., TH) and the cell row
+// y0 == TH (columns x0 = 0, step, .., TW - step).  They recompute, bit-identically, what the right /
+// lower neighbour tiles compute for themselves.  Level-`sub` halo pixels off the tile edge are needed
+// only for sub >= 4 (`deep`); at sub == 2 only those on the edge itself.  Column cells work on the
+// transposed halo columns (one lane per row -> consecutive bytes), row cells on the natural halo
+// rows; the slot indices hmap(sub), hmap(2*sub) are wave-uniform.  Used by BOTH paths (the halo may
+// leave the image even when the tile body does not), so every pixel is checked against the image.
 template <int INTERP>
 __device__ __forceinline__ void dec_halo_cells(u8 *buf, int s, Tile tl, u32 W, u32 H)
 {
     const int step = 2 * s, lstep = 31 - __clz(step);
     const int ncx = TW >> lstep, ncy = TH >> lstep;
-    const int lim = s >= 4 ? s : 0;
-    for (int j = threadIdx.x; j < ncx + ncy + 1; j += NL) {
-        int x0 = j <= ncy ? TW : (j - ncy - 1) << lstep;
-        int y0 = j <= ncy ? j << lstep : TH;
-        if (tl.X0 + x0 >= W || tl.Y0 + y0 >= H) continue;
-        u32 p = pred1<INTERP>(buf[laddr(x0, y0)], buf[laddr(x0, y0 + step)], buf[laddr(x0 + step, y0)],
-                              buf[laddr(x0 + step, y0 + step)]);
-        bool xin = x0 + s <= TW + lim && tl.X0 + x0 + s < W;
-        bool yin = y0 + s <= TH + lim && tl.Y0 + y0 + s < H;
-        const int as0 = laddr(x0 + s, y0), a0s = laddr(x0, y0 + s), ass = laddr(x0 + s, y0 + s);
-        if (xin) buf[as0] = (u8)(buf[as0] + p);
-        if (yin) buf[a0s] = (u8)(buf[a0s] + p);
-        if (xin && yin) buf[ass] = (u8)(buf[ass] + p);
+    const bool deep = s >= 4;
+    const int hs = hmap(s), h2 = hmap(step);
+    u8 *hc = buf + HCOL;
+    const int lane = threadIdx.x;
+    if (tl.X0 + TW < W && lane <= ncy) {           // column cells; lane == ncy is the corner cell (TW, TH)
+        const int y0 = lane << lstep;
+        if (tl.Y0 + y0 < H) {
+            const bool corner = y0 == TH;
+            const int ya = corner ? TH + h2 : y0 + step, yb = corner ? TH + hs : y0 + s;
+            u32 p = pred1<INTERP>(hc[y0], hc[ya], hc[h2 * HP + y0], hc[h2 * HP + ya]);
+            const bool xin = deep && tl.X0 + TW + s < W;
+            const bool yin = (deep || !corner) && tl.Y0 + y0 + s < H;
+            if (xin) hc[hs * HP + y0] = (u8)(hc[hs * HP + y0] + p);
+            if (yin) hc[yb] = (u8)(hc[yb] + p);
+            if (xin && yin) hc[hs * HP + yb] = (u8)(hc[hs * HP + yb] + p);
+        }
+    }
+    if (tl.Y0 + TH < H && lane < ncx) {            // row cells
+        const int x0 = lane << lstep;
+        if (tl.X0 + x0 < W) {
+            u8 *r0 = buf + TH * S + x0, *r1 = buf + (TH + h2) * S + x0, *rs = buf + (TH + hs) * S + x0;
+            const bool lastc = x0 + step == TW;    // right-hand corners are halo column 0
+            u32 lb = lastc ? hc[TH] : r0[step], rb = lastc ? hc[TH + h2] : r1[step];
+            u32 p = pred1<INTERP>(r0[0], r1[0], lb, rb);
+            const bool xin = tl.X0 + x0 + s < W;
+            const bool yin = deep && tl.Y0 + TH + s < H;
+            if (xin) r0[s] = (u8)(r0[s] + p);
+            if (yin) rs[0] = (u8)(rs[0] + p);
+            if (xin && yin) rs[s] = (u8)(rs[s] + p);
+        }
     }
 }
 
 template <int INTERP, bool IDENT>
 __device__ __forceinline__ void enc_halo_cells(u8 *buf, u8 *rbuf, const u8 *slut, int s, Tile tl, u32 W, u32 H)
 {
-    const int step = 2 * s, lstep = 31 - __clz(step);
+    const int step = 2 * s, hsub = s >> 1, lstep = 31 - __clz(step);
     const int ncx = TW >> lstep, ncy = TH >> lstep;
-    const int lim = s >= 4 ? s : 0;
-    for (int j = threadIdx.x; j < ncx + ncy + 1; j += NL) {
-        int x0 = j <= ncy ? TW : (j - ncy - 1) << lstep;
-        int y0 = j <= ncy ? j << lstep : TH;
-        if (tl.X0 + x0 >= W || tl.Y0 + y0 >= H) continue;
-        u32 p = pred1<INTERP>(rbuf[laddr2(x0, y0)], rbuf[laddr2(x0, y0 + step)], rbuf[laddr2(x0 + step, y0)],
-                              rbuf[laddr2(x0 + step, y0 + step)]);
-        bool xin = x0 + s <= TW + lim && tl.X0 + x0 + s < W;
-        bool yin = y0 + s <= TH + lim && tl.Y0 + y0 + s < H;
-        const int as0 = laddr(x0 + s, y0), a0s = laddr(x0, y0 + s), ass = laddr(x0 + s, y0 + s);
-        if (xin) {
-            u32 q = quant1<IDENT>(buf[as0], p, slut);
-            buf[as0] = (u8)q;
-            rbuf[laddr2(x0 + s, y0)] = (u8)(p + q);
+    const bool deep = s >= 4;
+    const int hs = hmap(s), h2 = hmap(step);
+    u8 *hc = buf + HCOL, *rc = rbuf + RCOL;
+    const int lane = threadIdx.x;
+    if (tl.X0 + TW < W && lane <= ncy) {           // column cells
+        const int y0 = lane << lstep;
+        if (tl.Y0 + y0 < H) {
+            const bool corner = y0 == TH;
+            const int yb = corner ? TH + hs : y0 + s;
+            const int z0 = y0 >> 1, za = corner ? TH / 2 + h2 : (y0 + step) >> 1, zb = corner ? TH / 2 + hs : (y0 + s) >> 1;
+            u32 p = pred1<INTERP>(rc[z0], rc[za], rc[h2 * HP2 + z0], rc[h2 * HP2 + za]);
+            const bool xin = deep && tl.X0 + TW + s < W;
+            const bool yin = (deep || !corner) && tl.Y0 + y0 + s < H;
+            if (xin) {
+                u32 q = quant1<IDENT>(hc[hs * HP + y0], p, slut);
+                hc[hs * HP + y0] = (u8)q;
+                rc[hs * HP2 + z0] = (u8)(p + q);
+            }
+            if (yin) {
+                u32 q = quant1<IDENT>(hc[yb], p, slut);
+                hc[yb] = (u8)q;
+                rc[zb] = (u8)(p + q);
+            }
+            if (xin && yin) {
+                u32 q = quant1<IDENT>(hc[hs * HP + yb], p, slut);
+                hc[hs * HP + yb] = (u8)q;
+                rc[hs * HP2 + zb] = (u8)(p + q);
+            }
         }
-        if (yin) {
-            u32 q = quant1<IDENT>(buf[a0s], p, slut);
-            buf[a0s] = (u8)q;
-            rbuf[laddr2(x0, y0 + s)] = (u8)(p + q);
-        }
-        if (xin && yin) {
-            u32 q = quant1<IDENT>(buf[ass], p, slut);
-            buf[ass] = (u8)q;
-            rbuf[laddr2(x0 + s, y0 + s)] = (u8)(p + q);
+    }
+    if (tl.Y0 + TH < H && lane < ncx) {            // row cells
+        const int x0 = lane << lstep;
+        if (tl.X0 + x0 < W) {
+            u8 *r0 = buf + TH * S + x0, *rs = buf + (TH + hs) * S + x0;
+            u8 *R0 = rbuf + (TH / 2) * S2 + (x0 >> 1), *R1 = rbuf + (TH / 2 + h2) * S2 + (x0 >> 1),
+               *RS = rbuf + (TH / 2 + hs) * S2 + (x0 >> 1);
+            const bool lastc = x0 + step == TW;
+            u32 lb = lastc ? rc[TH / 2] : R0[s], rb = lastc ? rc[TH / 2 + h2] : R1[s];
+            u32 p = pred1<INTERP>(R0[0], R1[0], lb, rb);
+            const bool xin = tl.X0 + x0 + s < W;
+            const bool yin = deep && tl.Y0 + TH + s < H;
+            if (xin) {
+                u32 q = quant1<IDENT>(r0[s], p, slut);
+                r0[s] = (u8)q;
+                R0[hsub] = (u8)(p + q);
+            }
+            if (yin) {
+                u32 q = quant1<IDENT>(rs[0], p, slut);
+                rs[0] = (u8)q;
+                RS[0] = (u8)(p + q);
+            }
+            if (xin && yin) {
+                u32 q = quant1<IDENT>(rs[s], p, slut);
+                rs[s] = (u8)q;
+                RS[hsub] = (u8)(p + q);
+            }
         }
     }
 }
@@ -427,9 +439,7 @@ struct Buf {
     u32 W, base;                 // base = Y0 * W + X0
 };
 
-// Everything a tile stages, held in registers between issue and commit (43 VGPRs): the next
-// tile's loads are issued right after the current tile's commit and stay in flight through the
-// whole compute phase of the current tile.
+// Everything a tile stages: all loads are issued before the first LDS write.
 struct Stage {
     v4u v[TH / 8];      // tile body: 8 x 16 B per lane (8 full 128-B lines per wave instruction)
     v4u hv;             // halo rows TH + {0,4,8,..}: full lines
@@ -785,62 +795,30 @@ __device__ __forceinline__ void dec_tile_fast(u8 *buf, const TileCtx &cur, const
     dec_fine_fast<INTERP>(buf, cur.b);
 }
 
-// PERSIST = false (default): one block per tile, XCD-contiguous order; fresh waves keep the CU's
-// phases naturally staggered.  PERSIST = true: resident waves pull tiles from the work queue and
-// prefetch the next tile into registers while computing the current one (measured, not faster on
-// MI355X for this kernel: DESIGN.md "Scheduling").
-template <int INTERP, bool SEEDED, bool PERSIST>
+// One block (= one wave) per interior tile, XCD-contiguous order.  (A persistent variant -- resident
+// waves pulling tiles from per-XCD atomic counters and prefetching the next tile into registers --
+// was built and measured: not faster on MI355X, see DESIGN.md "Scheduling".)
+template <int INTERP, bool SEEDED>
 __global__ __launch_bounds__(NL) void k_dec_fast(const u8 *__restrict__ src, u8 *__restrict__ dst, Frames f, u32 k,
-                                                 Seeds sd, TileGrid g, u32 *queue)
+                                                 Seeds sd, TileGrid g)
 {
-    __shared__ __attribute__((aligned(16))) u8 buf[BUF_BYTES];
-    const u32 W = f.width, H = f.height;
+    extern __shared__ __attribute__((aligned(16))) u8 smem[];
+    u8 *buf = smem - HCOL;
     const int nh = k >= 2 ? (int)k : 1;
-    if (!PERSIST) {
-        TileCtx cur = fast_ctx(range_first(g.nfast, blockIdx.x & 7u) + (blockIdx.x >> 3), src, dst, f, g);
-        Stage st;
-        stage_issue(st, cur.b, cur.tl, (int)k, nh);
-        stage_commit(buf, st, nh);
-        LDS_ORDER();
-        dec_tile_fast<INTERP, SEEDED>(buf, cur, sd, k, W, H);
-        return;
-    }
-    Queue q = {queue, g.nfast, blockIdx.x & 7u, 0u};
-    u32 t = queue_resolve(q, queue_pull(q));
-    if (t == kNoTile) return;
-    u32 ticket = queue_pull(q);
-    TileCtx cur = fast_ctx(t, src, dst, f, g);
-    {
-        Stage st;
-        stage_issue(st, cur.b, cur.tl, (int)k, nh);
-        stage_commit(buf, st, nh);
-    }
-    for (;;) {
-        // straight line per tile: issue(next) -> compute(current) -> commit(next).  The loads are older
-        // than this tile's stores, so the wait in commit never has to drain a store.
-        const u32 tn = queue_resolve(q, ticket);
-        const bool more = tn != kNoTile;
-        TileCtx nxt = cur;
-        Stage st;
-        if (more) {
-            nxt = fast_ctx(tn, src, dst, f, g);
-            stage_issue(st, nxt.b, nxt.tl, (int)k, nh);
-            ticket = queue_pull(q);   // consumed one tile later: its latency hides under this tile
-        }
-        LDS_ORDER();
-        dec_tile_fast<INTERP, SEEDED>(buf, cur, sd, k, W, H);
-        LDS_ORDER();   // the commit below overwrites what the fine level just read
-        if (!more) break;
-        stage_commit(buf, st, nh);
-        cur = nxt;
-    }
+    TileCtx cur = fast_ctx(range_first(g.nfast, blockIdx.x & 7u) + (blockIdx.x >> 3), src, dst, f, g);
+    Stage st;
+    stage_issue(st, cur.b, cur.tl, (int)k, nh);
+    stage_commit(buf, st, nh);
+    LDS_ORDER();
+    dec_tile_fast<INTERP, SEEDED>(buf, cur, sd, k, f.width, f.height);
 }
 
 template <int INTERP, bool SEEDED>
 __global__ __launch_bounds__(NL) void k_dec_edge(const u8 *__restrict__ src, u8 *__restrict__ dst, Frames f, u32 k,
                                                  Seeds sd, TileGrid g, u32 aligned)
 {
-    __shared__ __attribute__((aligned(16))) u8 buf[BUF_BYTES];
+    extern __shared__ __attribute__((aligned(16))) u8 smem[];
+    u8 *buf = smem - HCOL;
     const Tile tl = edge_tile(blockIdx.x, g);
     const u32 W = f.width, H = f.height;
     const u8 *fr = src + (size_t)tl.frame * f.frame_stride;
@@ -883,9 +861,10 @@ __device__ __forceinline__ void enc_seed(u8 *buf, u8 *rbuf, const Seeds &sd, Til
 }
 
 // lattice points outside the image must read as 0 (src/interpolator.rs:75-82) and are never written
-__device__ __forceinline__ void clear_lattice(u8 *rbuf)
+__device__ __forceinline__ void clear_lattice(u8 *rbuf, int nh)
 {
-    for (int i = threadIdx.x; i < RBUF_BYTES / 16; i += NL) reinterpret_cast<uint4 *>(rbuf)[i] = make_uint4(0, 0, 0, 0);
+    uint2 *base = reinterpret_cast<uint2 *>(rbuf + RCOL);
+    for (int i = threadIdx.x; i < rbuf_bytes(nh) / 8; i += NL) base[i] = make_uint2(0, 0);
 }
 
 template <int INTERP, bool IDENT, bool SEEDED>
@@ -904,70 +883,41 @@ __device__ __forceinline__ void enc_tile_fast(u8 *buf, u8 *rbuf, const u8 *slut,
     enc_fine_fast<INTERP, IDENT>(buf, rbuf, slut, cur.b);
 }
 
-template <int INTERP, bool IDENT, bool SEEDED, bool PERSIST>
+template <int INTERP, bool IDENT, bool SEEDED>
 __global__ __launch_bounds__(NL) void k_enc_fast(const u8 *__restrict__ src, u8 *__restrict__ dst, Frames f, u32 k,
-                                                 Lut256 lut, Seeds sd, TileGrid g, u32 *queue)
+                                                 Lut256 lut, Seeds sd, TileGrid g)
 {
-    __shared__ __attribute__((aligned(16))) u8 buf[BUF_BYTES];
-    __shared__ __attribute__((aligned(16))) u8 rbuf[RBUF_BYTES];
-    __shared__ __attribute__((aligned(16))) u8 slut[256];
-    const u32 W = f.width, H = f.height;
+    extern __shared__ __attribute__((aligned(16))) u8 smem[];
     const int nh = k >= 2 ? (int)k : 1;
+    u8 *buf = smem - HCOL;
+    u8 *rbuf = smem + buf_bytes(nh) - RCOL;
+    u8 *slut = smem + buf_bytes(nh) + rbuf_bytes(nh);
     if (!IDENT) reinterpret_cast<u32 *>(slut)[threadIdx.x] = lut.w[threadIdx.x];
-    if (!PERSIST) {
-        TileCtx cur = fast_ctx(range_first(g.nfast, blockIdx.x & 7u) + (blockIdx.x >> 3), src, dst, f, g);
-        Stage st;
-        stage_issue(st, cur.b, cur.tl, (int)k, nh);
-        clear_lattice(rbuf);
-        stage_commit(buf, st, nh);
-        LDS_ORDER();
-        enc_tile_fast<INTERP, IDENT, SEEDED>(buf, rbuf, slut, cur, sd, k, W, H);
-        return;
-    }
-    Queue q = {queue, g.nfast, blockIdx.x & 7u, 0u};
-    u32 t = queue_resolve(q, queue_pull(q));
-    if (t == kNoTile) return;
-    u32 ticket = queue_pull(q);
-    TileCtx cur = fast_ctx(t, src, dst, f, g);
-    {
-        Stage st;
-        stage_issue(st, cur.b, cur.tl, (int)k, nh);
-        stage_commit(buf, st, nh);
-    }
-    for (;;) {
-        const u32 tn = queue_resolve(q, ticket);
-        const bool more = tn != kNoTile;
-        TileCtx nxt = cur;
-        Stage st;
-        if (more) {
-            nxt = fast_ctx(tn, src, dst, f, g);
-            stage_issue(st, nxt.b, nxt.tl, (int)k, nh);
-            ticket = queue_pull(q);
-        }
-        clear_lattice(rbuf);
-        LDS_ORDER();
-        enc_tile_fast<INTERP, IDENT, SEEDED>(buf, rbuf, slut, cur, sd, k, W, H);
-        LDS_ORDER();
-        if (!more) break;
-        stage_commit(buf, st, nh);
-        cur = nxt;
-    }
+    TileCtx cur = fast_ctx(range_first(g.nfast, blockIdx.x & 7u) + (blockIdx.x >> 3), src, dst, f, g);
+    Stage st;
+    stage_issue(st, cur.b, cur.tl, (int)k, nh);
+    clear_lattice(rbuf, nh);
+    stage_commit(buf, st, nh);
+    LDS_ORDER();
+    enc_tile_fast<INTERP, IDENT, SEEDED>(buf, rbuf, slut, cur, sd, k, f.width, f.height);
 }
 
 template <int INTERP, bool IDENT, bool SEEDED>
 __global__ __launch_bounds__(NL) void k_enc_edge(const u8 *__restrict__ src, u8 *__restrict__ dst, Frames f, u32 k,
                                                  Lut256 lut, Seeds sd, TileGrid g, u32 aligned)
 {
-    __shared__ __attribute__((aligned(16))) u8 buf[BUF_BYTES];
-    __shared__ __attribute__((aligned(16))) u8 rbuf[RBUF_BYTES];
-    __shared__ __attribute__((aligned(16))) u8 slut[256];
+    extern __shared__ __attribute__((aligned(16))) u8 smem[];
+    const int nh0 = k >= 2 ? (int)k : 1;
+    u8 *buf = smem - HCOL;
+    u8 *rbuf = smem + buf_bytes(nh0) - RCOL;
+    u8 *slut = smem + buf_bytes(nh0) + rbuf_bytes(nh0);
     const Tile tl = edge_tile(blockIdx.x, g);
     const u32 W = f.width, H = f.height;
     const u8 *fr = src + (size_t)tl.frame * f.frame_stride;
     u8 *out = dst + (size_t)tl.frame * f.frame_stride;
     const int nh = k >= 2 ? (int)k : 1;
     if (!IDENT) reinterpret_cast<u32 *>(slut)[threadIdx.x] = lut.w[threadIdx.x];
-    clear_lattice(rbuf);
+    clear_lattice(rbuf, nh);
     stage_tile_generic(buf, fr, W, H, tl, nh, aligned != 0);
     LDS_ORDER();
     enc_seed<SEEDED>(buf, rbuf, sd, tl, k);
@@ -978,45 +928,6 @@ __global__ __launch_bounds__(NL) void k_enc_edge(const u8 *__restrict__ src, u8 
     }
     enc_fine_generic<INTERP, IDENT>(buf, rbuf, slut, out, tl, W, H, aligned != 0);
 }
-
-// Persistent grid: one wave per slot the kernel can occupy on the current device (LDS-limited),
-// never more blocks than tiles.  Cached per (device, kernel).
-u32 persistent_grid(const void *kernel, u32 ntiles)
-{
-    struct Entry {
-        int dev;
-        const void *kernel;
-        u32 slots;
-    };
-    static std::mutex mu;
-    static Entry cache[64];
-    static int n = 0;
-    int dev = 0;
-    (void)hipGetDevice(&dev);
-    std::lock_guard<std::mutex> lock(mu);
-    u32 slots = 0;
-    for (int i = 0; i < n; ++i)
-        if (cache[i].dev == dev && cache[i].kernel == kernel) slots = cache[i].slots;
-    if (slots == 0) {
-        int cus = 0, per_cu = 0;
-        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||
-            hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, NL, 0) != hipSuccess || cus <= 0 ||
-            per_cu <= 0) {
-            cus = 256;
-            per_cu = 8;
-        }
-        if (const char *e = getenv("HGI_WAVES_PER_CU")) {   // tuning / debugging knob
-            int v = atoi(e);
-            if (getenv("HGI_DEBUG")) fprintf(stderr, "[hgi] occupancy API: %d waves/CU x %d CUs; override %d\n", per_cu, cus, v);
-            if (v > 0) per_cu = v;
-        }
-        slots = (u32)cus * (u32)per_cu;
-        if (n < 64) cache[n++] = Entry{dev, kernel, slots};
-    }
-    return ntiles < slots ? ntiles : slots;
-}
-
-constexpr size_t kQueueBytes = 8 * kQueueStrideWords * sizeof(u32);
 
 inline bool ptr16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
@@ -1047,48 +958,22 @@ FusedGeom fused_geom(const void *a, const void *b, const Frames &f)
     return r;
 }
 
-// Grid + queue of a fast launch: persistent (<= resident slots, tiles pulled from `queue`) when there
-// are more tiles than slots and a queue buffer is available, else one block per tile.
-struct FastLaunch {
-    u32 blocks;
-    u32 *queue;
-};
-
-// `persistent_kernel` non-null and more tiles than resident slots: persistent launch.
-FastLaunch plan_fast(const void *persistent_kernel, u32 ntiles, u32 *queue, hipStream_t s, hipError_t *err)
-{
-    FastLaunch fl = {ntiles, nullptr};
-    if (!queue || !persistent_kernel) return fl;
-    const u32 slots = persistent_grid(persistent_kernel, ntiles);
-    if (slots < ntiles) {
-        *err = hipMemsetAsync(queue, 0, kQueueBytes, s);
-        fl.blocks = slots;
-        fl.queue = queue;
-    }
-    return fl;
-}
-
 }  // namespace
 
 hipError_t launch_decode_fused(const uint8_t *grid, uint8_t *img, const Frames &f, uint32_t k, int interp,
-                               const Seeds *seeds, uint32_t *queue, hipStream_t s)
+                               const Seeds *seeds, hipStream_t s)
 {
     FusedGeom r = fused_geom(grid, img, f);
     if (!r.ok || k < 1 || k > (u32)kFusedMaxLevels) return hipErrorInvalidValue;
     const TileGrid &g = r.g;
     Seeds sd = seeds ? *seeds : Seeds{nullptr, nullptr, 0, 0, 0};
-    dim3 b(NL);
-    hipError_t qerr = hipSuccess;
+    const dim3 b(NL);
+    const int nh = k >= 2 ? (int)k : 1;
+    const size_t lds = (size_t)buf_bytes(nh);
 #define HGI_DEC(I, SE)                                                                                              \
     do {                                                                                                            \
-        if (g.nfast) {                                                                                              \
-            FastLaunch fl = plan_fast(reinterpret_cast<const void *>(&k_dec_fast<I, SE, true>), g.nfast, queue, s, &qerr); \
-            if (fl.queue)                                                                                           \
-                hipLaunchKernelGGL((k_dec_fast<I, SE, true>), dim3(fl.blocks), b, 0, s, grid, img, f, k, sd, g, fl.queue); \
-            else                                                                                                    \
-                hipLaunchKernelGGL((k_dec_fast<I, SE, false>), dim3(g.nfast), b, 0, s, grid, img, f, k, sd, g, nullptr); \
-        }                                                                                                           \
-        if (g.nedge) hipLaunchKernelGGL((k_dec_edge<I, SE>), dim3(g.nedge), b, 0, s, grid, img, f, k, sd, g, r.aligned); \
+        if (g.nfast) hipLaunchKernelGGL((k_dec_fast<I, SE>), dim3(g.nfast), b, lds, s, grid, img, f, k, sd, g);      \
+        if (g.nedge) hipLaunchKernelGGL((k_dec_edge<I, SE>), dim3(g.nedge), b, lds, s, grid, img, f, k, sd, g, r.aligned); \
     } while (0)
     if (interp == kInterpCrossed) {
         if (seeds) HGI_DEC(kInterpCrossed, true); else HGI_DEC(kInterpCrossed, false);
@@ -1096,29 +981,24 @@ hipError_t launch_decode_fused(const uint8_t *grid, uint8_t *img, const Frames &
         if (seeds) HGI_DEC(kInterpLeftTop, true); else HGI_DEC(kInterpLeftTop, false);
     }
 #undef HGI_DEC
-    return qerr != hipSuccess ? qerr : hipGetLastError();
+    return hipGetLastError();
 }
 
 hipError_t launch_encode_fused(const uint8_t *img, uint8_t *grid, const Frames &f, uint32_t k, int interp,
-                               const Lut256 &lut, bool ident, const Seeds *seeds, uint32_t *queue, hipStream_t s)
+                               const Lut256 &lut, bool ident, const Seeds *seeds, hipStream_t s)
 {
     FusedGeom r = fused_geom(img, grid, f);
     if (!r.ok || k < 1 || k > (u32)kFusedMaxLevels) return hipErrorInvalidValue;
     const TileGrid &g = r.g;
     Seeds sd = seeds ? *seeds : Seeds{nullptr, nullptr, 0, 0, 0};
-    dim3 b(NL);
-    hipError_t qerr = hipSuccess;
+    const dim3 b(NL);
+    const int nh = k >= 2 ? (int)k : 1;
+    const size_t lds = (size_t)buf_bytes(nh) + rbuf_bytes(nh) + 256;
 #define HGI_ENC(I, ID, SE)                                                                                          \
     do {                                                                                                            \
-        if (g.nfast) {                                                                                              \
-            FastLaunch fl = plan_fast(reinterpret_cast<const void *>(&k_enc_fast<I, ID, SE, true>), g.nfast, queue, s, &qerr); \
-            if (fl.queue)                                                                                           \
-                hipLaunchKernelGGL((k_enc_fast<I, ID, SE, true>), dim3(fl.blocks), b, 0, s, img, grid, f, k, lut, sd, g, fl.queue); \
-            else                                                                                                    \
-                hipLaunchKernelGGL((k_enc_fast<I, ID, SE, false>), dim3(g.nfast), b, 0, s, img, grid, f, k, lut, sd, g, nullptr); \
-        }                                                                                                           \
+        if (g.nfast) hipLaunchKernelGGL((k_enc_fast<I, ID, SE>), dim3(g.nfast), b, lds, s, img, grid, f, k, lut, sd, g); \
         if (g.nedge)                                                                                                \
-            hipLaunchKernelGGL((k_enc_edge<I, ID, SE>), dim3(g.nedge), b, 0, s, img, grid, f, k, lut, sd, g, r.aligned); \
+            hipLaunchKernelGGL((k_enc_edge<I, ID, SE>), dim3(g.nedge), b, lds, s, img, grid, f, k, lut, sd, g, r.aligned); \
     } while (0)
 #define HGI_ENC_I(I)                                                          \
     do {                                                                      \
@@ -1128,7 +1008,7 @@ hipError_t launch_encode_fused(const uint8_t *img, uint8_t *grid, const Frames &
     if (interp == kInterpCrossed) HGI_ENC_I(kInterpCrossed); else HGI_ENC_I(kInterpLeftTop);
 #undef HGI_ENC_I
 #undef HGI_ENC
-    return qerr != hipSuccess ? qerr : hipGetLastError();
+    return hipGetLastError();
 }
 
 }  // namespace hgi

@@ -45,14 +45,11 @@ hipError_t launch_encode_level(uint8_t *rec, uint8_t *grid, const Frames &f, uin
                                int interp, const Lut256 &lut, hipStream_t s);
 
 // ---- fused path: the last k <= kFusedMaxLevels levels of every tile in one launch ------------
-// `queue`: kFusedQueueBytes of device memory for the persistent waves' work counters (zeroed on the
-// stream by the launcher); nullptr = one block per tile.
-constexpr size_t kFusedQueueBytes = 1024;
 hipError_t launch_decode_fused(const uint8_t *grid, uint8_t *img, const Frames &f, uint32_t k,
-                               int interp, const Seeds *seeds, uint32_t *queue, hipStream_t s);
+                               int interp, const Seeds *seeds, hipStream_t s);
 hipError_t launch_encode_fused(const uint8_t *img, uint8_t *grid, const Frames &f, uint32_t k,
                                int interp, const Lut256 &lut, bool lut_is_identity,
-                               const Seeds *seeds, uint32_t *queue, hipStream_t s);
+                               const Seeds *seeds, hipStream_t s);
 
 // dst[f][j][i] = src[f][j << k][i << k]  (the stride-2^k lattice as a dense plane)
 hipError_t launch_gather_lattice(const uint8_t *src, const Frames &f, uint32_t k, uint8_t *dst,
