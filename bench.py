@@ -23,7 +23,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 import rustyhgi_amd as H                      # noqa: E402
-from rustyhgi_amd import _ffi                 # noqa: E402
+from rustyhgi_amd import _ffi, batch          # noqa: E402
 from rustyhgi_amd.interpolator import Crossed  # noqa: E402
 from rustyhgi_amd.quantizator import Linear, QuantizationLevel, Quantizator  # noqa: E402
 
@@ -45,6 +45,21 @@ class TableQuantizator(Quantizator):
 
     def table(self):
         return self._t.copy()
+
+
+def pmc_traffic(kernel, frames, size, levels):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (FETCH_SIZE with the
+    gfx950 x2 correction + WRITE_SIZE; tools/profile.sh -> profiles/*_traffic.json), if that profile was
+    taken on this exact workload; else None.  bench.py cannot run the profiler on itself."""
+    path = os.path.join(ROOT, "profiles", "r01_traffic.json")
+    try:
+        with open(path) as f:
+            prof = json.load(f)
+        if prof["workload"] != {"frames": frames, "size": size, "levels": levels}:
+            return None
+        return prof["kernels"][kernel]["hbm_bytes_per_launch"]
+    except (OSError, KeyError, ValueError):
+        return None
 
 
 def cpu_baseline(args, lut, gpu_check):
@@ -93,15 +108,11 @@ def main():
 
     # ---- batch split: rank 0 owns the parameters; table + levels go out by RCCL broadcast ----
     level = QuantizationLevel.parse(args.quant)
-    params = torch.zeros(258, dtype=torch.uint8, device=dev)
     if rank == 0:
         q = Linear.from_level(level)
-        params[:256] = torch.from_numpy(q.table()).to(dev)
-        params[256], params[257] = q.error(), args.levels
-    if dist is not None:
-        dist.broadcast(params, src=0)
-    p = params.cpu().numpy()
-    lut, err, levels = p[:256].copy(), int(p[256]), int(p[257])
+        lut, err, levels = batch.broadcast_params(dist, dev, q.table(), q.error(), args.levels)
+    else:
+        lut, err, levels = batch.broadcast_params(dist, dev)
 
     # a real (non-null) stream made current for torch: the codec launches, the timing events and the
     # torch ops around them all live on it
@@ -115,7 +126,9 @@ def main():
     grids = torch.empty_like(imgs)
     outs = torch.empty_like(imgs)
     # frame f of rank r is global frame r*F + f of config C3 (ramp(3)): produced where it is used
-    _ffi.check(_ffi.lib().hgi_synth_u8_dev(ctx.handle, _ffi.SYNTH_RAMP, SEED0 + 3, rank * F, S, S,
+    first, count = batch.shard(world * F, world, rank)
+    assert count == F
+    _ffi.check(_ffi.lib().hgi_synth_u8_dev(ctx.handle, _ffi.SYNTH_RAMP, SEED0 + 3, first, S, S,
                                            imgs.data_ptr(), F, S * S))
     enc = H.Encoder(Crossed(), TableQuantizator(lut, err), levels, context=ctx)
     dec = H.Decoder(Crossed(), context=ctx)
@@ -142,14 +155,25 @@ def main():
         dec.decode_batch(grids, levels, out=outs)
         ev[k][2].record()
     fence()
-    elapsed = time.perf_counter() - t0
-    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-    if dist is not None:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    elapsed = float(t.item())
+    elapsed = batch.max_over_ranks(dist, time.perf_counter() - t0, dev)
 
     enc_ms = float(np.mean([e[0].elapsed_time(e[1]) for e in ev]))
     dec_ms = float(np.mean([e[1].elapsed_time(e[2]) for e in ev]))
+
+    # same-run reference point: a plain 16-B/lane streaming copy of the same 2 x F frames of traffic
+    copy_ms = None
+    if rank == 0:
+        ce = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+        n = F * S * S
+        for i in range(6):
+            if i == 1:
+                ce[0].record()
+            _ffi.check(_ffi.lib().hgi_copy_u8_dev(ctx.handle, imgs.data_ptr(), outs.data_ptr(), n))
+        ce[1].record()
+        torch.cuda.synchronize(dev)
+        copy_ms = ce[0].elapsed_time(ce[1]) / 5
+        dec.decode_batch(grids, levels, out=outs)      # restore the decoded frames the checks below read
+        torch.cuda.synchronize(dev)
 
     # ---- per-rank checks + stats gather (RCCL all-gather) ----
     stats = torch.zeros(3 * F, dtype=torch.int64, device=dev)
@@ -157,12 +181,7 @@ def main():
                                              stats.data_ptr()))
     st = stats.view(F, 3)
     mine = torch.stack([st[:, 0].sum(), st[:, 1].max(), grids.view(-1)[::4099].to(torch.int64).sum()])
-    allst = [torch.zeros_like(mine) for _ in range(world)]
-    if dist is not None:
-        dist.all_gather(allst, mine)
-    else:
-        allst = [mine]
-    allst = torch.stack(allst).cpu().numpy()
+    allst = batch.gather_stats(dist, mine)
     assert int(allst[:, 1].max()) <= err, "reconstruction error exceeds the quantizer bound"
 
     if rank == 0:
@@ -171,6 +190,8 @@ def main():
         dom, dom_ms = ("encode", enc_ms) if enc_ms >= dec_ms else ("decode", dec_ms)
         alg_bytes = 2.0 * F * S * S               # 2 B/px per direction, one launch per batch
         achieved = alg_bytes / (dom_ms * 1e-3) / 1e9
+        kernel = "k_%s_fast" % ("enc" if dom == "encode" else "dec")
+        traffic = pmc_traffic(kernel, F, S, levels)
         line = {
             "metric": "Mpixels/s encode+decode, 4K grayscale level=4 Medium", "value": round(value, 1),
             "unit": "Mpixels/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -182,10 +203,16 @@ def main():
                        "encode_ms": round(enc_ms, 4), "decode_ms": round(dec_ms, 4),
                        "max_abs_err": int(allst[:, 1].max()), "sq_err_sum": int(allst[:, 0].sum()),
                        "grid_checksums": [int(v) for v in allst[:, 2]]},
-            "roofline": {"bound": "hbm", "kernel": "k_%s_fused" % ("enc" if dom == "encode" else "dec"),
+            "roofline": {"bound": "hbm", "kernel": kernel,
                          "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
-                         "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": round(dom_ms, 4)},
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                         "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": round(dom_ms, 4),
+                         "other_kernel": {"kernel": "k_%s_fast" % ("dec" if dom == "encode" else "enc"),
+                                          "achieved": round(alg_bytes / (min(enc_ms, dec_ms) * 1e-3) / 1e9, 1),
+                                          "avg_launch_ms": round(min(enc_ms, dec_ms), 4)},
+                         "copy_same_run": {"achieved": round(alg_bytes / (copy_ms * 1e-3) / 1e9, 1),
+                                           "avg_launch_ms": round(copy_ms, 4),
+                                           "note": "16-B/lane copy kernel moving the same bytes"}},
         }
         if world == 1 and not args.no_cpu:
             check = {"grid": grids[:2].cpu().numpy(), "out": outs[:2].cpu().numpy()}

@@ -1,0 +1,28 @@
+//! Raw bindings of include/hgi.h (only what the codec surface needs).
+use std::os::raw::{c_char, c_int, c_void};
+
+#[repr(C)]
+pub struct HgiCtx {
+    _private: [u8; 0],
+}
+
+pub const HGI_OK: c_int = 0;
+pub const HGI_INTERP_LEFTTOP: c_int = 0;
+pub const HGI_INTERP_CROSSED: c_int = 1;
+
+extern "C" {
+    pub fn hgi_ctx_create(device: c_int, out: *mut *mut HgiCtx) -> c_int;
+    pub fn hgi_ctx_destroy(ctx: *mut HgiCtx);
+    pub fn hgi_last_error() -> *const c_char;
+    pub fn hgi_linear_lut(level: c_int, lut: *mut u8, max_err: *mut u8) -> c_int;
+    pub fn hgi_encode_u8(ctx: *mut HgiCtx, img: *const u8, width: u32, height: u32, levels: u32,
+                         interp: c_int, lut: *const u8, grid_out: *mut u8) -> c_int;
+    pub fn hgi_decode_u8(ctx: *mut HgiCtx, grid: *const u8, width: u32, height: u32, levels: u32,
+                         interp: c_int, img_out: *mut u8) -> c_int;
+    pub fn hgi_encode_u8_dev(ctx: *mut HgiCtx, d_img: *const c_void, width: u32, height: u32, levels: u32,
+                             interp: c_int, lut: *const u8, d_grid: *mut c_void, batch: usize,
+                             frame_stride: usize) -> c_int;
+    pub fn hgi_decode_u8_dev(ctx: *mut HgiCtx, d_grid: *const c_void, width: u32, height: u32, levels: u32,
+                             interp: c_int, d_img: *mut c_void, batch: usize, frame_stride: usize) -> c_int;
+    pub fn hgi_sync(ctx: *mut HgiCtx) -> c_int;
+}

@@ -22,5 +22,6 @@ run sq1 --kernel-trace --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY 
 run sq2 --kernel-trace --pmc SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAIT_INST_LDS SQ_INSTS_SALU
 run tcc --kernel-trace --pmc TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum
 python3 tools/summarize_prof.py "$OUT" > "$OUT/summary.md" 2>"$OUT/summarize.err"
+python3 tools/summarize_prof.py "$OUT" --traffic 64 4096 4 > "$OUT/traffic.json" 2>>"$OUT/summarize.err"
 cat "$OUT/passes.log"
 tail -60 "$OUT/summary.md"

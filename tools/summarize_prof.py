@@ -56,5 +56,32 @@ def main(out):
         print()
 
 
+def traffic_json(out, frames, size, levels):
+    """profiles/*_traffic.json: per-launch HBM bytes of the fused kernels (what bench.py reports as
+    roofline.traffic).  FETCH_SIZE / WRITE_SIZE are in KB; FETCH_SIZE x2 is the gfx950 correction for
+    wide coalesced reads (MI355X_MICROARCH.md, HBM section)."""
+    import json
+    per = defaultdict(dict)
+    for name, ctr in (("fetch", "FETCH_SIZE"), ("write", "WRITE_SIZE")):
+        acc = defaultdict(list)
+        for path in glob.glob(os.path.join(out, name, "**", "*counter_collection.csv"), recursive=True):
+            for row in csv.DictReader(open(path)):
+                if row["Counter_Name"] == ctr:
+                    acc[short(row["Kernel_Name"]).split("<")[0]].append(float(row["Counter_Value"]))
+        for k, v in acc.items():
+            per[k][ctr] = sum(v) / len(v)
+    kernels = {}
+    for k, c in per.items():
+        if k.startswith("k_") and "FETCH_SIZE" in c and "WRITE_SIZE" in c:
+            kernels[k] = {"fetch_kb_raw": c["FETCH_SIZE"], "write_kb": c["WRITE_SIZE"],
+                          "hbm_bytes_per_launch": int((2 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024)}
+    print(json.dumps({"workload": {"frames": frames, "size": size, "levels": levels},
+                      "method": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes), bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024",
+                      "kernels": kernels}, indent=1))
+
+
 if __name__ == "__main__":
-    main(sys.argv[1])
+    if len(sys.argv) > 2 and sys.argv[2] == "--traffic":
+        traffic_json(sys.argv[1], int(sys.argv[3]), int(sys.argv[4]), int(sys.argv[5]))
+    else:
+        main(sys.argv[1])
