@@ -59,6 +59,9 @@ static_assert(S % 16 == 0 && (HR * HP) % 16 == 0 && S2 % 8 == 0 && (HR * HP2) % 
 // k = 4 (the flagship configuration): 16 decode waves and 12 encode waves per CU fit the 160 KiB of LDS
 static_assert(16 * buf_bytes(4) <= 160 * 1024 && 12 * (buf_bytes(4) + rbuf_bytes(4) + 256) <= 160 * 1024, "LDS budget");
 
+#ifndef HGI_ABL
+#define HGI_ABL 0   // timing experiments: 1 no coarse levels, 2 no fine arithmetic, 4 no halo cells, 8 no sub==2 level
+#endif
 typedef u32 v4u __attribute__((ext_vector_type(4)));
 typedef u32 v2u __attribute__((ext_vector_type(2)));
 typedef u32 v3u __attribute__((ext_vector_type(3)));
@@ -100,11 +103,33 @@ typedef unsigned long long lanemask;
         Q_SEL(O0, K0, b0_, c0_, q0_, d0_); Q_SEL(O1, K1, b1_, c1_, q1_, d1_);                          \
         Q_SEL(O2, K2, b2_, c2_, q2_, d2_); Q_SEL(O3, K3, b3_, c3_, q3_, d3_);                          \
     } while (0)
+// one pixel held in its own registers (a = original, p = prediction, both clean bytes) -> residual
+#define Q_PIX1(out, a, p, slut)                                                                        \
+    do {                                                                                               \
+        u32 d_, np_ = ~(p);                                                                            \
+        lanemask b_, c_;                                                                               \
+        Q_SUB(d_, a, 0, p, 0);                                                                         \
+        u32 q_ = slut[d_];                                                                             \
+        Q_LT(b_, a, 0, p, 0);                                                                          \
+        Q_GT(c_, q_, np_, 0);                                                                          \
+        asm("s_xor_b64 vcc, %1, %2\n\tv_cndmask_b32_e32 %0, %3, %4, vcc"                               \
+            : "=v"(out) : "s"(b_), "s"(c_), "v"(q_), "v"(d_) : "vcc", "scc");                          \
+    } while (0)
 // dst.byte[KD] = (q.byte[KQ] + p.byte[J]) mod 256: the reconstruction of a freshly coded pixel
 #define Q_REC(dst, KD, q, KQ, p, J)                                                                    \
     asm("v_add_u16_sdwa %0, %1, %2 dst_sel:BYTE_" #KD " dst_unused:UNUSED_PRESERVE src0_sel:BYTE_" #KQ   \
         " src1_sel:BYTE_" #J                                                                           \
         : "+v"(dst) : "v"(q), "v"(p))
+
+// src/encoder.rs:53-60 for one pixel in its own registers (coarse levels, halo cells)
+template <bool IDENT>
+__device__ __forceinline__ u32 quant1s(u32 a, u32 p, const u8 *slut)
+{
+    if (IDENT) return (a - p) & 255u;
+    u32 out;
+    Q_PIX1(out, a, p, slut);
+    return out;
+}
 
 // ---------------------------------------------------------------------------------------------
 // tile bookkeeping
@@ -245,6 +270,16 @@ __device__ __forceinline__ void dec_halo_cells(u8 *buf, int s, Tile tl, u32 W, u
     }
 }
 
+// Encode: ONE pass per level for all halo cells (lanes 0..ncy: column cells on the transposed halo
+// columns, lanes 32..: row cells on the natural halo rows).  The pass is a latency chain (corners ->
+// prediction -> table -> write), so every LDS read is issued up front and unconditionally -- the
+// addresses of an active cell are always inside the tile's LDS planes, whether or not the pixel is
+// needed -- the three table look-ups fly together, and only the writes are conditional.
+struct HaloCell {
+    int lt, rt, lb, rb;      // corners
+    int nx, ny, nxy;         // new pixels (x0+s, y0), (x0, y0+s), (x0+s, y0+s)
+};
+
 template <int INTERP, bool IDENT>
 __device__ __forceinline__ void enc_halo_cells(u8 *buf, u8 *rbuf, const u8 *slut, int s, Tile tl, u32 W, u32 H)
 {
@@ -252,61 +287,47 @@ __device__ __forceinline__ void enc_halo_cells(u8 *buf, u8 *rbuf, const u8 *slut
     const int ncx = TW >> lstep, ncy = TH >> lstep;
     const bool deep = s >= 4;
     const int hs = hmap(s), h2 = hmap(step);
-    u8 *hc = buf + HCOL, *rc = rbuf + RCOL;
     const int lane = threadIdx.x;
-    if (tl.X0 + TW < W && lane <= ncy) {           // column cells
-        const int y0 = lane << lstep;
-        if (tl.Y0 + y0 < H) {
-            const bool corner = y0 == TH;
-            const int yb = corner ? TH + hs : y0 + s;
-            const int z0 = y0 >> 1, za = corner ? TH / 2 + h2 : (y0 + step) >> 1, zb = corner ? TH / 2 + hs : (y0 + s) >> 1;
-            u32 p = pred1<INTERP>(rc[z0], rc[za], rc[h2 * HP2 + z0], rc[h2 * HP2 + za]);
-            const bool xin = deep && tl.X0 + TW + s < W;
-            const bool yin = (deep || !corner) && tl.Y0 + y0 + s < H;
-            if (xin) {
-                u32 q = quant1<IDENT>(hc[hs * HP + y0], p, slut);
-                hc[hs * HP + y0] = (u8)q;
-                rc[hs * HP2 + z0] = (u8)(p + q);
-            }
-            if (yin) {
-                u32 q = quant1<IDENT>(hc[yb], p, slut);
-                hc[yb] = (u8)q;
-                rc[zb] = (u8)(p + q);
-            }
-            if (xin && yin) {
-                u32 q = quant1<IDENT>(hc[hs * HP + yb], p, slut);
-                hc[hs * HP + yb] = (u8)q;
-                rc[hs * HP2 + zb] = (u8)(p + q);
-            }
-        }
+    const bool col = lane < 32;
+    // column cell (x0 == TW, y0 = lane * step; y0 == TH is the corner cell)
+    const int y0 = lane << lstep;
+    const bool corner = y0 == TH;
+    const int yb = corner ? TH + hs : y0 + s;
+    const int z0 = y0 >> 1, za = corner ? TH / 2 + h2 : (y0 + step) >> 1, zb = corner ? TH / 2 + hs : (y0 + s) >> 1;
+    // row cell (y0 == TH, x0 = (lane - 32) * step); its right-hand corners may be halo column 0
+    const int x0 = (lane - 32) << lstep, w0 = x0 >> 1;
+    const bool lastc = x0 + step == TW;
+    const bool active = col ? (lane <= ncy && tl.X0 + TW < W && tl.Y0 + y0 < H)
+                            : (lane - 32 < ncx && tl.Y0 + TH < H && tl.X0 + x0 < W);
+    if (!active) return;
+    const bool xin = col ? (deep && tl.X0 + TW + s < W) : (tl.X0 + x0 + s < W);
+    const bool yin = col ? ((deep || !corner) && tl.Y0 + y0 + s < H) : (deep && tl.Y0 + TH + s < H);
+    HaloCell f, r;   // full-resolution plane (originals -> residuals), half-resolution plane (reconstruction)
+    f.nx = col ? HCOL + hs * HP + y0 : TH * S + x0 + s;
+    f.ny = col ? HCOL + yb : (TH + hs) * S + x0;
+    f.nxy = col ? HCOL + hs * HP + yb : (TH + hs) * S + x0 + s;
+    r.lt = col ? RCOL + z0 : (TH / 2) * S2 + w0;
+    r.rt = col ? RCOL + za : (TH / 2 + h2) * S2 + w0;
+    r.lb = col ? RCOL + h2 * HP2 + z0 : (lastc ? RCOL + TH / 2 : (TH / 2) * S2 + w0 + s);
+    r.rb = col ? RCOL + h2 * HP2 + za : (lastc ? RCOL + TH / 2 + h2 : (TH / 2 + h2) * S2 + w0 + s);
+    r.nx = col ? RCOL + hs * HP2 + z0 : (TH / 2) * S2 + w0 + hsub;
+    r.ny = col ? RCOL + zb : (TH / 2 + hs) * S2 + w0;
+    r.nxy = col ? RCOL + hs * HP2 + zb : (TH / 2 + hs) * S2 + w0 + hsub;
+    const u32 lt = rbuf[r.lt], rt = rbuf[r.rt], lb = rbuf[r.lb], rb = rbuf[r.rb];
+    const u32 ax = buf[f.nx], ay = buf[f.ny], axy = buf[f.nxy];
+    const u32 p = pred1<INTERP>(lt, rt, lb, rb);
+    const u32 qx = quant1s<IDENT>(ax, p, slut), qy = quant1s<IDENT>(ay, p, slut), qxy = quant1s<IDENT>(axy, p, slut);
+    if (xin) {
+        buf[f.nx] = (u8)qx;
+        rbuf[r.nx] = (u8)(p + qx);
     }
-    if (tl.Y0 + TH < H && lane < ncx) {            // row cells
-        const int x0 = lane << lstep;
-        if (tl.X0 + x0 < W) {
-            u8 *r0 = buf + TH * S + x0, *rs = buf + (TH + hs) * S + x0;
-            u8 *R0 = rbuf + (TH / 2) * S2 + (x0 >> 1), *R1 = rbuf + (TH / 2 + h2) * S2 + (x0 >> 1),
-               *RS = rbuf + (TH / 2 + hs) * S2 + (x0 >> 1);
-            const bool lastc = x0 + step == TW;
-            u32 lb = lastc ? rc[TH / 2] : R0[s], rb = lastc ? rc[TH / 2 + h2] : R1[s];
-            u32 p = pred1<INTERP>(R0[0], R1[0], lb, rb);
-            const bool xin = tl.X0 + x0 + s < W;
-            const bool yin = deep && tl.Y0 + TH + s < H;
-            if (xin) {
-                u32 q = quant1<IDENT>(r0[s], p, slut);
-                r0[s] = (u8)q;
-                R0[hsub] = (u8)(p + q);
-            }
-            if (yin) {
-                u32 q = quant1<IDENT>(rs[0], p, slut);
-                rs[0] = (u8)q;
-                RS[0] = (u8)(p + q);
-            }
-            if (xin && yin) {
-                u32 q = quant1<IDENT>(rs[s], p, slut);
-                rs[s] = (u8)q;
-                RS[hsub] = (u8)(p + q);
-            }
-        }
+    if (yin) {
+        buf[f.ny] = (u8)qy;
+        rbuf[r.ny] = (u8)(p + qy);
+    }
+    if (xin && yin) {
+        buf[f.nxy] = (u8)qxy;
+        rbuf[r.nxy] = (u8)(p + qxy);
     }
 }
 
@@ -350,17 +371,17 @@ __device__ __forceinline__ void enc_cells(u8 *buf, u8 *rbuf, const u8 *slut, int
         u32 p = pred1<INTERP>(rc[0], rc[s * S2], rr[0], rr[dn]);
         bool xin = !CHECK || tl.X0 + x0 + s < W, yin = !CHECK || tl.Y0 + y0 + s < H;
         if (xin) {
-            u32 q = quant1<IDENT>(c[s], p, slut);
+            u32 q = quant1s<IDENT>(c[s], p, slut);
             c[s] = (u8)q;
             rc[hs] = (u8)(p + q);
         }
         if (yin) {
-            u32 q = quant1<IDENT>(c[s * S], p, slut);
+            u32 q = quant1s<IDENT>(c[s * S], p, slut);
             c[s * S] = (u8)q;
             rc[hs * S2] = (u8)(p + q);
         }
         if (xin && yin) {
-            u32 q = quant1<IDENT>(c[s * S + s], p, slut);
+            u32 q = quant1s<IDENT>(c[s * S + s], p, slut);
             c[s * S + s] = (u8)q;
             rc[hs * S2 + hs] = (u8)(p + q);
         }
@@ -427,6 +448,137 @@ __device__ __noinline__ void enc_fine_generic(const u8 *buf, const u8 *rbuf, con
                                   quant4<IDENT>(O.z, pp2, slut), quant4<IDENT>(O.w, pp3, slut));
             store16(out, W, gx, gy + 1, o1, aligned);
         }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// encode, coarse levels, split-phase: one LDS dependency chain per level
+// ---------------------------------------------------------------------------------------------
+// At 12 waves per CU a dependent LDS round trip costs a few hundred cycles, and a level used to be
+// two or three of them back to back (cells, second half of the cells, halo cells).  Within a level
+// nothing depends on anything of that level, so all the reads of a level are issued first
+// (unconditionally: an idle lane reads offset 0), then the predictions, then all table look-ups, and
+// only the writes are conditional.
+struct CellAddr {
+    int lt, rt, lb, rb;      // corners, half-resolution reconstruction plane
+    int nx, ny, nxy;         // new pixels (x0+s, y0), (x0, y0+s), (x0+s, y0+s), full-resolution plane
+    int rx, ry, rxy;         // the same three in the reconstruction plane
+    bool xw, yw;             // write (x0+s, y0) / (x0, y0+s); (x0+s, y0+s) needs both
+};
+
+__device__ __forceinline__ CellAddr idle_cell()
+{
+    CellAddr c = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, false, false};
+    return c;
+}
+
+// i-th cell of level `s` inside the tile body (fast path: the body is inside the image)
+__device__ __forceinline__ CellAddr enc_body_cell(int i, int s, bool on)
+{
+    const int step = 2 * s, hsub = s >> 1, lstep = 31 - __clz(step);
+    const int ncx = TW >> lstep, lncx = 31 - __clz(ncx);
+    const int x0 = (i & (ncx - 1)) << lstep, y0 = (i >> lncx) << lstep;
+    const int c = y0 * S + x0, rc = (y0 >> 1) * S2 + (x0 >> 1);
+    const bool lastc = x0 + step == TW;      // right-hand corners are halo column 0 (transposed)
+    CellAddr a;
+    a.lt = rc;
+    a.rt = rc + s * S2;
+    a.lb = lastc ? RCOL + (y0 >> 1) : rc + s;
+    a.rb = lastc ? RCOL + (y0 >> 1) + s : rc + s * S2 + s;
+    a.nx = c + s;
+    a.ny = c + s * S;
+    a.nxy = c + s * S + s;
+    a.rx = rc + hsub;
+    a.ry = rc + hsub * S2;
+    a.rxy = rc + hsub * S2 + hsub;
+    a.xw = a.yw = true;
+    return on ? a : idle_cell();
+}
+
+// j-th halo cell of level `s`: j = 0..ncy are the column cells x0 == TW (y0 = j*step; y0 == TH is the
+// corner cell), j = ncy+1 .. ncy+ncx the row cells y0 == TH.  They recompute, bit-identically, what the
+// right / lower neighbour tiles compute for themselves.  Level-`sub` halo pixels off the tile edge are
+// needed only for sub >= 4 (`deep`); at sub == 2 only those on the edge itself.
+__device__ __forceinline__ CellAddr enc_halo_cell(int j, int s, Tile tl, u32 W, u32 H)
+{
+    const int step = 2 * s, hsub = s >> 1, lstep = 31 - __clz(step);
+    const int ncx = TW >> lstep, ncy = TH >> lstep;
+    const bool deep = s >= 4;
+    const int hs = hmap(s), h2 = hmap(step);
+    const bool col = j <= ncy;
+    const int y0 = j << lstep;
+    const bool corner = y0 == TH;
+    const int yb = corner ? TH + hs : y0 + s;
+    const int z0 = y0 >> 1, za = corner ? TH / 2 + h2 : (y0 + step) >> 1, zb = corner ? TH / 2 + hs : (y0 + s) >> 1;
+    const int x0 = (j - ncy - 1) << lstep, w0 = x0 >> 1;
+    const bool lastc = x0 + step == TW;
+    const bool active = col ? (tl.X0 + TW < W && tl.Y0 + y0 < H) : (j <= ncy + ncx && tl.Y0 + TH < H && tl.X0 + x0 < W);
+    CellAddr a;
+    a.lt = col ? RCOL + z0 : (TH / 2) * S2 + w0;
+    a.rt = col ? RCOL + za : (TH / 2 + h2) * S2 + w0;
+    a.lb = col ? RCOL + h2 * HP2 + z0 : (lastc ? RCOL + TH / 2 : (TH / 2) * S2 + w0 + s);
+    a.rb = col ? RCOL + h2 * HP2 + za : (lastc ? RCOL + TH / 2 + h2 : (TH / 2 + h2) * S2 + w0 + s);
+    a.nx = col ? HCOL + hs * HP + y0 : TH * S + x0 + s;
+    a.ny = col ? HCOL + yb : (TH + hs) * S + x0;
+    a.nxy = col ? HCOL + hs * HP + yb : (TH + hs) * S + x0 + s;
+    a.rx = col ? RCOL + hs * HP2 + z0 : (TH / 2) * S2 + w0 + hsub;
+    a.ry = col ? RCOL + zb : (TH / 2 + hs) * S2 + w0;
+    a.rxy = col ? RCOL + hs * HP2 + zb : (TH / 2 + hs) * S2 + w0 + hsub;
+    a.xw = col ? (deep && tl.X0 + TW + s < W) : (tl.X0 + x0 + s < W);
+    a.yw = col ? ((deep || !corner) && tl.Y0 + y0 + s < H) : (deep && tl.Y0 + TH + s < H);
+    return active ? a : idle_cell();
+}
+
+struct CellVal {
+    u32 lt, rt, lb, rb, ax, ay, axy;
+};
+
+__device__ __forceinline__ CellVal cell_load(const u8 *buf, const u8 *rbuf, const CellAddr &a)
+{
+    CellVal v = {rbuf[a.lt], rbuf[a.rt], rbuf[a.lb], rbuf[a.rb], buf[a.nx], buf[a.ny], buf[a.nxy]};
+    return v;
+}
+
+template <int INTERP, bool IDENT>
+__device__ __forceinline__ void cell_finish(u8 *buf, u8 *rbuf, const u8 *slut, const CellAddr &a, const CellVal &v)
+{
+    const u32 p = pred1<INTERP>(v.lt, v.rt, v.lb, v.rb);
+    const u32 qx = quant1s<IDENT>(v.ax, p, slut), qy = quant1s<IDENT>(v.ay, p, slut), qxy = quant1s<IDENT>(v.axy, p, slut);
+    if (a.xw) {
+        buf[a.nx] = (u8)qx;
+        rbuf[a.rx] = (u8)(p + qx);
+    }
+    if (a.yw) {
+        buf[a.ny] = (u8)qy;
+        rbuf[a.ry] = (u8)(p + qy);
+    }
+    if (a.xw && a.yw) {
+        buf[a.nxy] = (u8)qxy;
+        rbuf[a.rxy] = (u8)(p + qxy);
+    }
+}
+
+// One coarse level (sub >= 4) of an interior tile, body cells and halo cells in one chain.
+// sub == 4: 128 body cells (two per lane) + 25 halo cells; sub >= 8: <= 32 body cells on lanes 0..31,
+// the halo cells on lanes 32..63.
+template <int INTERP, bool IDENT>
+__device__ __forceinline__ void enc_level_coarse_fast(u8 *buf, u8 *rbuf, const u8 *slut, int s, Tile tl, u32 W, u32 H)
+{
+    const int lane = threadIdx.x;
+    if (s == 4) {
+        const CellAddr a0 = enc_body_cell(lane, 4, true), a1 = enc_body_cell(lane + NL, 4, true);
+        const CellAddr ah = lane < TH / 8 + 1 + TW / 8 ? enc_halo_cell(lane, 4, tl, W, H) : idle_cell();
+        const CellVal v0 = cell_load(buf, rbuf, a0), v1 = cell_load(buf, rbuf, a1), vh = cell_load(buf, rbuf, ah);
+        cell_finish<INTERP, IDENT>(buf, rbuf, slut, a0, v0);
+        cell_finish<INTERP, IDENT>(buf, rbuf, slut, a1, v1);
+        cell_finish<INTERP, IDENT>(buf, rbuf, slut, ah, vh);
+    } else {
+        const int step = 2 * s, lstep = 31 - __clz(step);
+        const int ncells = (TW >> lstep) * (TH >> lstep), nhalo = (TH >> lstep) + 1 + (TW >> lstep);
+        const CellAddr a = lane < 32 ? enc_body_cell(lane, s, lane < ncells)
+                                     : (lane - 32 < nhalo ? enc_halo_cell(lane - 32, s, tl, W, H) : idle_cell());
+        const CellVal v = cell_load(buf, rbuf, a);
+        cell_finish<INTERP, IDENT>(buf, rbuf, slut, a, v);
     }
 }
 
@@ -573,23 +725,41 @@ __device__ __forceinline__ void dec_fine_fast(const u8 *buf, const Buf &b)
 // encode, level sub == 2 of the tile body: four cells per lane; corners from the half-resolution
 // reconstruction lattice (rbuf), originals in / residuals out in buf, new reconstructions into rbuf
 template <int INTERP, bool IDENT>
-__device__ __forceinline__ void enc_level2_fast(u8 *buf, u8 *rbuf, const u8 *slut)
+__device__ __forceinline__ void enc_level2_fast(u8 *buf, u8 *rbuf, const u8 *slut, Tile tl, u32 W, u32 H)
 {
+    // the level's halo cells (17 column + 32 row cells): reads first, finished after the body below
+    const CellAddr ah = (int)threadIdx.x < TH / 4 + 1 + TW / 4 ? enc_halo_cell(threadIdx.x, 2, tl, W, H) : idle_cell();
+    const CellVal vh = cell_load(buf, rbuf, ah);
+    constexpr int NIT = (TH / 4) * CH / NL;
+    v4u A_[NIT], B_[NIT];
+    v2u cu_[NIT], cl_[NIT];
+    u32 hu_[NIT], hl_[NIT];
 #pragma unroll
-    for (int it = 0; it < (TH / 4) * CH / NL; ++it) {
+    for (int it = 0; it < NIT; ++it) {   // every read of the level before the first write
+        const int i = threadIdx.x + it * NL;
+        const int g = i >> LCH, c = i & (CH - 1);
+        const u8 *r0 = buf + 4 * g * S + 16 * c;
+        const u8 *q0 = rbuf + 2 * g * S2 + 8 * c;
+        A_[it] = *reinterpret_cast<const v4u *>(r0);
+        B_[it] = *reinterpret_cast<const v4u *>(r0 + 2 * S);
+        cu_[it] = *reinterpret_cast<const v2u *>(q0);
+        cl_[it] = *reinterpret_cast<const v2u *>(q0 + 2 * S2);
+        hu_[it] = rbuf[RCOL + 2 * g];
+        hl_[it] = rbuf[RCOL + 2 * g + 2];
+    }
+    LDS_ORDER();
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
         const int i = threadIdx.x + it * NL;
         const int g = i >> LCH, c = i & (CH - 1);
         u8 *r0 = buf + 4 * g * S + 16 * c;
         u8 *q0 = rbuf + 2 * g * S2 + 8 * c;
-        v4u A = *reinterpret_cast<const v4u *>(r0);
-        v4u B = *reinterpret_cast<const v4u *>(r0 + 2 * S);
-        v2u cu = *reinterpret_cast<const v2u *>(q0);
-        v2u cl = *reinterpret_cast<const v2u *>(q0 + 2 * S2);
+        const v4u A = A_[it], B = B_[it];
+        const v2u cu = cu_[it], cl = cl_[it];
         const bool last = c == CH - 1;
         u32 c8 = from_next_lane(cu.x), l8 = from_next_lane(cl.x);
-        const u32 hu = rbuf[RCOL + 2 * g], hl = rbuf[RCOL + 2 * g + 2];
-        c8 = last ? hu : c8;
-        l8 = last ? hl : l8;
+        c8 = last ? hu_[it] : c8;
+        l8 = last ? hl_[it] : l8;
         u32 ct = __builtin_amdgcn_perm(cu.y, cu.x, 0x06040200u), cb = __builtin_amdgcn_perm(cl.y, cl.x, 0x06040200u);
         u32 P = ct;
         if (INTERP == kInterpCrossed)
@@ -634,6 +804,7 @@ __device__ __forceinline__ void enc_level2_fast(u8 *buf, u8 *rbuf, const u8 *slu
         *reinterpret_cast<v2u *>(q0) = n0;
         *reinterpret_cast<v2u *>(q0 + S2) = n1;
     }
+    cell_finish<INTERP, IDENT>(buf, rbuf, slut, ah, vh);
 }
 
 template <int INTERP, bool IDENT>
@@ -646,40 +817,63 @@ __device__ __forceinline__ void enc_fine_fast(const u8 *buf, const u8 *rbuf, con
     const u8 *c0 = rbuf + rp0 * S2 + 8 * (lane & (CH - 1));
     const u8 *h0 = rbuf + RCOL + rp0;
     u32 voff = b.base + 2 * rp0 * b.W + 16 * (lane & (CH - 1));
+    const u32 Ws = __builtin_amdgcn_readfirstlane(b.W);
+    constexpr int NIT = (TH / 2) * CH / NL, PAIR = 2;   // two row-pair groups per LDS dependency chain
+    static_assert(NIT % PAIR == 0, "fine level iterations come in pairs");
 #pragma unroll 1
-    for (int it = 0; it < (TH / 2) * CH / NL;
-         ++it, r0 += 2 * (NL / CH) * S, c0 += (NL / CH) * S2, h0 += NL / CH, voff += 2 * (NL / CH) * b.W) {
-        v4u E = *reinterpret_cast<const v4u *>(r0);
-        v4u O = *reinterpret_cast<const v4u *>(r0 + S);
-        uint2 c = *reinterpret_cast<const uint2 *>(c0);
-        uint2 fl = *reinterpret_cast<const uint2 *>(c0 + S2);
-        u32 c8 = from_next_lane(c.x), f8 = from_next_lane(fl.x);
-        const u32 hc = h0[0], hf = h0[1];
-        c8 = last ? hc : c8;
-        f8 = last ? hf : f8;
-        u32 P0, P1;
-        pred8<INTERP>(c, c8, fl, f8, P0, P1);
-        u32 e0 = E.x, e1 = E.y, e2 = E.z, e3 = E.w, g0 = O.x, g1 = O.y, g2 = O.z, g3 = O.w;
-        if (IDENT) {
-            const u32 odd = 0xFF00FF00u;
-            const u32 pp0 = __builtin_amdgcn_perm(P0, P0, 0x01010000u), pp1 = __builtin_amdgcn_perm(P0, P0, 0x03030202u);
-            const u32 pp2 = __builtin_amdgcn_perm(P1, P1, 0x01010000u), pp3 = __builtin_amdgcn_perm(P1, P1, 0x03030202u);
-            e0 = sub4(e0, pp0 & odd); e1 = sub4(e1, pp1 & odd); e2 = sub4(e2, pp2 & odd); e3 = sub4(e3, pp3 & odd);
-            g0 = sub4(g0, pp0); g1 = sub4(g1, pp1); g2 = sub4(g2, pp2); g3 = sub4(g3, pp3);
-        } else {
-            const u32 N0 = ~P0, N1 = ~P1;
-            // row y: only the odd columns are new (cell j of the lane = byte j of P0, or byte j-4 of P1)
-            Q_PIX4(slut, P0, N0, e0, 1, 0, e0, 3, 1, e1, 1, 2, e1, 3, 3);
-            Q_PIX4(slut, P1, N1, e2, 1, 0, e2, 3, 1, e3, 1, 2, e3, 3, 3);
-            // row y+1: every column
-            Q_PIX4(slut, P0, N0, g0, 0, 0, g0, 1, 0, g0, 2, 1, g0, 3, 1);
-            Q_PIX4(slut, P0, N0, g1, 0, 2, g1, 1, 2, g1, 2, 3, g1, 3, 3);
-            Q_PIX4(slut, P1, N1, g2, 0, 0, g2, 1, 0, g2, 2, 1, g2, 3, 1);
-            Q_PIX4(slut, P1, N1, g3, 0, 2, g3, 1, 2, g3, 2, 3, g3, 3, 3);
+    for (int it = 0; it < NIT; it += PAIR) {
+        v4u E_[PAIR], O_[PAIR];
+        uint2 c_[PAIR], f_[PAIR];
+        u32 hc_[PAIR], hf_[PAIR];
+#pragma unroll
+        for (int j = 0; j < PAIR; ++j) {
+            const u8 *r = r0 + j * 2 * (NL / CH) * S, *c = c0 + j * (NL / CH) * S2, *h = h0 + j * (NL / CH);
+            E_[j] = *reinterpret_cast<const v4u *>(r);
+            O_[j] = *reinterpret_cast<const v4u *>(r + S);
+            c_[j] = *reinterpret_cast<const uint2 *>(c);
+            f_[j] = *reinterpret_cast<const uint2 *>(c + S2);
+            hc_[j] = h[0];
+            hf_[j] = h[1];
         }
-        v4u o0 = {e0, e1, e2, e3}, o1 = {g0, g1, g2, g3};
-        __builtin_amdgcn_raw_buffer_store_b128(o0, b.rd, voff, 0, 0);
-        __builtin_amdgcn_raw_buffer_store_b128(o1, b.rd, voff, __builtin_amdgcn_readfirstlane(b.W), 0);
+#pragma unroll
+        for (int j = 0; j < PAIR; ++j) {
+            const v4u E = E_[j], O = O_[j];
+            const uint2 c = c_[j], fl = f_[j];
+            // ninth corner of each lattice row: lane + 1, or the transposed halo column
+            u32 c8 = from_next_lane(c.x), f8 = from_next_lane(fl.x);
+            c8 = last ? hc_[j] : c8;
+            f8 = last ? hf_[j] : f8;
+            u32 P0, P1;
+            pred8<INTERP>(c, c8, fl, f8, P0, P1);
+            u32 e0 = E.x, e1 = E.y, e2 = E.z, e3 = E.w, g0 = O.x, g1 = O.y, g2 = O.z, g3 = O.w;
+            if (HGI_ABL & 2) {
+                e0 ^= P0; g0 ^= P1;
+            } else if (IDENT) {
+                const u32 odd = 0xFF00FF00u;
+                const u32 pp0 = __builtin_amdgcn_perm(P0, P0, 0x01010000u), pp1 = __builtin_amdgcn_perm(P0, P0, 0x03030202u);
+                const u32 pp2 = __builtin_amdgcn_perm(P1, P1, 0x01010000u), pp3 = __builtin_amdgcn_perm(P1, P1, 0x03030202u);
+                e0 = sub4(e0, pp0 & odd); e1 = sub4(e1, pp1 & odd); e2 = sub4(e2, pp2 & odd); e3 = sub4(e3, pp3 & odd);
+                g0 = sub4(g0, pp0); g1 = sub4(g1, pp1); g2 = sub4(g2, pp2); g3 = sub4(g3, pp3);
+            } else {
+                const u32 N0 = ~P0, N1 = ~P1;
+                // row y: only the odd columns are new (cell j of the lane = byte j of P0, or byte j-4 of P1)
+                Q_PIX4(slut, P0, N0, e0, 1, 0, e0, 3, 1, e1, 1, 2, e1, 3, 3);
+                Q_PIX4(slut, P1, N1, e2, 1, 0, e2, 3, 1, e3, 1, 2, e3, 3, 3);
+                // row y+1: every column
+                Q_PIX4(slut, P0, N0, g0, 0, 0, g0, 1, 0, g0, 2, 1, g0, 3, 1);
+                Q_PIX4(slut, P0, N0, g1, 0, 2, g1, 1, 2, g1, 2, 3, g1, 3, 3);
+                Q_PIX4(slut, P1, N1, g2, 0, 0, g2, 1, 0, g2, 2, 1, g2, 3, 1);
+                Q_PIX4(slut, P1, N1, g3, 0, 2, g3, 1, 2, g3, 2, 3, g3, 3, 3);
+            }
+            v4u o0 = {e0, e1, e2, e3}, o1 = {g0, g1, g2, g3};
+            const u32 vo = voff + j * 2 * (NL / CH) * Ws;
+            __builtin_amdgcn_raw_buffer_store_b128(o0, b.rd, vo, 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b128(o1, b.rd, vo, Ws, 0);
+        }
+        r0 += PAIR * 2 * (NL / CH) * S;
+        c0 += PAIR * (NL / CH) * S2;
+        h0 += PAIR * (NL / CH);
+        voff += PAIR * 2 * (NL / CH) * Ws;
     }
 }
 
@@ -784,12 +978,13 @@ template <int INTERP, bool SEEDED>
 __device__ __forceinline__ void dec_tile_fast(u8 *buf, const TileCtx &cur, const Seeds &sd, u32 k, u32 W, u32 H)
 {
     dec_seed<INTERP, SEEDED>(buf, sd, cur.tl, k);
-    for (int s = 1 << (k - 1); s >= 2; s >>= 1) {
-        if (s == 2)
-            dec_level2_fast<INTERP>(buf);
-        else
+    for (int s = 1 << (k - 1); s >= 2 && !(HGI_ABL & 1); s >>= 1) {
+        if (s == 2) {
+            if (!(HGI_ABL & 8)) dec_level2_fast<INTERP>(buf);
+        } else {
             dec_cells<INTERP, false>(buf, s, cur.tl, W, H);
-        dec_halo_cells<INTERP>(buf, s, cur.tl, W, H);
+        }
+        if (!(HGI_ABL & 4)) dec_halo_cells<INTERP>(buf, s, cur.tl, W, H);
         LDS_ORDER();
     }
     dec_fine_fast<INTERP>(buf, cur.b);
@@ -872,12 +1067,11 @@ __device__ __forceinline__ void enc_tile_fast(u8 *buf, u8 *rbuf, const u8 *slut,
                                               u32 W, u32 H)
 {
     enc_seed<SEEDED>(buf, rbuf, sd, cur.tl, k);
-    for (int s = 1 << (k - 1); s >= 2; s >>= 1) {
+    for (int s = 1 << (k - 1); s >= 2 && !(HGI_ABL & 1); s >>= 1) {
         if (s == 2)
-            enc_level2_fast<INTERP, IDENT>(buf, rbuf, slut);
+            enc_level2_fast<INTERP, IDENT>(buf, rbuf, slut, cur.tl, W, H);
         else
-            enc_cells<INTERP, IDENT, false>(buf, rbuf, slut, s, cur.tl, W, H);
-        enc_halo_cells<INTERP, IDENT>(buf, rbuf, slut, s, cur.tl, W, H);
+            enc_level_coarse_fast<INTERP, IDENT>(buf, rbuf, slut, s, cur.tl, W, H);
         LDS_ORDER();
     }
     enc_fine_fast<INTERP, IDENT>(buf, rbuf, slut, cur.b);

@@ -6,12 +6,14 @@
 # (FETCH_SIZE and WRITE_SIZE do not fit one TCC pass; never mix --pmc with API tracing).
 set -u
 TAG=${1:-r01}; shift || true
-ARGS=${@:---steps 5 --warmup 1 --no-cpu}
+ARGS=${@:---steps 20 --warmup 3 --no-cpu}
+PASSES=${PASSES:-trace fetch write sq1 sq2 tcc}
 OUT=$PWD/gpurun_out/prof/$TAG
 mkdir -p "$OUT"
 export TMPDIR=/tmp
 run() { # name, rocprof flags...
   local name=$1; shift
+  case " $PASSES " in *" $name "*) ;; *) return;; esac
   ( cd /tmp && rocprofv3 "$@" --output-format csv -d "$OUT/$name" -- python3 "$OLDPWD/bench.py" $ARGS ) > "$OUT/$name.log" 2>&1
   echo "$name rc=$?" >> "$OUT/passes.log"
 }
