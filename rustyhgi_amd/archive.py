@@ -1,0 +1,76 @@
+"""Mirror of the reference's `.hgi` container (src/archive.rs:13-56), byte-compatible on the wire:
+
+    55 A5 AD BA                      MAGIC 0xBAADA555, u32 little endian            (:13, :32)
+    bincode 1.x(Metadata)            u32 quantization_level (variant index), u32 interpolation,
+                                     u32 width, u32 height, u64 scale_level          (:15-22, :33)
+    raw DEFLATE, best compression, of bincode 1.x(Grid) = u64 len | bytes | u64 width  (:34-39; src/grid.rs:2-5)
+
+bincode 1.x defaults: little endian, fixed-width integers, enum variant as u32, usize as u64, Vec
+length as u64.  Any valid raw-DEFLATE stream decodes, so archives written here are
+readable by the reference and vice versa; the compressed bytes themselves need not match miniz's.
+This is host-side I/O around the codec, not part of the hot path.
+"""
+import struct
+import zlib
+
+import numpy as np
+
+from .grid import Grid
+from .interpolator import InterpolationType
+from .quantizator import QuantizationLevel
+
+MAGIC = 0xBAADA555
+
+
+class Metadata:
+    """src/archive.rs:15-22."""
+
+    def __init__(self, quantization_level, interpolation, width, height, scale_level):
+        self.quantization_level = QuantizationLevel(quantization_level)
+        self.interpolation = InterpolationType(interpolation)
+        self.width, self.height, self.scale_level = int(width), int(height), int(scale_level)
+
+    def __eq__(self, o):
+        return isinstance(o, Metadata) and vars(self) == vars(o)
+
+    def __repr__(self):
+        return "Metadata(%s, %s, %dx%d, scale_level=%d)" % (self.quantization_level.name, self.interpolation.name,
+                                                            self.width, self.height, self.scale_level)
+
+
+class Archive:
+    """src/archive.rs:24-28, with G = Grid."""
+
+    def __init__(self, metadata, grid):
+        self.metadata, self.grid = metadata, grid
+
+    def __eq__(self, o):
+        return isinstance(o, Archive) and self.metadata == o.metadata and self.grid == o.grid
+
+    def serialize_to_writer(self, w):
+        """src/archive.rs:31-41."""
+        m = self.metadata
+        w.write(struct.pack("<I", MAGIC))
+        w.write(struct.pack("<IIIIQ", int(m.quantization_level), int(m.interpolation), m.width, m.height, m.scale_level))
+        buf = self.grid.buffer
+        if type(buf).__module__.startswith("torch"):
+            buf = buf.cpu().numpy()
+        raw = np.ascontiguousarray(buf, dtype=np.uint8).tobytes()
+        body = struct.pack("<Q", len(raw)) + raw + struct.pack("<Q", self.grid.width)
+        enc = zlib.compressobj(9, zlib.DEFLATED, -15)          # raw DEFLATE, Compression::best()
+        w.write(enc.compress(body) + enc.flush())
+
+    @classmethod
+    def deserialize_from_reader(cls, r):
+        """src/archive.rs:43-55."""
+        head = r.read(4)
+        if len(head) != 4 or struct.unpack("<I", head)[0] != MAGIC:
+            raise ValueError("incorrect magic number")               # :48-50
+        q, i, width, height, scale = struct.unpack("<IIIIQ", r.read(24))
+        body = zlib.decompressobj(-15).decompress(r.read())
+        (n,) = struct.unpack_from("<Q", body, 0)
+        if len(body) < 16 + n:
+            raise ValueError("truncated grid")
+        data = np.frombuffer(body, np.uint8, n, 8).copy()
+        (gwidth,) = struct.unpack_from("<Q", body, 8 + n)
+        return cls(Metadata(q, i, width, height, scale), Grid(data, gwidth))

@@ -601,15 +601,27 @@ struct Stage {
 
 // Rows below the image return 0 from the buffer range check; columns right of the image are masked
 // with wave-uniform tests.
+template <bool RAGGED>
 __device__ __forceinline__ void stage_issue(Stage &st, const Buf &b, Tile tl, int k, int nh)
 {
     const int lane = threadIdx.x, c = lane & (CH - 1), r = lane >> LCH;
     const u32 W = __builtin_amdgcn_readfirstlane(b.W);   // soffset operands must be provably uniform
     const u32 voff = b.base + r * W + 16 * c;
+    // Interior tiles: every chunk is inside the image.  Ragged tiles (edge kernels): rows below the
+    // image come back as 0 from the range check (the row offsets go through voffset there, which is
+    // what the check sees), chunks right of it are masked.
+    const bool cin = tl.X0 + 16 * c < W;
 #pragma unroll
-    for (int j = 0; j < TH / 8; ++j) st.v[j] = __builtin_amdgcn_raw_buffer_load_b128(b.rs, voff, j * 8 * W, 0);
+    for (int j = 0; j < TH / 8; ++j) {
+        st.v[j] = v4u{0, 0, 0, 0};
+        if (RAGGED) {
+            if (cin) st.v[j] = __builtin_amdgcn_raw_buffer_load_b128(b.rs, voff + j * 8 * W, 0, 0);
+        } else {
+            st.v[j] = __builtin_amdgcn_raw_buffer_load_b128(b.rs, voff, j * 8 * W, 0);
+        }
+    }
     st.hv = v4u{0, 0, 0, 0};
-    if (lane < nh * CH) st.hv = __builtin_amdgcn_raw_buffer_load_b128(b.rs, b.base + (TH + hoff(r)) * W + 16 * c, 0, 0);
+    if (lane < nh * CH && cin) st.hv = __builtin_amdgcn_raw_buffer_load_b128(b.rs, b.base + (TH + hoff(r)) * W + 16 * c, 0, 0);
     const int hy = lane < TH / 2 ? 2 * lane : TH + hoff(lane - TH / 2);
     const u32 xo = b.base + hy * W + TW;
     const u32 xr = tl.X0 + TW;              // first column right of the tile
@@ -990,36 +1002,58 @@ __device__ __forceinline__ void dec_tile_fast(u8 *buf, const TileCtx &cur, const
     dec_fine_fast<INTERP>(buf, cur.b);
 }
 
-// One block (= one wave) per interior tile, XCD-contiguous order.  (A persistent variant -- resident
-// waves pulling tiles from per-XCD atomic counters and prefetching the next tile into registers --
-// was built and measured: not faster on MI355X, see DESIGN.md "Scheduling".)
-template <int INTERP, bool SEEDED>
-__global__ __launch_bounds__(NL) void k_dec_fast(const u8 *__restrict__ src, u8 *__restrict__ dst, Frames f, u32 k,
-                                                 Seeds sd, TileGrid g)
+// One block (= one wave) per tile, ONE launch per batch.  The first blocks take the ragged tiles
+// (their count padded to a multiple of 8 so that b % 8 keeps labelling the XCD), so the slow tiles
+// start first and overlap the interior ones; the interior tiles follow in XCD-contiguous order.
+// (A persistent variant -- resident waves pulling tiles from per-XCD atomic counters and prefetching
+// the next tile into registers -- was built and measured: not faster on MI355X, see DESIGN.md
+// "Scheduling".)
+struct BlockRole {
+    bool edge, idle;
+    u32 index;       // edge tile index, or position of the interior tile in the XCD-contiguous order
+};
+
+__device__ __forceinline__ BlockRole block_role(const TileGrid &g)
 {
-    extern __shared__ __attribute__((aligned(16))) u8 smem[];
-    u8 *buf = smem - HCOL;
-    const int nh = k >= 2 ? (int)k : 1;
-    TileCtx cur = fast_ctx(range_first(g.nfast, blockIdx.x & 7u) + (blockIdx.x >> 3), src, dst, f, g);
-    Stage st;
-    stage_issue(st, cur.b, cur.tl, (int)k, nh);
-    stage_commit(buf, st, nh);
-    LDS_ORDER();
-    dec_tile_fast<INTERP, SEEDED>(buf, cur, sd, k, f.width, f.height);
+    const u32 b = blockIdx.x, ne8 = (g.nedge + 7u) & ~7u;
+    BlockRole r;
+    r.edge = b < ne8;
+    r.idle = r.edge && b >= g.nedge;
+    const u32 fb = b - ne8;
+    r.index = r.edge ? b : range_first(g.nfast, fb & 7u) + (fb >> 3);
+    return r;
 }
 
 template <int INTERP, bool SEEDED>
-__global__ __launch_bounds__(NL) void k_dec_edge(const u8 *__restrict__ src, u8 *__restrict__ dst, Frames f, u32 k,
-                                                 Seeds sd, TileGrid g, u32 aligned)
+__global__ __launch_bounds__(NL) void k_dec_tiles(const u8 *__restrict__ src, u8 *__restrict__ dst, Frames f, u32 k,
+                                                  Seeds sd, TileGrid g, u32 aligned)
 {
     extern __shared__ __attribute__((aligned(16))) u8 smem[];
     u8 *buf = smem - HCOL;
-    const Tile tl = edge_tile(blockIdx.x, g);
+    const int nh = k >= 2 ? (int)k : 1;
     const u32 W = f.width, H = f.height;
+    const BlockRole role = block_role(g);
+    if (role.idle) return;
+    if (!role.edge) {
+        TileCtx cur = fast_ctx(role.index, src, dst, f, g);
+        Stage st;
+        stage_issue<false>(st, cur.b, cur.tl, (int)k, nh);
+        stage_commit(buf, st, nh);
+        LDS_ORDER();
+        dec_tile_fast<INTERP, SEEDED>(buf, cur, sd, k, W, H);
+        return;
+    }
+    // ragged tile (body crosses the image edge), unaligned rows, or offsets beyond 32 bits: every access checked
+    const Tile tl = edge_tile(role.index, g);
     const u8 *fr = src + (size_t)tl.frame * f.frame_stride;
     u8 *out = dst + (size_t)tl.frame * f.frame_stride;
-    const int nh = k >= 2 ? (int)k : 1;
-    stage_tile_generic(buf, fr, W, H, tl, nh, aligned != 0);
+    if (aligned & 2u) {   // aligned rows and 32-bit offsets: the buffer-load staging of the fast path
+        Stage st;
+        stage_issue<true>(st, make_buf(fr, out, W, H, tl), tl, (int)k, nh);
+        stage_commit(buf, st, nh);
+    } else {
+        stage_tile_generic(buf, fr, W, H, tl, nh, (aligned & 1u) != 0);
+    }
     LDS_ORDER();
     dec_seed<INTERP, SEEDED>(buf, sd, tl, k);
     for (int s = 1 << (k - 1); s >= 2; s >>= 1) {
@@ -1027,7 +1061,7 @@ __global__ __launch_bounds__(NL) void k_dec_edge(const u8 *__restrict__ src, u8 
         dec_halo_cells<INTERP>(buf, s, tl, W, H);
         LDS_ORDER();
     }
-    dec_fine_generic<INTERP>(buf, out, tl, W, H, aligned != 0);
+    dec_fine_generic<INTERP>(buf, out, tl, W, H, (aligned & 1u) != 0);
 }
 
 // ---- encode ---------------------------------------------------------------------------------------
@@ -1078,41 +1112,39 @@ __device__ __forceinline__ void enc_tile_fast(u8 *buf, u8 *rbuf, const u8 *slut,
 }
 
 template <int INTERP, bool IDENT, bool SEEDED>
-__global__ __launch_bounds__(NL) void k_enc_fast(const u8 *__restrict__ src, u8 *__restrict__ dst, Frames f, u32 k,
-                                                 Lut256 lut, Seeds sd, TileGrid g)
+__global__ __launch_bounds__(NL) void k_enc_tiles(const u8 *__restrict__ src, u8 *__restrict__ dst, Frames f, u32 k,
+                                                  Lut256 lut, Seeds sd, TileGrid g, u32 aligned)
 {
     extern __shared__ __attribute__((aligned(16))) u8 smem[];
     const int nh = k >= 2 ? (int)k : 1;
     u8 *buf = smem - HCOL;
     u8 *rbuf = smem + buf_bytes(nh) - RCOL;
     u8 *slut = smem + buf_bytes(nh) + rbuf_bytes(nh);
-    if (!IDENT) reinterpret_cast<u32 *>(slut)[threadIdx.x] = lut.w[threadIdx.x];
-    TileCtx cur = fast_ctx(range_first(g.nfast, blockIdx.x & 7u) + (blockIdx.x >> 3), src, dst, f, g);
-    Stage st;
-    stage_issue(st, cur.b, cur.tl, (int)k, nh);
-    clear_lattice(rbuf, nh);
-    stage_commit(buf, st, nh);
-    LDS_ORDER();
-    enc_tile_fast<INTERP, IDENT, SEEDED>(buf, rbuf, slut, cur, sd, k, f.width, f.height);
-}
-
-template <int INTERP, bool IDENT, bool SEEDED>
-__global__ __launch_bounds__(NL) void k_enc_edge(const u8 *__restrict__ src, u8 *__restrict__ dst, Frames f, u32 k,
-                                                 Lut256 lut, Seeds sd, TileGrid g, u32 aligned)
-{
-    extern __shared__ __attribute__((aligned(16))) u8 smem[];
-    const int nh0 = k >= 2 ? (int)k : 1;
-    u8 *buf = smem - HCOL;
-    u8 *rbuf = smem + buf_bytes(nh0) - RCOL;
-    u8 *slut = smem + buf_bytes(nh0) + rbuf_bytes(nh0);
-    const Tile tl = edge_tile(blockIdx.x, g);
     const u32 W = f.width, H = f.height;
+    const BlockRole role = block_role(g);
+    if (role.idle) return;
+    if (!IDENT) reinterpret_cast<u32 *>(slut)[threadIdx.x] = lut.w[threadIdx.x];
+    if (!role.edge) {
+        TileCtx cur = fast_ctx(role.index, src, dst, f, g);
+        Stage st;
+        stage_issue<false>(st, cur.b, cur.tl, (int)k, nh);
+        clear_lattice(rbuf, nh);
+        stage_commit(buf, st, nh);
+        LDS_ORDER();
+        enc_tile_fast<INTERP, IDENT, SEEDED>(buf, rbuf, slut, cur, sd, k, W, H);
+        return;
+    }
+    const Tile tl = edge_tile(role.index, g);
     const u8 *fr = src + (size_t)tl.frame * f.frame_stride;
     u8 *out = dst + (size_t)tl.frame * f.frame_stride;
-    const int nh = k >= 2 ? (int)k : 1;
-    if (!IDENT) reinterpret_cast<u32 *>(slut)[threadIdx.x] = lut.w[threadIdx.x];
     clear_lattice(rbuf, nh);
-    stage_tile_generic(buf, fr, W, H, tl, nh, aligned != 0);
+    if (aligned & 2u) {
+        Stage st;
+        stage_issue<true>(st, make_buf(fr, out, W, H, tl), tl, (int)k, nh);
+        stage_commit(buf, st, nh);
+    } else {
+        stage_tile_generic(buf, fr, W, H, tl, nh, (aligned & 1u) != 0);
+    }
     LDS_ORDER();
     enc_seed<SEEDED>(buf, rbuf, sd, tl, k);
     for (int s = 1 << (k - 1); s >= 2; s >>= 1) {
@@ -1120,7 +1152,7 @@ __global__ __launch_bounds__(NL) void k_enc_edge(const u8 *__restrict__ src, u8 
         enc_halo_cells<INTERP, IDENT>(buf, rbuf, slut, s, tl, W, H);
         LDS_ORDER();
     }
-    enc_fine_generic<INTERP, IDENT>(buf, rbuf, slut, out, tl, W, H, aligned != 0);
+    enc_fine_generic<INTERP, IDENT>(buf, rbuf, slut, out, tl, W, H, (aligned & 1u) != 0);
 }
 
 inline bool ptr16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
@@ -1145,10 +1177,10 @@ FusedGeom fused_geom(const void *a, const void *b, const Frames &f)
     g.full_y = fast ? f.height / TH : 0;
     if (g.full_x == 0 || g.full_y == 0) g.full_x = g.full_y = 0;
     const u64 all = (u64)g.tiles_x * g.tiles_y * f.batch, nfast = (u64)g.full_x * g.full_y * f.batch;
-    r.ok = all > 0 && all < (1ull << 31);
+    r.ok = all > 0 && all + 8 < (1ull << 31);
     g.nfast = (u32)nfast;
     g.nedge = (u32)(all - nfast);
-    r.aligned = aligned ? 1u : 0u;
+    r.aligned = (aligned ? 1u : 0u) | (fast ? 2u : 0u);   // bit 0: 16-B rows; bit 1: buffer-load staging allowed
     return r;
 }
 
@@ -1164,11 +1196,8 @@ hipError_t launch_decode_fused(const uint8_t *grid, uint8_t *img, const Frames &
     const dim3 b(NL);
     const int nh = k >= 2 ? (int)k : 1;
     const size_t lds = (size_t)buf_bytes(nh);
-#define HGI_DEC(I, SE)                                                                                              \
-    do {                                                                                                            \
-        if (g.nfast) hipLaunchKernelGGL((k_dec_fast<I, SE>), dim3(g.nfast), b, lds, s, grid, img, f, k, sd, g);      \
-        if (g.nedge) hipLaunchKernelGGL((k_dec_edge<I, SE>), dim3(g.nedge), b, lds, s, grid, img, f, k, sd, g, r.aligned); \
-    } while (0)
+    const dim3 blocks(((g.nedge + 7u) & ~7u) + g.nfast);
+#define HGI_DEC(I, SE) hipLaunchKernelGGL((k_dec_tiles<I, SE>), blocks, b, lds, s, grid, img, f, k, sd, g, r.aligned)
     if (interp == kInterpCrossed) {
         if (seeds) HGI_DEC(kInterpCrossed, true); else HGI_DEC(kInterpCrossed, false);
     } else {
@@ -1188,12 +1217,9 @@ hipError_t launch_encode_fused(const uint8_t *img, uint8_t *grid, const Frames &
     const dim3 b(NL);
     const int nh = k >= 2 ? (int)k : 1;
     const size_t lds = (size_t)buf_bytes(nh) + rbuf_bytes(nh) + 256;
-#define HGI_ENC(I, ID, SE)                                                                                          \
-    do {                                                                                                            \
-        if (g.nfast) hipLaunchKernelGGL((k_enc_fast<I, ID, SE>), dim3(g.nfast), b, lds, s, img, grid, f, k, lut, sd, g); \
-        if (g.nedge)                                                                                                \
-            hipLaunchKernelGGL((k_enc_edge<I, ID, SE>), dim3(g.nedge), b, lds, s, img, grid, f, k, lut, sd, g, r.aligned); \
-    } while (0)
+    const dim3 blocks(((g.nedge + 7u) & ~7u) + g.nfast);
+#define HGI_ENC(I, ID, SE) \
+    hipLaunchKernelGGL((k_enc_tiles<I, ID, SE>), blocks, b, lds, s, img, grid, f, k, lut, sd, g, r.aligned)
 #define HGI_ENC_I(I)                                                          \
     do {                                                                      \
         if (ident) { if (seeds) HGI_ENC(I, true, true); else HGI_ENC(I, true, false); } \

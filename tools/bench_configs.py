@@ -1,0 +1,85 @@
+#!/usr/bin/env python3
+"""Times the five BASELINE.json configurations on one MI355X (device-resident, hipEvents through torch)
+next to the CPU oracle on the same inputs, and checks each GPU result against the oracle.
+Writes a markdown table to stdout (committed under profiles/)."""
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import rustyhgi_amd as H                      # noqa: E402
+from rustyhgi_amd import _ffi                 # noqa: E402
+from rustyhgi_amd.interpolator import Crossed  # noqa: E402
+from rustyhgi_amd.quantizator import Linear, QuantizationLevel  # noqa: E402
+from oracle import hgi_oracle as O            # noqa: E402
+
+SEED0 = 0x48474930
+
+
+def gpu_time(fn, reps):
+    for _ in range(3):
+        fn()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / reps * 1e3   # us
+
+
+def main():
+    dev = torch.device("cuda", 0)
+    stream = torch.cuda.Stream(dev)
+    torch.cuda.set_stream(stream)
+    ctx = H.Context(0)
+    ctx.set_stream(stream.cuda_stream)
+    from PIL import Image
+    lena = np.fromfile(os.path.join(ROOT, "tests/golden/lena_256.u8"), np.uint8).reshape(256, 256)
+    fullhd = np.array(Image.open(os.path.join(ROOT, "tests/golden/fullhd_luma.png")))
+    cases = [
+        ("C0 LENA.TIF 256x256 L4 Medium", lena[None], 4, QuantizationLevel.Medium, 200),
+        ("C1 fullhd luma 1920x1080 L4 Medium", fullhd[None], 4, QuantizationLevel.Medium, 200),
+        ("C1' xy 1920x1080 L4 Lossless (criterion image)", O.synth(O.SYNTH_XY, 0, 0, 1920, 1080)[None], 4, QuantizationLevel.Lossless, 200),
+        ("C2 noise(2) 4096x4096 L6 Lossless", O.synth(O.SYNTH_NOISE, SEED0 + 2, 0, 4096, 4096)[None], 6, QuantizationLevel.Lossless, 100),
+        ("C3 ramp(3) 64x4096x4096 L4 Medium (one GPU's shard)", None, 4, QuantizationLevel.Medium, 20),
+        ("C4 ramp(4) 16384x16384 L8 High", O.synth(O.SYNTH_RAMP, SEED0 + 4, 0, 16384, 16384)[None], 8, QuantizationLevel.High, 20),
+    ]
+    print("| config | frames x WxH | GPU encode us | GPU decode us | GPU enc+dec Mpx/s | algorithmic GB/s (enc / dec) | oracle 1 thread Mpx/s | bit-exact vs oracle |")
+    print("|---|---|---|---|---|---|---|---|")
+    for name, host, levels, level, reps in cases:
+        q = Linear.from_level(level)
+        if host is None:
+            F, S = 64, 4096
+            imgs = torch.empty((F, S, S), dtype=torch.uint8, device=dev)
+            _ffi.check(_ffi.lib().hgi_synth_u8_dev(ctx.handle, _ffi.SYNTH_RAMP, SEED0 + 3, 0, S, S, imgs.data_ptr(), F, S * S))
+            host_check = imgs[:1].cpu().numpy()
+        else:
+            imgs = torch.from_numpy(np.ascontiguousarray(host)).to(dev)
+            host_check = host[:1]
+        F, Hh, W = imgs.shape
+        ctx.reserve(W, Hh, levels, F)
+        enc = H.Encoder(Crossed(), q, levels, context=ctx)
+        dec = H.Decoder(Crossed(), context=ctx)
+        grids, outs = torch.empty_like(imgs), torch.empty_like(imgs)
+        te = gpu_time(lambda: enc.encode_batch(imgs, out=grids), reps)
+        td = gpu_time(lambda: dec.decode_batch(grids, levels, out=outs), reps)
+        t0 = time.perf_counter()
+        want = O.encode(host_check[0], levels, q.table())
+        wdec = O.decode(want, levels)
+        tcpu = time.perf_counter() - t0
+        ok = bool((grids[0].cpu().numpy() == want).all() and (outs[0].cpu().numpy() == wdec).all())
+        px = F * Hh * W
+        print("| %s | %d x %dx%d | %.1f | %.1f | %.0f | %.0f / %.0f | %.1f | %s |" % (
+            name, F, W, Hh, te, td, px / (te + td), 2 * px / te / 1e3, 2 * px / td / 1e3, Hh * W / tcpu / 1e6,
+            "yes" if ok else "NO"))
+        del imgs, grids, outs
+    ctx.close()
+
+
+if __name__ == "__main__":
+    main()
