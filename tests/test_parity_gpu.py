@@ -274,3 +274,50 @@ def test_cpp_mirror_lib_rs_port(H):
     out = subprocess.run([exe], capture_output=True, text=True, timeout=120)
     assert out.returncode == 0, out.stdout + out.stderr
     assert "ok:" in out.stdout
+
+
+def test_cli_hgi_test_report_and_archive_interop(H, oracle, lena, tmp_path):
+    """The C++ `hgi` CLI (cli/hgi_cli.cpp, port of src/main.rs): `hgi test` on LENA (BASELINE config C0,
+    defaults level=4 medium) prints the report SURVEY Appendix B.2 derives from the reference source, its
+    .hgi is readable by the Python Archive mirror, and `hgi decode` reads an archive written by Python."""
+    import io
+    import os
+    import subprocess
+    from PIL import Image
+    from conftest import ROOT
+    from rustyhgi_amd import Archive, Grid, Metadata
+    exe = str(tmp_path / "hgi")
+    subprocess.check_call(["g++", "-O1", "-std=c++17", "-I", os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "cli", "hgi_cli.cpp"), "-L", os.path.join(ROOT, "rustyhgi_amd"),
+                           "-lhgi_hip", "-lz", "-Wl,-rpath," + os.path.join(ROOT, "rustyhgi_amd"), "-o", exe])
+    Image.fromarray(lena).save(str(tmp_path / "LENA.TIF"), compression=None)     # uncompressed, like res/LENA.TIF
+    out = subprocess.run([exe, "test", "LENA.TIF", "-s", "_m"], cwd=str(tmp_path), capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr
+    lines = out.stdout.splitlines()
+    assert lines[0] == "Uncompressed: 64 kb" and lines[1] == "Compressed:   15 kb"
+    assert lines[2].startswith("Ratio:        4.0") and lines[3] == "SD:           9.17"
+    lut = oracle.linear_lut(2)[0]
+    want = oracle.encode(lena, 4, lut)
+    with open(str(tmp_path / "LENA_m.hgi"), "rb") as f:
+        arc = Archive.deserialize_from_reader(f)
+    assert arc.metadata == Metadata(2, 0, 256, 256, 4) and (arc.grid.as_image() == want).all()
+    pgm = open(str(tmp_path / "LENA_m.pgm"), "rb").read()
+    assert pgm.startswith(b"P5\n256 256\n255\n") and pgm[15:] == oracle.decode(want, 4).tobytes()
+    # Python-written archive (High) -> `hgi decode`
+    g3 = oracle.encode(lena, 4, oracle.linear_lut(3)[0])
+    with open(str(tmp_path / "py.hgi"), "wb") as f:
+        Archive(Metadata(3, 0, 256, 256, 4), Grid(g3, 256)).serialize_to_writer(f)
+    out = subprocess.run([exe, "decode", "-i", "py.hgi", "-o", "py.pgm"], cwd=str(tmp_path), capture_output=True, text=True)
+    assert out.returncode == 0, out.stderr
+    assert open(str(tmp_path / "py.pgm"), "rb").read()[15:] == oracle.decode(g3, 4).tobytes()
+    # encode via PGM input, case-insensitive level, then errors
+    out = subprocess.run([exe, "encode", "-i", "LENA_m.pgm", "-o", "e.hgi", "-q", "LoW", "-l", "3"], cwd=str(tmp_path),
+                         capture_output=True, text=True)
+    assert out.returncode == 0, out.stderr
+    with open(str(tmp_path / "e.hgi"), "rb") as f:
+        arc = Archive.deserialize_from_reader(f)
+    dec_m = oracle.decode(want, 4)
+    assert arc.metadata == Metadata(1, 0, 256, 256, 3) and (arc.grid.as_image() == oracle.encode(dec_m, 3, oracle.linear_lut(1)[0])).all()
+    bad = subprocess.run([exe, "encode", "-i", "LENA.TIF", "-o", "x.hgi", "-q", "loseless"], cwd=str(tmp_path),
+                         capture_output=True, text=True)
+    assert bad.returncode != 0 and "An error occured" in bad.stderr          # SURVEY T4: not typo tolerant
