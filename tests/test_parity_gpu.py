@@ -321,3 +321,50 @@ def test_cli_hgi_test_report_and_archive_interop(H, oracle, lena, tmp_path):
     bad = subprocess.run([exe, "encode", "-i", "LENA.TIF", "-o", "x.hgi", "-q", "loseless"], cwd=str(tmp_path),
                          capture_output=True, text=True)
     assert bad.returncode != 0 and "An error occured" in bad.stderr          # not typo tolerant
+
+
+def test_batch_layouts_and_alignment(H, ctxs, oracle):
+    """Device-pointer entry points under awkward layouts: padded frame_stride, base pointers that are not
+    16-B aligned (forces the fully checked path), ragged frames in a batch, both directions."""
+    import torch
+    from rustyhgi_amd import _ffi
+    L = _ffi.lib()
+    ctx = ctxs["fused"]
+    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    rng = np.random.default_rng(5)
+    lut = oracle.linear_lut(3)[0]
+    for (B, Hh, W, pad, shift, levels) in [(3, 130, 384, 4096, 0, 4), (2, 64, 128, 16, 16, 4), (3, 70, 272, 48, 0, 5),
+                                           (2, 96, 256, 0, 1, 4), (4, 33, 100, 7, 3, 3), (2, 200, 640, 640, 0, 7)]:
+        stride = Hh * W + pad
+        host = rng.integers(0, 256, (B, Hh, W), dtype=np.uint8)
+        src = torch.zeros(B * stride + 64, dtype=torch.uint8, device="cuda")
+        dst = torch.full((B * stride + 64,), 0xEE, dtype=torch.uint8, device="cuda")
+        out = torch.full((B * stride + 64,), 0xDD, dtype=torch.uint8, device="cuda")
+        for f in range(B):
+            src[shift + f * stride: shift + f * stride + Hh * W] = torch.from_numpy(host[f].reshape(-1)).cuda()
+        _ffi.check(L.hgi_encode_u8_dev(ctx.handle, src.data_ptr() + shift, W, Hh, levels, 1, lut.ctypes.data,
+                                       dst.data_ptr() + shift, B, stride))
+        _ffi.check(L.hgi_decode_u8_dev(ctx.handle, dst.data_ptr() + shift, W, Hh, levels, 1, out.data_ptr() + shift, B, stride))
+        torch.cuda.synchronize()
+        d, o = dst.cpu().numpy(), out.cpu().numpy()
+        for f in range(B):
+            want = oracle.encode(host[f], levels, lut)
+            a = shift + f * stride
+            assert_same(d[a:a + Hh * W].reshape(Hh, W), want, "encode B%d %dx%d pad%d shift%d frame %d" % (B, W, Hh, pad, shift, f))
+            assert_same(o[a:a + Hh * W].reshape(Hh, W), oracle.decode(want, levels), "decode frame %d" % f)
+            if pad:   # the padding between frames is never written
+                assert (d[a + Hh * W:a + stride] == 0xEE).all() and (o[a + Hh * W:a + stride] == 0xDD).all()
+        assert (d[:shift] == 0xEE).all() and (d[shift + B * stride - pad:] == 0xEE).all()
+    ctx.use_own_stream()
+
+
+@pytest.mark.parametrize("w,h,levels", [(8192, 64, 4), (128, 4096, 6), (16, 5000, 3), (5000, 16, 3), (2048, 2048, 31),
+                                        (129, 65, 31), (1920, 1080, 1), (1920, 1080, 2), (1936, 1096, 6)])
+def test_extreme_shapes_and_levels(ctxs, oracle, w, h, levels):
+    """Strips, tile-boundary +1 sizes, levels = 31 (only the base sample (0,0) seeds the whole image)."""
+    img = oracle.synth(oracle.SYNTH_NOISE, 77, levels, w, h)
+    for q in (0, 2):
+        lut = oracle.linear_lut(q)[0]
+        want = oracle.encode(img, levels, lut)
+        assert_same(gpu_encode(ctxs["fused"], img, levels, lut), want, "encode %dx%d L%d q%d" % (w, h, levels, q))
+        assert_same(gpu_decode(ctxs["fused"], want, levels), oracle.decode(want, levels), "decode %dx%d L%d q%d" % (w, h, levels, q))
