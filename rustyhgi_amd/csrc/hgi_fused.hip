@@ -33,7 +33,7 @@ constexpr int TH = kTileH;
 constexpr int NL = kThreads;       // lanes
 constexpr int CH = TW / 16;        // 16-B chunks per tile row
 constexpr int LCH = 3;             // log2(CH)
-constexpr int HR = kFusedMaxLevels;   // halo rows / columns a tile can need (offsets 0,4,8,16,32,64)
+constexpr int HR = 6;   // halo rows / columns a tile can need (offsets 0,4,8,16,32,64); >= kFusedMaxLevels
 // LDS layout (bank-conflict model and measurements: DESIGN.md "LDS layout").  LDS is dynamic: a tile
 // that needs nh halo rows allocates TH + nh rows, which is what sets the waves per CU.
 //   full-resolution plane: [halo columns, transposed][rows 0 .. TH + nh - 1, pitch S]
@@ -57,7 +57,7 @@ static_assert(S % 16 == 0 && (HR * HP) % 16 == 0 && S2 % 8 == 0 && (HR * HP2) % 
                   HP2 >= TH / 2 + HR && buf_bytes(1) % 16 == 0 && rbuf_bytes(1) % 8 == 0,
               "LDS pitches keep vector alignment");
 // k = 4 (the flagship configuration): 16 decode waves and 12 encode waves per CU fit the 160 KiB of LDS
-static_assert(16 * buf_bytes(4) <= 160 * 1024 && 12 * (buf_bytes(4) + rbuf_bytes(4) + 256) <= 160 * 1024, "LDS budget");
+static_assert(TH != 64 || (16 * buf_bytes(4) <= 160 * 1024 && 12 * (buf_bytes(4) + rbuf_bytes(4) + 256) <= 160 * 1024), "LDS budget");
 
 #ifndef HGI_LOAD_AUX
 #define HGI_LOAD_AUX 0    // cache policy of the streaming tile-body loads (2 = nt)
@@ -572,7 +572,8 @@ __device__ __forceinline__ void enc_level_coarse_fast(u8 *buf, u8 *rbuf, const u
 {
     const int lane = threadIdx.x;
     if (s == 4) {
-        const CellAddr a0 = enc_body_cell(lane, 4, true), a1 = enc_body_cell(lane + NL, 4, true);
+        constexpr int ncells4 = (TW / 8) * (TH / 8);
+        const CellAddr a0 = enc_body_cell(lane, 4, lane < ncells4), a1 = enc_body_cell(lane + NL, 4, lane + NL < ncells4);
         const CellAddr ah = lane < TH / 8 + 1 + TW / 8 ? enc_halo_cell(lane, 4, tl, W, H) : idle_cell();
         const CellVal v0 = cell_load(buf, rbuf, a0), v1 = cell_load(buf, rbuf, a1), vh = cell_load(buf, rbuf, ah);
         cell_finish<INTERP, IDENT>(buf, rbuf, slut, a0, v0);

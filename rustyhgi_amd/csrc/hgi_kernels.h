@@ -10,9 +10,12 @@ constexpr int kInterpLeftTop = 0;
 constexpr int kInterpCrossed = 1;
 
 // Fused tile geometry (see DESIGN.md "Kernels").
+#ifndef HGI_TILE_H
+#define HGI_TILE_H 64         // tile rows (experiments: 32)
+#endif
 constexpr int kTileW = 128;   // pixels per tile row: 8 lanes x 16 B = one 128-B line
-constexpr int kTileH = 64;    // tile rows
-constexpr int kFusedMaxLevels = 6;  // 2^6 == kTileH: deepest pyramid one tile can hold
+constexpr int kTileH = HGI_TILE_H;
+constexpr int kFusedMaxLevels = HGI_TILE_H == 64 ? 6 : 5;  // 2^k <= kTileH: deepest pyramid one tile can hold
 constexpr int kThreads = 64;  // ONE wave owns a tile: no workgroup barriers anywhere
 
 // 256-entry quantizer table passed BY VALUE in the kernarg segment: no device-side table to

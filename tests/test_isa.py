@@ -1,0 +1,30 @@
+"""Static checks on the compiled gfx950 ISA of the fused kernels (hipcc cross-compiles without a GPU):
+no spills/scratch, and no partial-register (SDWA dst_sel) write immediately followed by a dependent
+VALU read -- the gfx940+ forwarding hazard the hand-written byte chains must never hit (tools/check_isa.py)."""
+import os
+import shutil
+import subprocess
+import sys
+
+import pytest
+
+from conftest import ROOT
+
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+
+
+@pytest.mark.timeout(600)
+def test_fused_kernels_isa_is_hazard_free(tmp_path):
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("hipcc not available")
+    out = str(tmp_path / "hgi_fused.s")
+    subprocess.check_call([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "--cuda-device-only", "-S",
+                           os.path.join(ROOT, "rustyhgi_amd", "csrc", "hgi_fused.hip"), "-o", out],
+                          stderr=subprocess.DEVNULL)
+    import check_isa
+    r = check_isa.check(out)
+    assert r["kernels"] == 12                      # {dec x 2 interp x 2 seeded} + {enc x 2 x 2 ident x 2 seeded}
+    assert r["partial_writes"] > 500               # the SDWA paths are really there
+    assert r["adjacent_dependent"] == 0, r["examples"]
+    assert r["scratch_bytes"] == 0 and r["vgpr_spills"] == 0
