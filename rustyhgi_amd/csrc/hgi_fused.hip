@@ -978,28 +978,46 @@ __device__ __forceinline__ TileCtx fast_ctx(u32 t, const u8 *src, u8 *dst, const
 }
 
 // ---- decode ---------------------------------------------------------------------------------------
-template <int INTERP, bool SEEDED>
-__device__ __forceinline__ void dec_seed(u8 *buf, const Seeds &sd, Tile tl, u32 k)
+// Seeds: lattice points = 0 (mod 2^k) of a deeper pyramid come from the already coded coarser pyramid
+// (compact planes, one byte per lattice point).  A tile touches (TW >> k) + 2 by (TH >> k) + 2 of them
+// (<= 64 for every k the seeded kernels run with), one per lane; the loads are issued together with the
+// tile's own loads so their latency is not a chain of its own.
+struct SeedRegs {
+    u32 rec, q;      // reconstruction / residual of this lane's lattice point (0 outside the image)
+    int bx, by;      // lattice coordinates inside the tile's halo frame
+    bool on;
+};
+
+template <bool WANT_Q>
+__device__ __forceinline__ SeedRegs seed_issue(const Seeds &sd, Tile tl, u32 k)
 {
-    if (!SEEDED) return;
-    // lattice points = 0 (mod 2^k) come from the already decoded coarser pyramid
     const int ext = k >= 2 ? 2 : 1;   // offset 2^k beyond the tile is only ever read for k >= 2
     const int nbx = (TW >> k) + ext, nby = (TH >> k) + ext;
-    const u8 *sp = sd.rec + (size_t)tl.frame * sd.stride;
-    for (int i = threadIdx.x; i < nbx * nby; i += NL) {
-        int by = i / nbx, bx = i - by * nbx;
-        u32 sx = (tl.X0 >> k) + bx, sy = (tl.Y0 >> k) + by;
-        u8 v = (sx < sd.sw && sy < sd.sh) ? sp[(size_t)sy * sd.sw + sx] : (u8)0;
-        buf[laddr(bx << k, by << k)] = v;
+    const int i = threadIdx.x;
+    SeedRegs r;
+    r.by = i / nbx;
+    r.bx = i - r.by * nbx;
+    r.on = i < nbx * nby;
+    r.rec = r.q = 0;
+    const u32 sx = (tl.X0 >> k) + r.bx, sy = (tl.Y0 >> k) + r.by;
+    if (r.on && sx < sd.sw && sy < sd.sh) {
+        const size_t at = (size_t)tl.frame * sd.stride + (size_t)sy * sd.sw + sx;
+        r.rec = sd.rec[at];
+        if (WANT_Q) r.q = sd.q[at];
     }
+    return r;
+}
+
+__device__ __forceinline__ void dec_seed_commit(u8 *buf, const SeedRegs &r, u32 k)
+{
+    if (r.on) buf[laddr(r.bx << k, r.by << k)] = (u8)r.rec;
     LDS_ORDER();
 }
 
 // One tile of the fast path, out of LDS: levels sub = 2^(k-1) .. 2 in place, then the finest level to HBM.
-template <int INTERP, bool SEEDED>
-__device__ __forceinline__ void dec_tile_fast(u8 *buf, const TileCtx &cur, const Seeds &sd, u32 k, u32 W, u32 H)
+template <int INTERP>
+__device__ __forceinline__ void dec_tile_fast(u8 *buf, const TileCtx &cur, u32 k, u32 W, u32 H)
 {
-    dec_seed<INTERP, SEEDED>(buf, sd, cur.tl, k);
     for (int s = 1 << (k - 1); s >= 2 && !(HGI_ABL & 1); s >>= 1) {
         if (s == 2) {
             if (!(HGI_ABL & 8)) dec_level2_fast<INTERP>(buf);
@@ -1047,16 +1065,21 @@ __global__ __launch_bounds__(NL) void k_dec_tiles(const u8 *__restrict__ src, u8
     if (!role.edge) {
         TileCtx cur = fast_ctx(role.index, src, dst, f, g);
         Stage st;
+        SeedRegs seeds;
         stage_issue<false>(st, cur.b, cur.tl, (int)k, nh);
+        if (SEEDED) seeds = seed_issue<false>(sd, cur.tl, k);
         stage_commit(buf, st, nh);
         LDS_ORDER();
-        dec_tile_fast<INTERP, SEEDED>(buf, cur, sd, k, W, H);
+        if (SEEDED) dec_seed_commit(buf, seeds, k);
+        dec_tile_fast<INTERP>(buf, cur, k, W, H);
         return;
     }
     // ragged tile (body crosses the image edge), unaligned rows, or offsets beyond 32 bits: every access checked
     const Tile tl = edge_tile(role.index, g);
     const u8 *fr = src + (size_t)tl.frame * f.frame_stride;
     u8 *out = dst + (size_t)tl.frame * f.frame_stride;
+    SeedRegs seeds;
+    if (SEEDED) seeds = seed_issue<false>(sd, tl, k);
     if (aligned & 2u) {   // aligned rows and 32-bit offsets: the buffer-load staging of the fast path
         Stage st;
         stage_issue<true>(st, make_buf(fr, out, W, H, tl), tl, (int)k, nh);
@@ -1065,7 +1088,7 @@ __global__ __launch_bounds__(NL) void k_dec_tiles(const u8 *__restrict__ src, u8
         stage_tile_generic(buf, fr, W, H, tl, nh, (aligned & 1u) != 0);
     }
     LDS_ORDER();
-    dec_seed<INTERP, SEEDED>(buf, sd, tl, k);
+    if (SEEDED) dec_seed_commit(buf, seeds, k);
     for (int s = 1 << (k - 1); s >= 2; s >>= 1) {
         dec_cells<INTERP, true>(buf, s, tl, W, H);
         dec_halo_cells<INTERP>(buf, s, tl, W, H);
@@ -1075,26 +1098,24 @@ __global__ __launch_bounds__(NL) void k_dec_tiles(const u8 *__restrict__ src, u8
 }
 
 // ---- encode ---------------------------------------------------------------------------------------
-// lattice points = 0 (mod 2^k): reconstruction == original (src/encoder.rs:26-37), or the coarser
-// pyramid's reconstruction + residuals when this launch is the lower part of a deeper pyramid.
+// lattice points = 0 (mod 2^k): reconstruction == original (src/encoder.rs:26-37), or -- when this
+// launch is the lower part of a deeper pyramid -- the coarser pyramid's reconstruction, with its
+// residuals taking the place of the originals in the output.
 template <bool SEEDED>
-__device__ __forceinline__ void enc_seed(u8 *buf, u8 *rbuf, const Seeds &sd, Tile tl, u32 k)
+__device__ __forceinline__ void enc_seed_commit(u8 *buf, u8 *rbuf, const SeedRegs &r, u32 k)
 {
-    const int ext = k >= 2 ? 2 : 1;
-    const int nbx = (TW >> k) + ext, nby = (TH >> k) + ext;
-    const u8 *sr = SEEDED ? sd.rec + (size_t)tl.frame * sd.stride : nullptr;
-    const u8 *sq = SEEDED ? sd.q + (size_t)tl.frame * sd.stride : nullptr;
-    for (int i = threadIdx.x; i < nbx * nby; i += NL) {
-        int by = i / nbx, bx = i - by * nbx;
-        int li = laddr(bx << k, by << k);
-        u8 rv = buf[li];
-        if (SEEDED) {
-            u32 sx = (tl.X0 >> k) + bx, sy = (tl.Y0 >> k) + by;
-            bool in = sx < sd.sw && sy < sd.sh;
-            rv = in ? sr[(size_t)sy * sd.sw + sx] : (u8)0;
-            buf[li] = in ? sq[(size_t)sy * sd.sw + sx] : (u8)0;
+    if (SEEDED) {
+        if (r.on) {
+            buf[laddr(r.bx << k, r.by << k)] = (u8)r.q;
+            rbuf[laddr2(r.bx << k, r.by << k)] = (u8)r.rec;
         }
-        rbuf[laddr2(bx << k, by << k)] = rv;
+    } else {
+        const int ext = k >= 2 ? 2 : 1;
+        const int nbx = (TW >> k) + ext, nby = (TH >> k) + ext;
+        for (int i = threadIdx.x; i < nbx * nby; i += NL) {
+            int by = i / nbx, bx = i - by * nbx;
+            rbuf[laddr2(bx << k, by << k)] = buf[laddr(bx << k, by << k)];
+        }
     }
     LDS_ORDER();
 }
@@ -1106,11 +1127,9 @@ __device__ __forceinline__ void clear_lattice(u8 *rbuf, int nh)
     for (int i = threadIdx.x; i < rbuf_bytes(nh) / 8; i += NL) base[i] = make_uint2(0, 0);
 }
 
-template <int INTERP, bool IDENT, bool SEEDED>
-__device__ __forceinline__ void enc_tile_fast(u8 *buf, u8 *rbuf, const u8 *slut, const TileCtx &cur, const Seeds &sd, u32 k,
-                                              u32 W, u32 H)
+template <int INTERP, bool IDENT>
+__device__ __forceinline__ void enc_tile_fast(u8 *buf, u8 *rbuf, const u8 *slut, const TileCtx &cur, u32 k, u32 W, u32 H)
 {
-    enc_seed<SEEDED>(buf, rbuf, sd, cur.tl, k);
     for (int s = 1 << (k - 1); s >= 2 && !(HGI_ABL & 1); s >>= 1) {
         if (s == 2)
             enc_level2_fast<INTERP, IDENT>(buf, rbuf, slut, cur.tl, W, H);
@@ -1137,16 +1156,21 @@ __global__ __launch_bounds__(NL) void k_enc_tiles(const u8 *__restrict__ src, u8
     if (!role.edge) {
         TileCtx cur = fast_ctx(role.index, src, dst, f, g);
         Stage st;
+        SeedRegs seeds;
         stage_issue<false>(st, cur.b, cur.tl, (int)k, nh);
+        if (SEEDED) seeds = seed_issue<true>(sd, cur.tl, k);
         clear_lattice(rbuf, nh);
         stage_commit(buf, st, nh);
         LDS_ORDER();
-        enc_tile_fast<INTERP, IDENT, SEEDED>(buf, rbuf, slut, cur, sd, k, W, H);
+        enc_seed_commit<SEEDED>(buf, rbuf, seeds, k);
+        enc_tile_fast<INTERP, IDENT>(buf, rbuf, slut, cur, k, W, H);
         return;
     }
     const Tile tl = edge_tile(role.index, g);
     const u8 *fr = src + (size_t)tl.frame * f.frame_stride;
     u8 *out = dst + (size_t)tl.frame * f.frame_stride;
+    SeedRegs seeds;
+    if (SEEDED) seeds = seed_issue<true>(sd, tl, k);
     clear_lattice(rbuf, nh);
     if (aligned & 2u) {
         Stage st;
@@ -1156,7 +1180,7 @@ __global__ __launch_bounds__(NL) void k_enc_tiles(const u8 *__restrict__ src, u8
         stage_tile_generic(buf, fr, W, H, tl, nh, (aligned & 1u) != 0);
     }
     LDS_ORDER();
-    enc_seed<SEEDED>(buf, rbuf, sd, tl, k);
+    enc_seed_commit<SEEDED>(buf, rbuf, seeds, k);
     for (int s = 1 << (k - 1); s >= 2; s >>= 1) {
         enc_cells<INTERP, IDENT, true>(buf, rbuf, slut, s, tl, W, H);
         enc_halo_cells<INTERP, IDENT>(buf, rbuf, slut, s, tl, W, H);
