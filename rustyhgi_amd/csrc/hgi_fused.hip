@@ -276,67 +276,6 @@ __device__ __forceinline__ void dec_halo_cells(u8 *buf, int s, Tile tl, u32 W, u
     }
 }
 
-// Encode: ONE pass per level for all halo cells (lanes 0..ncy: column cells on the transposed halo
-// columns, lanes 32..: row cells on the natural halo rows).  The pass is a latency chain (corners ->
-// prediction -> table -> write), so every LDS read is issued up front and unconditionally -- the
-// addresses of an active cell are always inside the tile's LDS planes, whether or not the pixel is
-// needed -- the three table look-ups fly together, and only the writes are conditional.
-struct HaloCell {
-    int lt, rt, lb, rb;      // corners
-    int nx, ny, nxy;         // new pixels (x0+s, y0), (x0, y0+s), (x0+s, y0+s)
-};
-
-template <int INTERP, bool IDENT>
-__device__ __forceinline__ void enc_halo_cells(u8 *buf, u8 *rbuf, const u8 *slut, int s, Tile tl, u32 W, u32 H)
-{
-    const int step = 2 * s, hsub = s >> 1, lstep = 31 - __clz(step);
-    const int ncx = TW >> lstep, ncy = TH >> lstep;
-    const bool deep = s >= 4;
-    const int hs = hmap(s), h2 = hmap(step);
-    const int lane = threadIdx.x;
-    const bool col = lane < 32;
-    // column cell (x0 == TW, y0 = lane * step; y0 == TH is the corner cell)
-    const int y0 = lane << lstep;
-    const bool corner = y0 == TH;
-    const int yb = corner ? TH + hs : y0 + s;
-    const int z0 = y0 >> 1, za = corner ? TH / 2 + h2 : (y0 + step) >> 1, zb = corner ? TH / 2 + hs : (y0 + s) >> 1;
-    // row cell (y0 == TH, x0 = (lane - 32) * step); its right-hand corners may be halo column 0
-    const int x0 = (lane - 32) << lstep, w0 = x0 >> 1;
-    const bool lastc = x0 + step == TW;
-    const bool active = col ? (lane <= ncy && tl.X0 + TW < W && tl.Y0 + y0 < H)
-                            : (lane - 32 < ncx && tl.Y0 + TH < H && tl.X0 + x0 < W);
-    if (!active) return;
-    const bool xin = col ? (deep && tl.X0 + TW + s < W) : (tl.X0 + x0 + s < W);
-    const bool yin = col ? ((deep || !corner) && tl.Y0 + y0 + s < H) : (deep && tl.Y0 + TH + s < H);
-    HaloCell f, r;   // full-resolution plane (originals -> residuals), half-resolution plane (reconstruction)
-    f.nx = col ? HCOL + hs * HP + y0 : TH * S + x0 + s;
-    f.ny = col ? HCOL + yb : (TH + hs) * S + x0;
-    f.nxy = col ? HCOL + hs * HP + yb : (TH + hs) * S + x0 + s;
-    r.lt = col ? RCOL + z0 : (TH / 2) * S2 + w0;
-    r.rt = col ? RCOL + za : (TH / 2 + h2) * S2 + w0;
-    r.lb = col ? RCOL + h2 * HP2 + z0 : (lastc ? RCOL + TH / 2 : (TH / 2) * S2 + w0 + s);
-    r.rb = col ? RCOL + h2 * HP2 + za : (lastc ? RCOL + TH / 2 + h2 : (TH / 2 + h2) * S2 + w0 + s);
-    r.nx = col ? RCOL + hs * HP2 + z0 : (TH / 2) * S2 + w0 + hsub;
-    r.ny = col ? RCOL + zb : (TH / 2 + hs) * S2 + w0;
-    r.nxy = col ? RCOL + hs * HP2 + zb : (TH / 2 + hs) * S2 + w0 + hsub;
-    const u32 lt = rbuf[r.lt], rt = rbuf[r.rt], lb = rbuf[r.lb], rb = rbuf[r.rb];
-    const u32 ax = buf[f.nx], ay = buf[f.ny], axy = buf[f.nxy];
-    const u32 p = pred1<INTERP>(lt, rt, lb, rb);
-    const u32 qx = quant1s<IDENT>(ax, p, slut), qy = quant1s<IDENT>(ay, p, slut), qxy = quant1s<IDENT>(axy, p, slut);
-    if (xin) {
-        buf[f.nx] = (u8)qx;
-        rbuf[r.nx] = (u8)(p + qx);
-    }
-    if (yin) {
-        buf[f.ny] = (u8)qy;
-        rbuf[r.ny] = (u8)(p + qy);
-    }
-    if (xin && yin) {
-        buf[f.nxy] = (u8)qxy;
-        rbuf[r.nxy] = (u8)(p + qxy);
-    }
-}
-
 // One level (sub >= 2) of the tile body in LDS, in place.  CHECK = test every pixel against the image.
 template <int INTERP, bool CHECK>
 __device__ __forceinline__ void dec_cells(u8 *buf, int s, Tile tl, u32 W, u32 H)
@@ -562,6 +501,17 @@ __device__ __forceinline__ void cell_finish(u8 *buf, u8 *rbuf, const u8 *slut, c
         buf[a.nxy] = (u8)qxy;
         rbuf[a.rxy] = (u8)(p + qxy);
     }
+}
+
+// All halo cells of level `s` in one pass (<= 49 lanes); the ragged-tile path uses it after its checked
+// body-cell loop, the interior path folds the same cells into its own chains below.
+template <int INTERP, bool IDENT>
+__device__ __forceinline__ void enc_halo_pass(u8 *buf, u8 *rbuf, const u8 *slut, int s, Tile tl, u32 W, u32 H)
+{
+    const int lstep = 31 - __clz(2 * s), nhalo = (TH >> lstep) + 1 + (TW >> lstep);
+    const CellAddr a = (int)threadIdx.x < nhalo ? enc_halo_cell(threadIdx.x, s, tl, W, H) : idle_cell();
+    const CellVal v = cell_load(buf, rbuf, a);
+    cell_finish<INTERP, IDENT>(buf, rbuf, slut, a, v);
 }
 
 // One coarse level (sub >= 4) of an interior tile, body cells and halo cells in one chain.
@@ -1183,7 +1133,7 @@ __global__ __launch_bounds__(NL) void k_enc_tiles(const u8 *__restrict__ src, u8
     enc_seed_commit<SEEDED>(buf, rbuf, seeds, k);
     for (int s = 1 << (k - 1); s >= 2; s >>= 1) {
         enc_cells<INTERP, IDENT, true>(buf, rbuf, slut, s, tl, W, H);
-        enc_halo_cells<INTERP, IDENT>(buf, rbuf, slut, s, tl, W, H);
+        enc_halo_pass<INTERP, IDENT>(buf, rbuf, slut, s, tl, W, H);
         LDS_ORDER();
     }
     enc_fine_generic<INTERP, IDENT>(buf, rbuf, slut, out, tl, W, H, (aligned & 1u) != 0);
