@@ -1,5 +1,10 @@
 // gfx950 (MI355X / CDNA4) fused HGI kernels: all levels of a tile in one launch, LDS-resident.
 //
+// This is the implementation, included by hgi_fused_dec.hip and hgi_fused_enc.hip: the two directions
+// are separate translation units because they want different LDS layouts (HGI_S_PAD / HGI_S2_PAD below):
+// decode is at the HBM floor and prefers padded rows (fewer bank conflicts), encode is bound by LDS
+// latency chains and prefers the extra wave per CU that unpadded rows buy.
+//
 // Reference algorithm (paths relative to pl0q1n/RustyHGI):
 //   src/encoder.rs:39-71, src/decoder.rs:18-46, src/interpolator.rs:15-28 / :41-90, src/utils.rs:12-41
 //
@@ -41,10 +46,16 @@ constexpr int HR = 6;   // halo rows / columns a tile can need (offsets 0,4,8,16
 //     that the lanes of a halo-cell pass (one lane per row) touch consecutive bytes instead of one
 //     bank, and so that every offset stays a compile-time constant whatever nh is.
 //   half-resolution plane (encode: reconstruction of the even/even lattice): same scheme.
-constexpr int S = TW + 16;
+#ifndef HGI_S_PAD
+#define HGI_S_PAD 16    // row pad of the full-resolution plane (bank skew vs. LDS per wave)
+#endif
+#ifndef HGI_S2_PAD
+#define HGI_S2_PAD 8
+#endif
+constexpr int S = TW + HGI_S_PAD;
 constexpr int HP = 72;             // >= TH + HR
 constexpr int HCOL = -(HR * HP);   // the transposed halo columns sit in front of row 0
-constexpr int S2 = TW / 2 + 8;
+constexpr int S2 = TW / 2 + HGI_S2_PAD;
 constexpr int HP2 = 40;            // >= TH / 2 + HR
 constexpr int RCOL = -(HR * HP2);
 
@@ -57,7 +68,12 @@ static_assert(S % 16 == 0 && (HR * HP) % 16 == 0 && S2 % 8 == 0 && (HR * HP2) % 
                   HP2 >= TH / 2 + HR && buf_bytes(1) % 16 == 0 && rbuf_bytes(1) % 8 == 0,
               "LDS pitches keep vector alignment");
 // k = 4 (the flagship configuration): 16 decode waves and 12 encode waves per CU fit the 160 KiB of LDS
-static_assert(TH != 64 || (16 * buf_bytes(4) <= 160 * 1024 && 12 * (buf_bytes(4) + rbuf_bytes(4) + 256) <= 160 * 1024), "LDS budget");
+#ifdef HGI_FUSED_DECODE
+static_assert(TH != 64 || 16 * buf_bytes(4) <= 160 * 1024, "LDS budget: 16 decode waves per CU at k = 4");
+#endif
+#ifdef HGI_FUSED_ENCODE
+static_assert(TH != 64 || 13 * (buf_bytes(4) + rbuf_bytes(4) + 256) <= 160 * 1024, "LDS budget: 13 encode waves per CU at k = 4");
+#endif
 
 #ifndef HGI_LOAD_AUX
 #define HGI_LOAD_AUX 0    // cache policy of the streaming tile-body loads (2 = nt)
@@ -1170,6 +1186,7 @@ FusedGeom fused_geom(const void *a, const void *b, const Frames &f)
 
 }  // namespace
 
+#ifdef HGI_FUSED_DECODE
 hipError_t launch_decode_fused(const uint8_t *grid, uint8_t *img, const Frames &f, uint32_t k, int interp,
                                const Seeds *seeds, hipStream_t s)
 {
@@ -1191,6 +1208,9 @@ hipError_t launch_decode_fused(const uint8_t *grid, uint8_t *img, const Frames &
     return hipGetLastError();
 }
 
+#endif  // HGI_FUSED_DECODE
+
+#ifdef HGI_FUSED_ENCODE
 hipError_t launch_encode_fused(const uint8_t *img, uint8_t *grid, const Frames &f, uint32_t k, int interp,
                                const Lut256 &lut, bool ident, const Seeds *seeds, hipStream_t s)
 {
@@ -1214,5 +1234,7 @@ hipError_t launch_encode_fused(const uint8_t *img, uint8_t *grid, const Frames &
 #undef HGI_ENC
     return hipGetLastError();
 }
+
+#endif  // HGI_FUSED_ENCODE
 
 }  // namespace hgi

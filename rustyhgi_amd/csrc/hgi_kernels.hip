@@ -1,5 +1,5 @@
 // gfx950 (MI355X / CDNA4) kernels of the HGI encode/decode core: level-wise path + harness kernels.
-// (The fused LDS-tile path lives in hgi_fused.hip; shared device helpers in hgi_dev.h.)
+// (The fused LDS-tile path lives in hgi_fused_impl.h / hgi_fused_{dec,enc}.hip; shared device helpers in hgi_dev.h.)
 //
 // Algorithm (reference, paths relative to pl0q1n/RustyHGI):
 //   src/encoder.rs:39-71   closed-loop encode: predict -> residual -> quantize -> overflow fallback

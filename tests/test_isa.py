@@ -18,13 +18,14 @@ def test_fused_kernels_isa_is_hazard_free(tmp_path):
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     if not os.path.exists(hipcc):
         pytest.skip("hipcc not available")
-    out = str(tmp_path / "hgi_fused.s")
-    subprocess.check_call([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "--cuda-device-only", "-S",
-                           os.path.join(ROOT, "rustyhgi_amd", "csrc", "hgi_fused.hip"), "-o", out],
-                          stderr=subprocess.DEVNULL)
     import check_isa
-    r = check_isa.check(out)
-    assert r["kernels"] == 12                      # {dec x 2 interp x 2 seeded} + {enc x 2 x 2 ident x 2 seeded}
-    assert r["partial_writes"] > 500               # the SDWA paths are really there
-    assert r["adjacent_dependent"] == 0, r["examples"]
-    assert r["scratch_bytes"] == 0 and r["vgpr_spills"] == 0
+    # {dec x 2 interp x 2 seeded} and {enc x 2 interp x 2 ident x 2 seeded}: one translation unit per direction
+    for tu, kernels, sdwa in (("hgi_fused_dec.hip", 4, 100), ("hgi_fused_enc.hip", 8, 400)):
+        out = str(tmp_path / (tu + ".s"))
+        subprocess.check_call([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "--cuda-device-only", "-S",
+                               os.path.join(ROOT, "rustyhgi_amd", "csrc", tu), "-o", out], stderr=subprocess.DEVNULL)
+        r = check_isa.check(out)
+        assert r["kernels"] == kernels, (tu, r)
+        assert r["partial_writes"] > sdwa, (tu, r)         # the SDWA paths are really there
+        assert r["adjacent_dependent"] == 0, (tu, r["examples"])
+        assert r["scratch_bytes"] == 0 and r["vgpr_spills"] == 0, (tu, r)

@@ -3,7 +3,7 @@
 
 1. gfx940+ forwarding hazard: a VALU op that writes only part of a VGPR (SDWA dst_sel BYTE_n / WORD_n)
    must not be followed immediately by a VALU op that reads that VGPR (one wait state required).  The
-   hand-written SDWA byte chains of hgi_fused.hip rely on the compiler padding between asm statements;
+   hand-written SDWA byte chains of hgi_fused_impl.h rely on the compiler padding between asm statements;
    this verifies the padding is there in the build that ships.
 2. No scratch (spills) in any kernel.
 Usage: check_isa.py <file.s>   (hipcc --offload-arch=gfx950 -O3 --cuda-device-only -S ... -o file.s)
