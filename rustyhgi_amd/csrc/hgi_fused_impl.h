@@ -169,8 +169,16 @@ __device__ __forceinline__ int laddr2(int x, int y)
 {
     return x < TW ? lrow2(y) * S2 + (x >> 1) : RCOL + hmap(x - TW) * HP2 + lrow2(y);
 }
-// value of lane + 1 (within rows of 16 lanes): the first dword of the next 16-B chunk of the same row
-__device__ __forceinline__ u32 from_next_lane(u32 v) { return (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x101, 0xF, 0xF, true); }
+// Value of lane + 1: the first dword of the next 16-B chunk of the same row.  Through the LDS crossbar
+// (ds_bpermute_b32; no memory access, no bank conflicts), NOT through DPP: the hand-written SDWA
+// statements are opaque to the compiler's hazard recognizer, and DPP is the one instruction class
+// with multi-cycle VALU -> read hazards.  A fully unrolled build with v_mov_b32_dpp here produced
+// sporadic wrong dwords in lanes 12..15 of each row of 16; tools/check_isa.py now
+// rejects any DPP in these kernels.
+__device__ __forceinline__ u32 from_next_lane(u32 v)
+{
+    return (u32)__builtin_amdgcn_ds_bpermute((int)((threadIdx.x + 1) << 2), (int)v);
+}
 
 struct Tile {
     u32 frame, X0, Y0;

@@ -29,3 +29,4 @@ def test_fused_kernels_isa_is_hazard_free(tmp_path):
         assert r["partial_writes"] > sdwa, (tu, r)         # the SDWA paths are really there
         assert r["adjacent_dependent"] == 0, (tu, r["examples"])
         assert r["scratch_bytes"] == 0 and r["vgpr_spills"] == 0, (tu, r)
+        assert r["dpp"] == 0, (tu, "DPP next to opaque SDWA asm is not allowed", r)

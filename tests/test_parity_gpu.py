@@ -246,6 +246,38 @@ def test_full_size_properties(H, ctxs, oracle, golden):
     ctx.use_own_stream()
 
 
+def test_saturated_device_repeat(H, ctxs, oracle):
+    """Every CU busy with many resident waves, noise input (every quantizer branch taken), repeated:
+    the configuration that exposed a DPP-next-to-inline-asm hazard in an experimental build
+    (DESIGN.md 4.5).  18 frames of 4096^2 per launch, 4 launches per direction, bit-exact each time."""
+    import torch
+    from rustyhgi_amd import _ffi
+    L, ctx = _ffi.lib(), ctxs["fused"]
+    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    W = Hh = 4096
+    levels, nf = 4, 18
+    img = oracle.synth(oracle.SYNTH_NOISE, SEED0, 0, W, Hh)
+    lut = oracle.linear_lut(2)[0]
+    grid = oracle.encode(img, levels, lut)
+    want = oracle.decode(grid, levels)
+    d_img = torch.from_numpy(img).cuda().expand(nf, Hh, W).contiguous()
+    d_grid = torch.from_numpy(grid).cuda().expand(nf, Hh, W).contiguous()
+    d_want = torch.from_numpy(want).cuda()
+    g_want = torch.from_numpy(grid).cuda()
+    out = torch.empty_like(d_img)
+    for rep in range(4):
+        out.fill_(0x5A)
+        _ffi.check(L.hgi_decode_u8_dev(ctx.handle, d_grid.data_ptr(), W, Hh, levels, 1, out.data_ptr(), nf, W * Hh))
+        torch.cuda.synchronize()
+        assert int((out != d_want).sum().item()) == 0, "decode rep %d" % rep
+        out.fill_(0xA5)
+        _ffi.check(L.hgi_encode_u8_dev(ctx.handle, d_img.data_ptr(), W, Hh, levels, 1, lut.ctypes.data,
+                                       out.data_ptr(), nf, W * Hh))
+        torch.cuda.synchronize()
+        assert int((out != g_want).sum().item()) == 0, "encode rep %d" % rep
+    ctx.use_own_stream()
+
+
 def test_error_paths_on_device(ctxs):
     from rustyhgi_amd import _ffi
     L, ctx = _ffi.lib(), ctxs["fused"]
