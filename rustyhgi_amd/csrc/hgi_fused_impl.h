@@ -170,11 +170,9 @@ __device__ __forceinline__ int laddr2(int x, int y)
     return x < TW ? lrow2(y) * S2 + (x >> 1) : RCOL + hmap(x - TW) * HP2 + lrow2(y);
 }
 // Value of lane + 1: the first dword of the next 16-B chunk of the same row.  Through the LDS crossbar
-// (ds_bpermute_b32; no memory access, no bank conflicts), NOT through DPP: the hand-written SDWA
-// statements are opaque to the compiler's hazard recognizer, and DPP is the one instruction class
-// with multi-cycle VALU -> read hazards.  A fully unrolled build with v_mov_b32_dpp here produced
-// sporadic wrong dwords in lanes 12..15 of each row of 16; tools/check_isa.py now
-// rejects any DPP in these kernels.
+// (ds_bpermute_b32; no memory access, no bank conflicts) rather than DPP: a VALU write -> DPP read needs
+// two wait states, and the compiler cannot count them through the inline-asm SDWA statements.  Same
+// speed; tools/check_isa.py rejects any DPP in these kernels.
 __device__ __forceinline__ u32 from_next_lane(u32 v)
 {
     return (u32)__builtin_amdgcn_ds_bpermute((int)((threadIdx.x + 1) << 2), (int)v);
@@ -195,6 +193,19 @@ __device__ __forceinline__ u32 range_first(u32 ntiles, u32 x) { return x * (ntil
 // kept from moving accesses across (it cannot see that lanes exchange data).  No s_barrier, no
 // vmcnt drain: the workgroup is one wave.
 #define LDS_ORDER() asm volatile("" ::: "memory")
+
+// The two 16-B row stores of a lane's fine-level task, then two wait states during which the eight
+// data registers stay allocated.  A VALU write to a data VGPR of a > 64-bit store in the issue slot
+// right after it can reach memory instead of the stored value.  LLVM pads for that only when soffset
+// is not an SGPR; on gfx950 it was observed with soffset in an SGPR as well (first data dword, last
+// quad of every 16 lanes, only with the store path backed up -- DESIGN.md 4.5), so the spacing is
+// made explicit here and checked in the ISA (tools/check_isa.py rule 4).
+__device__ __forceinline__ void store_row_pair(v4u r0, v4u r1, __amdgpu_buffer_rsrc_t rd, u32 voff, u32 pitch)
+{
+    __builtin_amdgcn_raw_buffer_store_b128(r0, rd, voff, 0, HGI_STORE_AUX);
+    __builtin_amdgcn_raw_buffer_store_b128(r1, rd, voff, pitch, HGI_STORE_AUX);
+    asm volatile("s_nop 1" ::"v"(r0), "v"(r1));
+}
 
 // =============================================================================================
 // GENERIC PATH (ragged tiles, unaligned widths): every access checked against the image
@@ -710,8 +721,7 @@ __device__ __forceinline__ void dec_fine_fast(const u8 *buf, const Buf &b)
         HGI_ADDB(o2, 0, P1, 0); HGI_ADDB(o2, 1, P1, 0); HGI_ADDB(o2, 2, P1, 1); HGI_ADDB(o2, 3, P1, 1);
         HGI_ADDB(o3, 0, P1, 2); HGI_ADDB(o3, 1, P1, 2); HGI_ADDB(o3, 2, P1, 3); HGI_ADDB(o3, 3, P1, 3);
         v4u r0v = {e0, e1, e2, e3}, r1v = {o0, o1, o2, o3};
-        __builtin_amdgcn_raw_buffer_store_b128(r0v, b.rd, voff, 0, HGI_STORE_AUX);
-        __builtin_amdgcn_raw_buffer_store_b128(r1v, b.rd, voff, __builtin_amdgcn_readfirstlane(b.W), HGI_STORE_AUX);
+        store_row_pair(r0v, r1v, b.rd, voff, __builtin_amdgcn_readfirstlane(b.W));
     }
 }
 
@@ -863,8 +873,7 @@ __device__ __forceinline__ void enc_fine_fast(const u8 *buf, const u8 *rbuf, con
             }
             v4u o0 = {e0, e1, e2, e3}, o1 = {g0, g1, g2, g3};
             const u32 vo = voff + j * 2 * (NL / CH) * Ws;
-            __builtin_amdgcn_raw_buffer_store_b128(o0, b.rd, vo, 0, HGI_STORE_AUX);
-            __builtin_amdgcn_raw_buffer_store_b128(o1, b.rd, vo, Ws, HGI_STORE_AUX);
+            store_row_pair(o0, o1, b.rd, vo, Ws);
         }
         r0 += PAIR * 2 * (NL / CH) * S;
         c0 += PAIR * (NL / CH) * S2;

@@ -1,6 +1,8 @@
-"""Static checks on the compiled gfx950 ISA of the fused kernels (hipcc cross-compiles without a GPU):
-no spills/scratch, and no partial-register (SDWA dst_sel) write immediately followed by a dependent
-VALU read -- the gfx940+ forwarding hazard the hand-written byte chains must never hit (tools/check_isa.py)."""
+"""Static checks on the compiled gfx950 ISA of the kernels (hipcc cross-compiles without a GPU): no
+spills/scratch, no partial-register (SDWA dst_sel) write immediately followed by a dependent VALU read,
+no DPP, and no redefinition of a wide store's data VGPRs within two wait states (tools/check_isa.py).
+The hand-written SDWA statements are opaque to the compiler's hazard recognizer, so these are checked
+on the ISA that ships -- and on a second schedule of the same source (the 32-row tile build)."""
 import os
 import shutil
 import subprocess
@@ -29,4 +31,14 @@ def test_fused_kernels_isa_is_hazard_free(tmp_path):
         assert r["partial_writes"] > sdwa, (tu, r)         # the SDWA paths are really there
         assert r["adjacent_dependent"] == 0, (tu, r["examples"])
         assert r["scratch_bytes"] == 0 and r["vgpr_spills"] == 0, (tu, r)
+        assert r["store_data_overwritten"] == 0, (tu, "data VGPR of a wide store redefined too early", r)
         assert r["dpp"] == 0, (tu, "DPP next to opaque SDWA asm is not allowed", r)
+    # same rules on other schedules of the same source, and on the level-wise / harness kernels
+    for tu, extra in (("hgi_fused_dec.hip", ["-DHGI_TILE_H=32"]), ("hgi_fused_enc.hip", ["-DHGI_TILE_H=32"]),
+                      ("hgi_kernels.hip", [])):
+        out = str(tmp_path / (tu + ".alt.s"))
+        subprocess.check_call([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "--cuda-device-only", "-S"] + extra +
+                              [os.path.join(ROOT, "rustyhgi_amd", "csrc", tu), "-o", out], stderr=subprocess.DEVNULL)
+        r = check_isa.check(out)
+        assert r["adjacent_dependent"] == 0 and r["store_data_overwritten"] == 0 and r["dpp"] == 0, (tu, extra, r)
+        assert r["scratch_bytes"] == 0 and r["vgpr_spills"] == 0, (tu, extra, r)

@@ -248,7 +248,7 @@ def test_full_size_properties(H, ctxs, oracle, golden):
 
 def test_saturated_device_repeat(H, ctxs, oracle):
     """Every CU busy with many resident waves, noise input (every quantizer branch taken), repeated:
-    the configuration that exposed a DPP-next-to-inline-asm hazard in an experimental build
+    the configuration that exposed the wide-store data hazard in an experimental build
     (DESIGN.md 4.5).  18 frames of 4096^2 per launch, 4 launches per direction, bit-exact each time."""
     import torch
     from rustyhgi_amd import _ffi

@@ -8,10 +8,53 @@
 2. No scratch (spills) in any kernel.
 3. No DPP instruction: the kernels' SDWA statements are inline asm, invisible to the compiler's hazard
    recognizer, and DPP has multi-cycle VALU -> read hazards (a DPP build was observed to corrupt data).
+4. Wide-store data hazard: after a store of more than 64 bits (buffer/global/flat dwordx3/x4) none of its
+   data VGPRs may be redefined within the next two wait states.  LLVM pads for this itself except when a
+   buffer store's soffset is an SGPR, which it takes to be safe; on gfx950 a VALU write in the very next
+   slot was observed to reach memory in place of the stored dword.
 Usage: check_isa.py <file.s>   (hipcc --offload-arch=gfx950 -O3 --cuda-device-only -S ... -o file.s)
 """
 import re
 import sys
+
+
+STORE_WAIT_STATES = 2
+
+
+def written_vgprs(ins):
+    ops = ins.split(None, 1)
+    if len(ops) < 2 or re.match(r"(buffer|global|flat|scratch)_store|ds_write|s_|buffer_wbl2|buffer_inv", ins):
+        return set()
+    dst = ops[1].split(",")[0].strip()
+    m = re.match(r"v\[(\d+):(\d+)\]", dst)
+    if m:
+        return set(range(int(m.group(1)), int(m.group(2)) + 1))
+    m = re.match(r"v(\d+)$", dst)
+    return {int(m.group(1))} if m else set()
+
+
+def store_hazards(real):
+    found = []
+    for i, ins in enumerate(real):
+        if not re.match(r"(buffer|global|flat)_store_dwordx[34]\b", ins):
+            continue
+        ops = ins.split(None, 1)[1]
+        if ins.startswith("buffer"):
+            m = re.match(r"v\[(\d+):(\d+)\]", ops)            # buffer: vdata first
+        else:
+            m = re.search(r",\s*v\[(\d+):(\d+)\]", ops)       # global/flat: vaddr, vdata
+        if not m:
+            continue
+        data = set(range(int(m.group(1)), int(m.group(2)) + 1))
+        ws, j = 0, i + 1
+        while j < len(real) and ws < STORE_WAIT_STATES:
+            if written_vgprs(real[j]) & data:
+                found.append((ins, real[j]))
+                break
+            n = re.match(r"s_nop (\d+)", real[j])
+            ws += int(n.group(1)) + 1 if n else 1
+            j += 1
+    return found
 
 
 def check(path):
@@ -29,11 +72,14 @@ def check(path):
         if nxt.startswith("v_") and len(ops) > 1 and re.search(r"\b" + m.group(2) + r"\b", ops[1]):
             adjacent += 1
             examples.append((cur, nxt))
+    stores = store_hazards(real)
+    examples += stores
     dpp = sum(1 for l in real if re.search(r"_dpp\b|row_sh[lr]:|quad_perm:|row_bcast|wave_sh", l))
     scratch = [int(v) for v in re.findall(r"\.private_segment_fixed_size:\s+(\d+)", text)]
     spills = [int(v) for v in re.findall(r"\.vgpr_spill_count:\s+(\d+)", text)]
-    return dict(partial_writes=partial, adjacent_dependent=adjacent, examples=examples[:5],
-                kernels=len(scratch), scratch_bytes=max(scratch or [0]), vgpr_spills=max(spills or [0]), dpp=dpp)
+    return dict(partial_writes=partial, adjacent_dependent=adjacent, examples=examples[:8],
+                kernels=len(scratch), scratch_bytes=max(scratch or [0]), vgpr_spills=max(spills or [0]), dpp=dpp,
+                store_data_overwritten=len(stores))
 
 
 if __name__ == "__main__":
@@ -41,4 +87,5 @@ if __name__ == "__main__":
     print({k: v for k, v in r.items() if k != "examples"})
     for cur, nxt in r["examples"]:
         print("  ", cur, "\n     ->", nxt)
-    sys.exit(1 if r["adjacent_dependent"] or r["scratch_bytes"] or r["vgpr_spills"] or r["dpp"] else 0)
+    sys.exit(1 if r["adjacent_dependent"] or r["scratch_bytes"] or r["vgpr_spills"] or r["dpp"] or r["store_data_overwritten"]
+             else 0)
