@@ -1,7 +1,12 @@
 // Decode direction of the fused kernels (k_dec_tiles + launch_decode_fused).
-// Layout: rows padded by 16 B -- decode sits on the HBM floor (0.385-0.40 ms per 64 x 4096^2 frames) and
-// loses 5 % to LDS bank conflicts without the pad.  k = 4: 10 224 B of LDS per wave, 16 waves per CU.
+// Layout: only the even rows of a tile live in LDS (odd rows stay in the registers they were loaded into),
+// rows unpadded: k = 4 needs 4 848 B of LDS per wave; ~50 VGPRs, so 8 waves per SIMD.  Measured on the
+// 64 x 4096^2 shard: row pad 0 / 16 / 32 B -> 0.396 / 0.403 / 0.402 ms.
 #define HGI_FUSED_DECODE 1
-#define HGI_S_PAD 16
+#ifndef HGI_S_PAD
+#define HGI_S_PAD 0
+#endif
+#ifndef HGI_S2_PAD
 #define HGI_S2_PAD 8
+#endif
 #include "hgi_fused_impl.h"

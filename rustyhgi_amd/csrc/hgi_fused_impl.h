@@ -40,12 +40,16 @@ constexpr int CH = TW / 16;        // 16-B chunks per tile row
 constexpr int LCH = 3;             // log2(CH)
 constexpr int HR = 6;   // halo rows / columns a tile can need (offsets 0,4,8,16,32,64); >= kFusedMaxLevels
 // LDS layout (bank-conflict model and measurements: DESIGN.md "LDS layout").  LDS is dynamic: a tile
-// that needs nh halo rows allocates TH + nh rows, which is what sets the waves per CU.
-//   full-resolution plane: [halo columns, transposed][rows 0 .. TH + nh - 1, pitch S]
-//     `buf` points at row 0; the halo COLUMNS live in front of it at buf[HCOL + idx * HP + row], so
+// that needs nh halo rows allocates TH / 2 + nh rows, which is what sets the waves per CU.
+//   ODD image rows never enter LDS: every level but the finest touches even coordinates only, and the
+//   finest level reads an odd row exactly once -- in the lane that loaded it, so it stays in that
+//   lane's registers from the staging load to the store (the staging lane map IS the fine-level map).
+//   even-row plane `buf`: [halo columns, transposed][LDS row r = image row 2r, r < TH / 2; then the
+//     halo rows TH + {0,4,8,..} at r = TH / 2 + hmap], pitch S, full x resolution.
+//     `buf` points at row 0; the halo COLUMNS live in front of it at buf[HCOL + idx * HP + r], so
 //     that the lanes of a halo-cell pass (one lane per row) touch consecutive bytes instead of one
 //     bank, and so that every offset stays a compile-time constant whatever nh is.
-//   half-resolution plane (encode: reconstruction of the even/even lattice): same scheme.
+//   half-resolution plane `rbuf` (encode: reconstruction of the even/even lattice): same rows, x / 2.
 #ifndef HGI_S_PAD
 #define HGI_S_PAD 16    // row pad of the full-resolution plane (bank skew vs. LDS per wave)
 #endif
@@ -53,26 +57,26 @@ constexpr int HR = 6;   // halo rows / columns a tile can need (offsets 0,4,8,16
 #define HGI_S2_PAD 8
 #endif
 constexpr int S = TW + HGI_S_PAD;
-constexpr int HP = 72;             // >= TH + HR
+constexpr int HP = 40;             // >= TH / 2 + HR
 constexpr int HCOL = -(HR * HP);   // the transposed halo columns sit in front of row 0
 constexpr int S2 = TW / 2 + HGI_S2_PAD;
 constexpr int HP2 = 40;            // >= TH / 2 + HR
 constexpr int RCOL = -(HR * HP2);
 
-__host__ __device__ constexpr int buf_bytes(int nh) { return HR * HP + (TH + nh) * S; }
+__host__ __device__ constexpr int buf_bytes(int nh) { return HR * HP + (TH / 2 + nh) * S; }
 __host__ __device__ constexpr int rbuf_bytes(int nh) { return HR * HP2 + (TH / 2 + nh) * S2; }
 
 static_assert(NL == 64 && CH == (1 << LCH) && (TH & (TH - 1)) == 0 && (1 << kFusedMaxLevels) <= TH, "tile geometry");
 // 16-B accesses on the full-resolution rows, 8-B accesses on the half-resolution rows
-static_assert(S % 16 == 0 && (HR * HP) % 16 == 0 && S2 % 8 == 0 && (HR * HP2) % 16 == 0 && HP >= TH + HR &&
+static_assert(S % 16 == 0 && (HR * HP) % 16 == 0 && S2 % 8 == 0 && (HR * HP2) % 16 == 0 && HP >= TH / 2 + HR &&
                   HP2 >= TH / 2 + HR && buf_bytes(1) % 16 == 0 && rbuf_bytes(1) % 8 == 0,
               "LDS pitches keep vector alignment");
-// k = 4 (the flagship configuration): 16 decode waves and 12 encode waves per CU fit the 160 KiB of LDS
+// k = 4 (the flagship configuration): LDS leaves room for 24 decode / 18 encode waves per CU
 #ifdef HGI_FUSED_DECODE
-static_assert(TH != 64 || 16 * buf_bytes(4) <= 160 * 1024, "LDS budget: 16 decode waves per CU at k = 4");
+static_assert(TH != 64 || 24 * buf_bytes(4) <= 160 * 1024, "LDS budget: 24 decode waves per CU at k = 4");
 #endif
 #ifdef HGI_FUSED_ENCODE
-static_assert(TH != 64 || 13 * (buf_bytes(4) + rbuf_bytes(4) + 256) <= 160 * 1024, "LDS budget: 13 encode waves per CU at k = 4");
+static_assert(TH != 64 || 18 * (buf_bytes(4) + rbuf_bytes(4) + 256) <= 160 * 1024, "LDS budget: 18 encode waves per CU at k = 4");
 #endif
 
 #ifndef HGI_LOAD_AUX
@@ -161,9 +165,10 @@ __device__ __forceinline__ u32 quant1s(u32 a, u32 p, const u8 *slut)
 // rows/columns are stored compactly at index hmap(offset).
 __device__ __forceinline__ int hmap(int off) { return off ? 30 - __clz(off) : 0; }   // 4->1, 8->2 ...
 __device__ __forceinline__ int hoff(int idx) { return idx ? 2 << idx : 0; }           // 1->4, 2->8 ...
-__device__ __forceinline__ int lrow(int y) { return y < TH ? y : TH + hmap(y - TH); }
-__device__ __forceinline__ int lrow2(int y) { return y < TH ? y >> 1 : TH / 2 + hmap(y - TH); }
-// byte offset of pixel (x, y) of the tile (halo included) in the full- / half-resolution plane
+// LDS row of the EVEN image row y of the tile (halo included); both planes index rows alike
+__device__ __forceinline__ int lrow(int y) { return y < TH ? y >> 1 : TH / 2 + hmap(y - TH); }
+__device__ __forceinline__ int lrow2(int y) { return lrow(y); }
+// byte offset of pixel (x, y), y even, of the tile (halo included) in the even-row / half-resolution plane
 __device__ __forceinline__ int laddr(int x, int y) { return x < TW ? lrow(y) * S + x : HCOL + hmap(x - TW) * HP + lrow(y); }
 __device__ __forceinline__ int laddr2(int x, int y)
 {
@@ -247,20 +252,20 @@ __device__ __noinline__ void stage_tile_generic(u8 *buf, const u8 *__restrict__ 
                                                 bool aligned)
 {
     const int lane = threadIdx.x;
-    for (int i = lane; i < (TH + nh) * CH; i += NL) {
+    for (int i = lane; i < (TH / 2 + nh) * CH; i += NL) {      // even rows and halo rows only
         int rr = i >> LCH, c = i & (CH - 1);
-        int y = rr < TH ? rr : TH + hoff(rr - TH);
+        int y = rr < TH / 2 ? 2 * rr : TH + hoff(rr - TH / 2);
         uint4 v = load16(fr, W, H, tl.X0 + 16 * c, tl.Y0 + y, aligned);
         *reinterpret_cast<uint4 *>(buf + rr * S + 16 * c) = v;
     }
     // halo columns TW + {0,4,8,..} (and the halo x halo corner block): byte gathers.  Column offset
     // `off` is only ever touched on rows = 0 (mod max(off, 2)).
-    for (int i = lane; i < 8 * (TH + nh); i += NL) {
+    for (int i = lane; i < 8 * (TH / 2 + nh); i += NL) {
         int hc = i & 7, rr = i >> 3;
         if (hc >= nh) continue;
         int off = hoff(hc);
-        int y = rr < TH ? rr : TH + hoff(rr - TH);
-        if (rr < TH && (y & ((off ? off : 2) - 1))) continue;
+        int y = rr < TH / 2 ? 2 * rr : TH + hoff(rr - TH / 2);
+        if (rr < TH / 2 && (y & ((off ? off : 2) - 1))) continue;
         u32 gx = tl.X0 + TW + off, gy = tl.Y0 + y;
         buf[HCOL + hc * HP + rr] = (gx < W && gy < H) ? fr[(size_t)gy * W + gx] : (u8)0;
     }
@@ -286,21 +291,22 @@ __device__ __forceinline__ void dec_halo_cells(u8 *buf, int s, Tile tl, u32 W, u
         const int y0 = lane << lstep;
         if (tl.Y0 + y0 < H) {
             const bool corner = y0 == TH;
-            const int ya = corner ? TH + h2 : y0 + step, yb = corner ? TH + hs : y0 + s;
-            u32 p = pred1<INTERP>(hc[y0], hc[ya], hc[h2 * HP + y0], hc[h2 * HP + ya]);
+            // LDS rows of image rows y0, y0 + step, y0 + s
+            const int z0 = y0 >> 1, za = corner ? TH / 2 + h2 : (y0 + step) >> 1, zb = corner ? TH / 2 + hs : (y0 + s) >> 1;
+            u32 p = pred1<INTERP>(hc[z0], hc[za], hc[h2 * HP + z0], hc[h2 * HP + za]);
             const bool xin = deep && tl.X0 + TW + s < W;
             const bool yin = (deep || !corner) && tl.Y0 + y0 + s < H;
-            if (xin) hc[hs * HP + y0] = (u8)(hc[hs * HP + y0] + p);
-            if (yin) hc[yb] = (u8)(hc[yb] + p);
-            if (xin && yin) hc[hs * HP + yb] = (u8)(hc[hs * HP + yb] + p);
+            if (xin) hc[hs * HP + z0] = (u8)(hc[hs * HP + z0] + p);
+            if (yin) hc[zb] = (u8)(hc[zb] + p);
+            if (xin && yin) hc[hs * HP + zb] = (u8)(hc[hs * HP + zb] + p);
         }
     }
     if (tl.Y0 + TH < H && lane < ncx) {            // row cells
         const int x0 = lane << lstep;
         if (tl.X0 + x0 < W) {
-            u8 *r0 = buf + TH * S + x0, *r1 = buf + (TH + h2) * S + x0, *rs = buf + (TH + hs) * S + x0;
+            u8 *r0 = buf + (TH / 2) * S + x0, *r1 = buf + (TH / 2 + h2) * S + x0, *rs = buf + (TH / 2 + hs) * S + x0;
             const bool lastc = x0 + step == TW;    // right-hand corners are halo column 0
-            u32 lb = lastc ? hc[TH] : r0[step], rb = lastc ? hc[TH + h2] : r1[step];
+            u32 lb = lastc ? hc[TH / 2] : r0[step], rb = lastc ? hc[TH / 2 + h2] : r1[step];
             u32 p = pred1<INTERP>(r0[0], r1[0], lb, rb);
             const bool xin = tl.X0 + x0 + s < W;
             const bool yin = deep && tl.Y0 + TH + s < H;
@@ -317,19 +323,20 @@ __device__ __forceinline__ void dec_cells(u8 *buf, int s, Tile tl, u32 W, u32 H)
 {
     const int step = 2 * s, lstep = 31 - __clz(step);
     const int ncx = TW >> lstep, ncy = TH >> lstep, lncx = 31 - __clz(ncx);
-    // natural LDS coordinates: x0 + step <= TW and y0 + step <= TH map to themselves
+    // natural LDS coordinates: x0 + step <= TW maps to itself, image row y <= TH to LDS row y / 2
+    const int hs = s >> 1;
     for (int i = threadIdx.x; i < ncx * ncy; i += NL) {
         int x0 = (i & (ncx - 1)) << lstep, y0 = (i >> lncx) << lstep;
         if (CHECK && (tl.X0 + x0 >= W || tl.Y0 + y0 >= H)) continue;
-        u8 *c = buf + y0 * S + x0;
+        u8 *c = buf + (y0 >> 1) * S + x0;
         // right-hand corners of the last cell column are halo column 0 (transposed); y0 + step <= TH is a natural row
-        const u8 *cr = x0 + step < TW ? c + step : buf + HCOL + y0;
-        const int dn = x0 + step < TW ? step * S : step;
-        u32 p = pred1<INTERP>(c[0], c[step * S], cr[0], cr[dn]);
+        const u8 *cr = x0 + step < TW ? c + step : buf + HCOL + (y0 >> 1);
+        const int dn = x0 + step < TW ? s * S : s;
+        u32 p = pred1<INTERP>(c[0], c[s * S], cr[0], cr[dn]);
         bool xin = !CHECK || tl.X0 + x0 + s < W, yin = !CHECK || tl.Y0 + y0 + s < H;
         if (xin) c[s] = (u8)(c[s] + p);
-        if (yin) c[s * S] = (u8)(c[s * S] + p);
-        if (xin && yin) c[s * S + s] = (u8)(c[s * S + s] + p);
+        if (yin) c[hs * S] = (u8)(c[hs * S] + p);
+        if (xin && yin) c[hs * S + s] = (u8)(c[hs * S + s] + p);
     }
 }
 
@@ -344,7 +351,7 @@ __device__ __forceinline__ void enc_cells(u8 *buf, u8 *rbuf, const u8 *slut, int
     for (int i = threadIdx.x; i < ncx * ncy; i += NL) {
         int x0 = (i & (ncx - 1)) << lstep, y0 = (i >> lncx) << lstep;
         if (CHECK && (tl.X0 + x0 >= W || tl.Y0 + y0 >= H)) continue;
-        u8 *c = buf + y0 * S + x0;
+        u8 *c = buf + (y0 >> 1) * S + x0;
         u8 *rc = rbuf + (y0 >> 1) * S2 + (x0 >> 1);
         const u8 *rr = x0 + step < TW ? rc + s : rbuf + RCOL + (y0 >> 1);
         const int dn = x0 + step < TW ? s * S2 : s;
@@ -356,13 +363,13 @@ __device__ __forceinline__ void enc_cells(u8 *buf, u8 *rbuf, const u8 *slut, int
             rc[hs] = (u8)(p + q);
         }
         if (yin) {
-            u32 q = quant1s<IDENT>(c[s * S], p, slut);
-            c[s * S] = (u8)q;
+            u32 q = quant1s<IDENT>(c[hs * S], p, slut);
+            c[hs * S] = (u8)q;
             rc[hs * S2] = (u8)(p + q);
         }
         if (xin && yin) {
-            u32 q = quant1s<IDENT>(c[s * S + s], p, slut);
-            c[s * S + s] = (u8)q;
+            u32 q = quant1s<IDENT>(c[hs * S + s], p, slut);
+            c[hs * S + s] = (u8)q;
             rc[hs * S2 + hs] = (u8)(p + q);
         }
     }
@@ -370,17 +377,18 @@ __device__ __forceinline__ void enc_cells(u8 *buf, u8 *rbuf, const u8 *slut, int
 
 // finest level, generic: 16 px x 2 rows per lane, checked stores
 template <int INTERP>
-__device__ __noinline__ void dec_fine_generic(const u8 *buf, u8 *__restrict__ out, Tile tl, u32 W, u32 H, bool aligned)
+__device__ __noinline__ void dec_fine_generic(const u8 *buf, const u8 *__restrict__ fr, u8 *__restrict__ out, Tile tl,
+                                              u32 W, u32 H, bool aligned)
 {
     for (int i = threadIdx.x; i < (TH / 2) * CH; i += NL) {
-        const int y = 2 * (i >> LCH), x = 16 * (i & (CH - 1));
+        const int z = i >> LCH, y = 2 * z, x = 16 * (i & (CH - 1));
         const u32 gx = tl.X0 + x, gy = tl.Y0 + y;
         if (gx >= W || gy >= H) continue;
-        const u8 *r0 = buf + y * S + x;
+        const u8 *r0 = buf + z * S + x;
         uint4 E = *reinterpret_cast<const uint4 *>(r0);
-        uint4 O = *reinterpret_cast<const uint4 *>(r0 + S);
-        uint4 F = *reinterpret_cast<const uint4 *>(r0 + 2 * S);
-        u32 e16 = x + 16 < TW ? r0[16] : buf[HCOL + y], f16 = x + 16 < TW ? r0[2 * S + 16] : buf[HCOL + y + 2];
+        uint4 O = load16(fr, W, H, gx, gy + 1, aligned);     // odd rows never enter LDS
+        uint4 F = *reinterpret_cast<const uint4 *>(r0 + S);
+        u32 e16 = x + 16 < TW ? r0[16] : buf[HCOL + z], f16 = x + 16 < TW ? r0[S + 16] : buf[HCOL + z + 1];
         uint2 c, fl;
         c.x = __builtin_amdgcn_perm(E.y, E.x, 0x06040200u);
         c.y = __builtin_amdgcn_perm(E.w, E.z, 0x06040200u);
@@ -399,17 +407,17 @@ __device__ __noinline__ void dec_fine_generic(const u8 *buf, u8 *__restrict__ ou
 }
 
 template <int INTERP, bool IDENT>
-__device__ __noinline__ void enc_fine_generic(const u8 *buf, const u8 *rbuf, const u8 *slut, u8 *__restrict__ out,
-                                              Tile tl, u32 W, u32 H, bool aligned)
+__device__ __forceinline__ void enc_fine_generic(const u8 *buf, const u8 *rbuf, const u8 *slut, const u8 *__restrict__ fr,
+                                              u8 *__restrict__ out, Tile tl, u32 W, u32 H, bool aligned)
 {
     for (int i = threadIdx.x; i < (TH / 2) * CH; i += NL) {
         const int y = 2 * (i >> LCH), x = 16 * (i & (CH - 1));
         const u32 gx = tl.X0 + x, gy = tl.Y0 + y;
         if (gx >= W || gy >= H) continue;
-        const u8 *r0 = buf + y * S + x;
+        const u8 *r0 = buf + (y >> 1) * S + x;
         const u8 *c0 = rbuf + (y >> 1) * S2 + (x >> 1);
         uint4 E = *reinterpret_cast<const uint4 *>(r0);
-        uint4 O = *reinterpret_cast<const uint4 *>(r0 + S);
+        uint4 O = load16(fr, W, H, gx, gy + 1, aligned);     // odd rows never enter LDS
         uint2 c = *reinterpret_cast<const uint2 *>(c0);
         uint2 fl = *reinterpret_cast<const uint2 *>(c0 + S2);
         u32 c8 = x + 16 < TW ? c0[8] : rbuf[RCOL + (y >> 1)], f8 = x + 16 < TW ? c0[S2 + 8] : rbuf[RCOL + (y >> 1) + 1];
@@ -423,6 +431,7 @@ __device__ __noinline__ void enc_fine_generic(const u8 *buf, const u8 *rbuf, con
         uint4 o0 = make_uint4(__builtin_amdgcn_perm(q0, E.x, 0x05020400u), __builtin_amdgcn_perm(q0, E.y, 0x07020600u),
                               __builtin_amdgcn_perm(q1, E.z, 0x05020400u), __builtin_amdgcn_perm(q1, E.w, 0x07020600u));
         store16(out, W, gx, gy, o0, aligned);
+        __builtin_amdgcn_sched_barrier(0);   // row y + 1 after row y: this cold path must not set the kernel's register count
         if (gy + 1 < H) {
             uint4 o1 = make_uint4(quant4<IDENT>(O.x, pp0, slut), quant4<IDENT>(O.y, pp1, slut),
                                   quant4<IDENT>(O.z, pp2, slut), quant4<IDENT>(O.w, pp3, slut));
@@ -458,7 +467,7 @@ __device__ __forceinline__ CellAddr enc_body_cell(int i, int s, bool on)
     const int step = 2 * s, hsub = s >> 1, lstep = 31 - __clz(step);
     const int ncx = TW >> lstep, lncx = 31 - __clz(ncx);
     const int x0 = (i & (ncx - 1)) << lstep, y0 = (i >> lncx) << lstep;
-    const int c = y0 * S + x0, rc = (y0 >> 1) * S2 + (x0 >> 1);
+    const int c = (y0 >> 1) * S + x0, rc = (y0 >> 1) * S2 + (x0 >> 1);
     const bool lastc = x0 + step == TW;      // right-hand corners are halo column 0 (transposed)
     CellAddr a;
     a.lt = rc;
@@ -466,8 +475,8 @@ __device__ __forceinline__ CellAddr enc_body_cell(int i, int s, bool on)
     a.lb = lastc ? RCOL + (y0 >> 1) : rc + s;
     a.rb = lastc ? RCOL + (y0 >> 1) + s : rc + s * S2 + s;
     a.nx = c + s;
-    a.ny = c + s * S;
-    a.nxy = c + s * S + s;
+    a.ny = c + hsub * S;
+    a.nxy = c + hsub * S + s;
     a.rx = rc + hsub;
     a.ry = rc + hsub * S2;
     a.rxy = rc + hsub * S2 + hsub;
@@ -488,7 +497,6 @@ __device__ __forceinline__ CellAddr enc_halo_cell(int j, int s, Tile tl, u32 W, 
     const bool col = j <= ncy;
     const int y0 = j << lstep;
     const bool corner = y0 == TH;
-    const int yb = corner ? TH + hs : y0 + s;
     const int z0 = y0 >> 1, za = corner ? TH / 2 + h2 : (y0 + step) >> 1, zb = corner ? TH / 2 + hs : (y0 + s) >> 1;
     const int x0 = (j - ncy - 1) << lstep, w0 = x0 >> 1;
     const bool lastc = x0 + step == TW;
@@ -498,9 +506,9 @@ __device__ __forceinline__ CellAddr enc_halo_cell(int j, int s, Tile tl, u32 W, 
     a.rt = col ? RCOL + za : (TH / 2 + h2) * S2 + w0;
     a.lb = col ? RCOL + h2 * HP2 + z0 : (lastc ? RCOL + TH / 2 : (TH / 2) * S2 + w0 + s);
     a.rb = col ? RCOL + h2 * HP2 + za : (lastc ? RCOL + TH / 2 + h2 : (TH / 2 + h2) * S2 + w0 + s);
-    a.nx = col ? HCOL + hs * HP + y0 : TH * S + x0 + s;
-    a.ny = col ? HCOL + yb : (TH + hs) * S + x0;
-    a.nxy = col ? HCOL + hs * HP + yb : (TH + hs) * S + x0 + s;
+    a.nx = col ? HCOL + hs * HP + z0 : (TH / 2) * S + x0 + s;
+    a.ny = col ? HCOL + zb : (TH / 2 + hs) * S + x0;
+    a.nxy = col ? HCOL + hs * HP + zb : (TH / 2 + hs) * S + x0 + s;
     a.rx = col ? RCOL + hs * HP2 + z0 : (TH / 2) * S2 + w0 + hsub;
     a.ry = col ? RCOL + zb : (TH / 2 + hs) * S2 + w0;
     a.rxy = col ? RCOL + hs * HP2 + zb : (TH / 2 + hs) * S2 + w0 + hsub;
@@ -550,7 +558,7 @@ __device__ __forceinline__ void enc_halo_pass(u8 *buf, u8 *rbuf, const u8 *slut,
 }
 
 // One coarse level (sub >= 4) of an interior tile, body cells and halo cells in one chain.
-// sub == 4: 128 body cells (two per lane) + 25 halo cells; sub >= 8: <= 32 body cells on lanes 0..31,
+// sub == 4: 128 body cells (two per lane), then the 25 halo cells; sub >= 8: <= 32 body cells on lanes 0..31,
 // the halo cells on lanes 32..63.
 template <int INTERP, bool IDENT>
 __device__ __forceinline__ void enc_level_coarse_fast(u8 *buf, u8 *rbuf, const u8 *slut, int s, Tile tl, u32 W, u32 H)
@@ -559,11 +567,12 @@ __device__ __forceinline__ void enc_level_coarse_fast(u8 *buf, u8 *rbuf, const u
     if (s == 4) {
         constexpr int ncells4 = (TW / 8) * (TH / 8);
         const CellAddr a0 = enc_body_cell(lane, 4, lane < ncells4), a1 = enc_body_cell(lane + NL, 4, lane + NL < ncells4);
-        const CellAddr ah = lane < TH / 8 + 1 + TW / 8 ? enc_halo_cell(lane, 4, tl, W, H) : idle_cell();
-        const CellVal v0 = cell_load(buf, rbuf, a0), v1 = cell_load(buf, rbuf, a1), vh = cell_load(buf, rbuf, ah);
+        const CellVal v0 = cell_load(buf, rbuf, a0), v1 = cell_load(buf, rbuf, a1);
         cell_finish<INTERP, IDENT>(buf, rbuf, slut, a0, v0);
         cell_finish<INTERP, IDENT>(buf, rbuf, slut, a1, v1);
-        cell_finish<INTERP, IDENT>(buf, rbuf, slut, ah, vh);
+        // the 25 halo cells in a pass of their own: three cells in flight per lane was the register peak
+        LDS_ORDER();
+        enc_halo_pass<INTERP, IDENT>(buf, rbuf, slut, 4, tl, W, H);
     } else {
         const int step = 2 * s, lstep = 31 - __clz(step);
         const int ncells = (TW >> lstep) * (TH >> lstep), nhalo = (TH >> lstep) + 1 + (TW >> lstep);
@@ -583,9 +592,16 @@ struct Buf {
     u32 W, base;                 // base = Y0 * W + X0
 };
 
+// Row pair (image rows 2p, 2p + 1) a lane owns in iteration `it` of the finest level, p = fine_pair0 + 8 * it:
+// the octets of a half-wave take pairs 0,2,4,6 / 1,3,5,7, i.e. LDS rows two apart (bank skew).
+// The staging loads of the odd rows use the same map, which is what lets those rows stay in registers.
+__device__ __forceinline__ int fine_pair0() { return 2 * (((int)threadIdx.x >> LCH) & 3) + ((int)threadIdx.x >> 5); }
+constexpr int NFINE = (TH / 2) * CH / NL;   // fine-level iterations = odd rows a lane holds
+
 // Everything a tile stages: all loads are issued before the first LDS write.
 struct Stage {
-    v4u v[TH / 8];      // tile body: 8 x 16 B per lane (8 full 128-B lines per wave instruction)
+    v4u e[TH / 16];     // even rows: 16 B per lane and row group (8 full 128-B lines per wave instruction) -> LDS
+    v4u o[NFINE];       // odd rows, fine-level lane map: stay in registers until the finest level
     v4u hv;             // halo rows TH + {0,4,8,..}: full lines
     v3u x0;             // halo columns: one lane per (even) row; this 12-B load holds offsets 0/4/8
     u32 d16, d32, d64;  // ... and single dwords supply offsets 16/32/64
@@ -593,24 +609,31 @@ struct Stage {
 
 // Rows below the image return 0 from the buffer range check; columns right of the image are masked
 // with wave-uniform tests.
+// RAGGED tiles finish in the generic fine level, which fetches its odd rows itself.
 template <bool RAGGED>
 __device__ __forceinline__ void stage_issue(Stage &st, const Buf &b, Tile tl, int k, int nh)
 {
     const int lane = threadIdx.x, c = lane & (CH - 1), r = lane >> LCH;
     const u32 W = __builtin_amdgcn_readfirstlane(b.W);   // soffset operands must be provably uniform
-    const u32 voff = b.base + r * W + 16 * c;
+    const u32 voff = b.base + 2 * r * W + 16 * c;                       // even rows 2 * (r + 8 j)
+    const u32 vodd = b.base + (2 * fine_pair0() + 1) * W + 16 * c;      // odd rows 2 * (pair0 + 8 it) + 1
     // Interior tiles: every chunk is inside the image.  Ragged tiles (edge kernels): rows below the
     // image come back as 0 from the range check (the row offsets go through voffset there, which is
     // what the check sees), chunks right of it are masked.
     const bool cin = tl.X0 + 16 * c < W;
 #pragma unroll
-    for (int j = 0; j < TH / 8; ++j) {
-        st.v[j] = v4u{0, 0, 0, 0};
+    for (int j = 0; j < TH / 16; ++j) {
+        st.e[j] = v4u{0, 0, 0, 0};
         if (RAGGED) {
-            if (cin) st.v[j] = __builtin_amdgcn_raw_buffer_load_b128(b.rs, voff + j * 8 * W, 0, 0);
+            if (cin) st.e[j] = __builtin_amdgcn_raw_buffer_load_b128(b.rs, voff + j * 16 * W, 0, 0);
         } else {
-            st.v[j] = __builtin_amdgcn_raw_buffer_load_b128(b.rs, voff, j * 8 * W, HGI_LOAD_AUX);
+            st.e[j] = __builtin_amdgcn_raw_buffer_load_b128(b.rs, voff, j * 16 * W, HGI_LOAD_AUX);
         }
+    }
+#pragma unroll
+    for (int j = 0; j < NFINE; ++j) {
+        st.o[j] = v4u{0, 0, 0, 0};
+        if (!RAGGED) st.o[j] = __builtin_amdgcn_raw_buffer_load_b128(b.rs, vodd, j * 16 * W, HGI_LOAD_AUX);
     }
     st.hv = v4u{0, 0, 0, 0};
     if (lane < nh * CH && cin) st.hv = __builtin_amdgcn_raw_buffer_load_b128(b.rs, b.base + (TH + hoff(r)) * W + 16 * c, 0, 0);
@@ -631,11 +654,11 @@ __device__ __forceinline__ void stage_commit(u8 *buf, const Stage &st, int nh)
 {
     const int lane = threadIdx.x, c = lane & (CH - 1), r = lane >> LCH;
 #pragma unroll
-    for (int j = 0; j < TH / 8; ++j) *reinterpret_cast<v4u *>(buf + (r + 8 * j) * S + 16 * c) = st.v[j];
-    if (lane < nh * CH) *reinterpret_cast<v4u *>(buf + (TH + r) * S + 16 * c) = st.hv;
+    for (int j = 0; j < TH / 16; ++j) *reinterpret_cast<v4u *>(buf + (r + 8 * j) * S + 16 * c) = st.e[j];
+    if (lane < nh * CH) *reinterpret_cast<v4u *>(buf + (TH / 2 + r) * S + 16 * c) = st.hv;
     if (lane < TH / 2 + nh) {
-        // transposed halo columns: slot {0..5} <- offsets {0, 4, 8, 16, 32, 64}, one byte per row
-        u8 *h = buf + HCOL + (lane < TH / 2 ? 2 * lane : TH + (lane - TH / 2));
+        // transposed halo columns: slot {0..5} <- offsets {0, 4, 8, 16, 32, 64}, one byte per LDS row
+        u8 *h = buf + HCOL + lane;
         h[0 * HP] = (u8)st.x0.x;
         h[1 * HP] = (u8)st.x0.y;
         h[2 * HP] = (u8)st.x0.z;
@@ -658,15 +681,15 @@ __device__ __forceinline__ void dec_level2_fast(u8 *buf)
 #pragma unroll
     for (int it = 0; it < (TH / 4) * CH / NL; ++it) {
         const int i = threadIdx.x + it * NL;
-        u8 *r0 = buf + 4 * (i >> LCH) * S + 16 * (i & (CH - 1));
+        u8 *r0 = buf + 2 * (i >> LCH) * S + 16 * (i & (CH - 1));      // image rows y0, y0 + 2, y0 + 4 = LDS rows z0 ..
         v4u A = *reinterpret_cast<const v4u *>(r0);
-        v4u B = *reinterpret_cast<const v4u *>(r0 + 2 * S);
-        v4u C = *reinterpret_cast<const v4u *>(r0 + 4 * S);
+        v4u B = *reinterpret_cast<const v4u *>(r0 + S);
+        v4u C = *reinterpret_cast<const v4u *>(r0 + 2 * S);
         // ninth corner of each row: first byte of the next chunk = lane + 1, or the halo column
-        const int y0 = 4 * (i >> LCH);
+        const int z0 = 2 * (i >> LCH);
         const bool last = (i & (CH - 1)) == CH - 1;
         u32 a16 = from_next_lane(A.x), c16 = from_next_lane(C.x);
-        const u32 ha = buf[HCOL + y0], hc = buf[HCOL + y0 + 4];
+        const u32 ha = buf[HCOL + z0], hc = buf[HCOL + z0 + 2];
         a16 = last ? ha : a16;
         c16 = last ? hc : c16;
         u32 ct = gather_b0(A), cb = gather_b0(C);
@@ -679,29 +702,29 @@ __device__ __forceinline__ void dec_level2_fast(u8 *buf)
         HGI_ADDB(b0, 2, P, 0); HGI_ADDB(b1, 2, P, 1); HGI_ADDB(b2, 2, P, 2); HGI_ADDB(b3, 2, P, 3);
         v4u An = {a0, a1, a2, a3}, Bn = {b0, b1, b2, b3};
         *reinterpret_cast<v4u *>(r0) = An;
-        *reinterpret_cast<v4u *>(r0 + 2 * S) = Bn;
+        *reinterpret_cast<v4u *>(r0 + S) = Bn;
     }
 }
 
-// finest level: 16 px x 2 rows per lane, LDS -> packed VALU -> 16-B buffer stores
+// finest level: 16 px x 2 rows per lane; even rows from LDS, odd rows from the registers they were loaded
+// into, packed VALU, 16-B buffer stores
 template <int INTERP>
-__device__ __forceinline__ void dec_fine_fast(const u8 *buf, const Buf &b)
+__device__ __forceinline__ void dec_fine_fast(const u8 *buf, const Buf &b, const v4u (&odd)[NFINE])
 {
     const int lane = threadIdx.x;
-    // octets of a half-wave take row pairs 0,2,4,6 / 1,3,5,7: rows 4 apart = 32 banks apart (S = 160)
-    const int rp0 = 2 * ((lane >> LCH) & 3) + (lane >> 5);
+    const int rp0 = fine_pair0();
     const bool last = (lane & (CH - 1)) == CH - 1;
-    const u8 *r0 = buf + 2 * rp0 * S + 16 * (lane & (CH - 1));
-    const u8 *h0 = buf + HCOL + 2 * rp0;
+    const u8 *r0 = buf + rp0 * S + 16 * (lane & (CH - 1));
+    const u8 *h0 = buf + HCOL + rp0;
     u32 voff = b.base + 2 * rp0 * b.W + 16 * (lane & (CH - 1));
-#pragma unroll 2
-    for (int it = 0; it < (TH / 2) * CH / NL; ++it, r0 += 2 * (NL / CH) * S, h0 += 2 * (NL / CH), voff += 2 * (NL / CH) * b.W) {
+#pragma unroll
+    for (int it = 0; it < NFINE; ++it, r0 += (NL / CH) * S, h0 += NL / CH, voff += 2 * (NL / CH) * b.W) {
         v4u E = *reinterpret_cast<const v4u *>(r0);
-        v4u O = *reinterpret_cast<const v4u *>(r0 + S);
-        v4u F = *reinterpret_cast<const v4u *>(r0 + 2 * S);
+        v4u O = odd[it];
+        v4u F = *reinterpret_cast<const v4u *>(r0 + S);
         // ninth corner of each lattice row: first byte of the next chunk = lane + 1, or the halo column
         u32 e16 = from_next_lane(E.x), f16 = from_next_lane(F.x);
-        const u32 he = h0[0], hf = h0[2];
+        const u32 he = h0[0], hf = h0[1];
         e16 = last ? he : e16;
         f16 = last ? hf : f16;
         uint2 c, fl;
@@ -730,39 +753,27 @@ __device__ __forceinline__ void dec_fine_fast(const u8 *buf, const Buf &b)
 template <int INTERP, bool IDENT>
 __device__ __forceinline__ void enc_level2_fast(u8 *buf, u8 *rbuf, const u8 *slut, Tile tl, u32 W, u32 H)
 {
-    // the level's halo cells (17 column + 32 row cells): reads first, finished after the body below
-    const CellAddr ah = (int)threadIdx.x < TH / 4 + 1 + TW / 4 ? enc_halo_cell(threadIdx.x, 2, tl, W, H) : idle_cell();
-    const CellVal vh = cell_load(buf, rbuf, ah);
+    // One iteration (64 lanes x 4 cells) at a time, all its reads before its first write, and the level's
+    // halo cells in a pass of their own afterwards: with the odd rows parked in registers the level is
+    // the kernel's register high-water mark, and 96 VGPRs (5 waves per SIMD) beat the longer chains that
+    // batching both iterations and the halo cells into one bought at 12 waves per CU.
     constexpr int NIT = (TH / 4) * CH / NL;
-    v4u A_[NIT], B_[NIT];
-    v2u cu_[NIT], cl_[NIT];
-    u32 hu_[NIT], hl_[NIT];
-#pragma unroll
-    for (int it = 0; it < NIT; ++it) {   // every read of the level before the first write
-        const int i = threadIdx.x + it * NL;
-        const int g = i >> LCH, c = i & (CH - 1);
-        const u8 *r0 = buf + 4 * g * S + 16 * c;
-        const u8 *q0 = rbuf + 2 * g * S2 + 8 * c;
-        A_[it] = *reinterpret_cast<const v4u *>(r0);
-        B_[it] = *reinterpret_cast<const v4u *>(r0 + 2 * S);
-        cu_[it] = *reinterpret_cast<const v2u *>(q0);
-        cl_[it] = *reinterpret_cast<const v2u *>(q0 + 2 * S2);
-        hu_[it] = rbuf[RCOL + 2 * g];
-        hl_[it] = rbuf[RCOL + 2 * g + 2];
-    }
-    LDS_ORDER();
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
         const int i = threadIdx.x + it * NL;
         const int g = i >> LCH, c = i & (CH - 1);
-        u8 *r0 = buf + 4 * g * S + 16 * c;
+        u8 *r0 = buf + 2 * g * S + 16 * c;
         u8 *q0 = rbuf + 2 * g * S2 + 8 * c;
-        const v4u A = A_[it], B = B_[it];
-        const v2u cu = cu_[it], cl = cl_[it];
+        const v4u A = *reinterpret_cast<const v4u *>(r0);
+        const v4u B = *reinterpret_cast<const v4u *>(r0 + S);
+        const v2u cu = *reinterpret_cast<const v2u *>(q0);
+        const v2u cl = *reinterpret_cast<const v2u *>(q0 + 2 * S2);
+        const u32 hu = rbuf[RCOL + 2 * g], hl = rbuf[RCOL + 2 * g + 2];
+        LDS_ORDER();
         const bool last = c == CH - 1;
         u32 c8 = from_next_lane(cu.x), l8 = from_next_lane(cl.x);
-        c8 = last ? hu_[it] : c8;
-        l8 = last ? hl_[it] : l8;
+        c8 = last ? hu : c8;
+        l8 = last ? hl : l8;
         u32 ct = __builtin_amdgcn_perm(cu.y, cu.x, 0x06040200u), cb = __builtin_amdgcn_perm(cl.y, cl.x, 0x06040200u);
         u32 P = ct;
         if (INTERP == kInterpCrossed)
@@ -803,20 +814,23 @@ __device__ __forceinline__ void enc_level2_fast(u8 *buf, u8 *rbuf, const u8 *slu
         }
         v4u An = {a0, a1, a2, a3}, Bn = {b0, b1, b2, b3};
         *reinterpret_cast<v4u *>(r0) = An;
-        *reinterpret_cast<v4u *>(r0 + 2 * S) = Bn;
+        *reinterpret_cast<v4u *>(r0 + S) = Bn;
         *reinterpret_cast<v2u *>(q0) = n0;
         *reinterpret_cast<v2u *>(q0 + S2) = n1;
+        __builtin_amdgcn_sched_barrier(0);   // keep the next iteration's reads behind this one's arithmetic
     }
-    cell_finish<INTERP, IDENT>(buf, rbuf, slut, ah, vh);
+    LDS_ORDER();
+    enc_halo_pass<INTERP, IDENT>(buf, rbuf, slut, 2, tl, W, H);
 }
 
 template <int INTERP, bool IDENT>
-__device__ __forceinline__ void enc_fine_fast(const u8 *buf, const u8 *rbuf, const u8 *slut, const Buf &b)
+__device__ __forceinline__ void enc_fine_fast(const u8 *buf, const u8 *rbuf, const u8 *slut, const Buf &b,
+                                              const v4u (&odd)[NFINE])
 {
     const int lane = threadIdx.x;
-    const int rp0 = 2 * ((lane >> LCH) & 3) + (lane >> 5);   // as in dec_fine_fast
+    const int rp0 = fine_pair0();
     const bool last = (lane & (CH - 1)) == CH - 1;
-    const u8 *r0 = buf + 2 * rp0 * S + 16 * (lane & (CH - 1));
+    const u8 *r0 = buf + rp0 * S + 16 * (lane & (CH - 1));
     const u8 *c0 = rbuf + rp0 * S2 + 8 * (lane & (CH - 1));
     const u8 *h0 = rbuf + RCOL + rp0;
     u32 voff = b.base + 2 * rp0 * b.W + 16 * (lane & (CH - 1));
@@ -824,18 +838,18 @@ __device__ __forceinline__ void enc_fine_fast(const u8 *buf, const u8 *rbuf, con
 #ifndef HGI_FINE_BATCH
 #define HGI_FINE_BATCH 2
 #endif
-    constexpr int NIT = (TH / 2) * CH / NL, PAIR = HGI_FINE_BATCH;   // row-pair groups per LDS dependency chain
+    constexpr int NIT = NFINE, PAIR = HGI_FINE_BATCH;   // row-pair groups per LDS dependency chain
     static_assert(NIT % PAIR == 0, "fine level iterations come in pairs");
-#pragma unroll 1
+#pragma unroll
     for (int it = 0; it < NIT; it += PAIR) {
         v4u E_[PAIR], O_[PAIR];
         uint2 c_[PAIR], f_[PAIR];
         u32 hc_[PAIR], hf_[PAIR];
 #pragma unroll
         for (int j = 0; j < PAIR; ++j) {
-            const u8 *r = r0 + j * 2 * (NL / CH) * S, *c = c0 + j * (NL / CH) * S2, *h = h0 + j * (NL / CH);
+            const u8 *r = r0 + j * (NL / CH) * S, *c = c0 + j * (NL / CH) * S2, *h = h0 + j * (NL / CH);
             E_[j] = *reinterpret_cast<const v4u *>(r);
-            O_[j] = *reinterpret_cast<const v4u *>(r + S);
+            O_[j] = odd[it + j];
             c_[j] = *reinterpret_cast<const uint2 *>(c);
             f_[j] = *reinterpret_cast<const uint2 *>(c + S2);
             hc_[j] = h[0];
@@ -875,7 +889,7 @@ __device__ __forceinline__ void enc_fine_fast(const u8 *buf, const u8 *rbuf, con
             const u32 vo = voff + j * 2 * (NL / CH) * Ws;
             store_row_pair(o0, o1, b.rd, vo, Ws);
         }
-        r0 += PAIR * 2 * (NL / CH) * S;
+        r0 += PAIR * (NL / CH) * S;
         c0 += PAIR * (NL / CH) * S2;
         h0 += PAIR * (NL / CH);
         voff += PAIR * 2 * (NL / CH) * Ws;
@@ -999,7 +1013,7 @@ __device__ __forceinline__ void dec_seed_commit(u8 *buf, const SeedRegs &r, u32 
 
 // One tile of the fast path, out of LDS: levels sub = 2^(k-1) .. 2 in place, then the finest level to HBM.
 template <int INTERP>
-__device__ __forceinline__ void dec_tile_fast(u8 *buf, const TileCtx &cur, u32 k, u32 W, u32 H)
+__device__ __forceinline__ void dec_tile_fast(u8 *buf, const TileCtx &cur, const v4u (&odd)[NFINE], u32 k, u32 W, u32 H)
 {
     for (int s = 1 << (k - 1); s >= 2 && !(HGI_ABL & 1); s >>= 1) {
         if (s == 2) {
@@ -1010,7 +1024,7 @@ __device__ __forceinline__ void dec_tile_fast(u8 *buf, const TileCtx &cur, u32 k
         if (!(HGI_ABL & 4)) dec_halo_cells<INTERP>(buf, s, cur.tl, W, H);
         LDS_ORDER();
     }
-    dec_fine_fast<INTERP>(buf, cur.b);
+    dec_fine_fast<INTERP>(buf, cur.b, odd);
 }
 
 // One block (= one wave) per tile, ONE launch per batch.  The first blocks take the ragged tiles
@@ -1035,8 +1049,11 @@ __device__ __forceinline__ BlockRole block_role(const TileGrid &g)
     return r;
 }
 
+#ifndef HGI_DEC_WAVES_PER_EU
+#define HGI_DEC_WAVES_PER_EU 8
+#endif
 template <int INTERP, bool SEEDED>
-__global__ __launch_bounds__(NL) void k_dec_tiles(const u8 *__restrict__ src, u8 *__restrict__ dst, Frames f, u32 k,
+__global__ __launch_bounds__(NL) __attribute__((amdgpu_waves_per_eu(HGI_DEC_WAVES_PER_EU))) void k_dec_tiles(const u8 *__restrict__ src, u8 *__restrict__ dst, Frames f, u32 k,
                                                   Seeds sd, TileGrid g, u32 aligned)
 {
     extern __shared__ __attribute__((aligned(16))) u8 smem[];
@@ -1054,7 +1071,7 @@ __global__ __launch_bounds__(NL) void k_dec_tiles(const u8 *__restrict__ src, u8
         stage_commit(buf, st, nh);
         LDS_ORDER();
         if (SEEDED) dec_seed_commit(buf, seeds, k);
-        dec_tile_fast<INTERP>(buf, cur, k, W, H);
+        dec_tile_fast<INTERP>(buf, cur, st.o, k, W, H);
         return;
     }
     // ragged tile (body crosses the image edge), unaligned rows, or offsets beyond 32 bits: every access checked
@@ -1077,7 +1094,7 @@ __global__ __launch_bounds__(NL) void k_dec_tiles(const u8 *__restrict__ src, u8
         dec_halo_cells<INTERP>(buf, s, tl, W, H);
         LDS_ORDER();
     }
-    dec_fine_generic<INTERP>(buf, out, tl, W, H, (aligned & 1u) != 0);
+    dec_fine_generic<INTERP>(buf, fr, out, tl, W, H, (aligned & 1u) != 0);
 }
 
 // ---- encode ---------------------------------------------------------------------------------------
@@ -1111,7 +1128,8 @@ __device__ __forceinline__ void clear_lattice(u8 *rbuf, int nh)
 }
 
 template <int INTERP, bool IDENT>
-__device__ __forceinline__ void enc_tile_fast(u8 *buf, u8 *rbuf, const u8 *slut, const TileCtx &cur, u32 k, u32 W, u32 H)
+__device__ __forceinline__ void enc_tile_fast(u8 *buf, u8 *rbuf, const u8 *slut, const TileCtx &cur,
+                                              const v4u (&odd)[NFINE], u32 k, u32 W, u32 H)
 {
     for (int s = 1 << (k - 1); s >= 2 && !(HGI_ABL & 1); s >>= 1) {
         if (s == 2)
@@ -1120,11 +1138,16 @@ __device__ __forceinline__ void enc_tile_fast(u8 *buf, u8 *rbuf, const u8 *slut,
             enc_level_coarse_fast<INTERP, IDENT>(buf, rbuf, slut, s, cur.tl, W, H);
         LDS_ORDER();
     }
-    enc_fine_fast<INTERP, IDENT>(buf, rbuf, slut, cur.b);
+    enc_fine_fast<INTERP, IDENT>(buf, rbuf, slut, cur.b, odd);
 }
 
+// Occupancy targets handed to the register allocator: encode fits 96 VGPRs (5 waves per SIMD, 20 per CU;
+// LDS allows 21 at k = 4) without spilling -- tests/test_isa.py checks that -- decode needs ~50.
+#ifndef HGI_ENC_WAVES_PER_EU
+#define HGI_ENC_WAVES_PER_EU 5
+#endif
 template <int INTERP, bool IDENT, bool SEEDED>
-__global__ __launch_bounds__(NL) void k_enc_tiles(const u8 *__restrict__ src, u8 *__restrict__ dst, Frames f, u32 k,
+__global__ __launch_bounds__(NL) __attribute__((amdgpu_waves_per_eu(IDENT ? HGI_ENC_WAVES_PER_EU - 1 : HGI_ENC_WAVES_PER_EU))) void k_enc_tiles(const u8 *__restrict__ src, u8 *__restrict__ dst, Frames f, u32 k,
                                                   Lut256 lut, Seeds sd, TileGrid g, u32 aligned)
 {
     extern __shared__ __attribute__((aligned(16))) u8 smem[];
@@ -1146,7 +1169,7 @@ __global__ __launch_bounds__(NL) void k_enc_tiles(const u8 *__restrict__ src, u8
         stage_commit(buf, st, nh);
         LDS_ORDER();
         enc_seed_commit<SEEDED>(buf, rbuf, seeds, k);
-        enc_tile_fast<INTERP, IDENT>(buf, rbuf, slut, cur, k, W, H);
+        enc_tile_fast<INTERP, IDENT>(buf, rbuf, slut, cur, st.o, k, W, H);
         return;
     }
     const Tile tl = edge_tile(role.index, g);
@@ -1169,7 +1192,7 @@ __global__ __launch_bounds__(NL) void k_enc_tiles(const u8 *__restrict__ src, u8
         enc_halo_pass<INTERP, IDENT>(buf, rbuf, slut, s, tl, W, H);
         LDS_ORDER();
     }
-    enc_fine_generic<INTERP, IDENT>(buf, rbuf, slut, out, tl, W, H, (aligned & 1u) != 0);
+    enc_fine_generic<INTERP, IDENT>(buf, rbuf, slut, fr, out, tl, W, H, (aligned & 1u) != 0);
 }
 
 inline bool ptr16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
