@@ -87,6 +87,28 @@ __global__ void k_copy_tiles(const uint8_t *__restrict__ src, uint8_t *__restric
     for (int j = 0; j < 8; ++j) __builtin_amdgcn_raw_buffer_store_b128(v[j], rd, base + j * 8u * W, 0, AUX_ST);
 }
 
+// general tile copy: one wave per TWT x THT tile (TWT * THT = 8192 B), rows of TWT / 16 lanes; order = 0: XCD-contiguous
+// row-major tiles; 1: plain row-major block order
+template <int TWT, int AUX_LD, int AUX_ST>
+__global__ void k_copy_shape(const uint8_t *__restrict__ src, uint8_t *__restrict__ dst, uint32_t bytes_lo, uint32_t W,
+                             uint32_t ntiles, int order)
+{
+    constexpr int LPR = TWT / 16, RPL = 64 / LPR, THT = 8192 / TWT, NLD = THT / RPL;
+    __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(src), 0, bytes_lo, 0x00020000);
+    __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc(dst, 0, bytes_lo, 0x00020000);
+    const uint32_t tiles_x = W / TWT;
+    const uint32_t b = blockIdx.x, per = ntiles >> 3;
+    const uint32_t t = order == 0 ? (b & 7u) * per + (b >> 3) : b;
+    const uint32_t ty = t / tiles_x, tx = t - ty * tiles_x;
+    const uint32_t lane = threadIdx.x;
+    const uint32_t base = (ty * THT + lane / LPR) * W + tx * TWT + (lane % LPR) * 16u;
+    v4u v[NLD];
+#pragma unroll
+    for (int j = 0; j < NLD; ++j) v[j] = __builtin_amdgcn_raw_buffer_load_b128(rs, base + j * RPL * W, 0, AUX_LD);
+#pragma unroll
+    for (int j = 0; j < NLD; ++j) __builtin_amdgcn_raw_buffer_store_b128(v[j], rd, base + j * RPL * W, 0, AUX_ST);
+}
+
 struct Timer {
     hipEvent_t a, b;
     Timer()
@@ -184,6 +206,27 @@ int main(int argc, char **argv)
         }
         double t = T.ms([&] { hipLaunchKernelGGL((k_copy_tiles<0>), dim3(ntiles), dim3(64), 0, 0, a, b, lo, W, tiles_x, ntiles); });
         printf("tile copy 128x64 per wave, default stores           : %7.1f GB/s (%.3f ms)\n", gbs(2.0 * n, t), t);
+    }
+    {
+        const uint32_t W = 4096, ntiles = (uint32_t)(n / 8192);
+#define RUN_SHAPE(TWT, LD, ST, ORD)                                                                                        \
+    do {                                                                                                                    \
+        double t_ = T.ms([&] { hipLaunchKernelGGL((k_copy_shape<TWT, LD, ST>), dim3(ntiles), dim3(64), 0, 0, a, b, lo, W, ntiles, ORD); }); \
+        printf("shape copy %4d x %3d per wave, ld_aux %d st_aux %d, %s : %7.1f GB/s (%.3f ms)\n", TWT, 8192 / TWT, LD, ST,      \
+               ORD ? "row-major blocks " : "XCD-contiguous   ", gbs(2.0 * n, t_), t_);                                        \
+    } while (0)
+        RUN_SHAPE(64, 0, 2, 0);
+        RUN_SHAPE(128, 0, 2, 0);
+        RUN_SHAPE(256, 0, 2, 0);
+        RUN_SHAPE(512, 0, 2, 0);
+        RUN_SHAPE(1024, 0, 2, 0);
+        RUN_SHAPE(128, 0, 2, 1);
+        RUN_SHAPE(256, 0, 2, 1);
+        RUN_SHAPE(1024, 0, 2, 1);
+        RUN_SHAPE(128, 2, 2, 0);
+        RUN_SHAPE(256, 2, 2, 0);
+        RUN_SHAPE(1024, 2, 2, 0);
+        RUN_SHAPE(128, 0, 0, 0);
     }
     double t = T.ms([&] { CK(hipMemcpyAsync(b, a, n, hipMemcpyDeviceToDevice, 0)); });
     printf("hipMemcpyAsync D2D : %7.1f GB/s (%.3f ms)\n", gbs(2.0 * n, t), t);
