@@ -92,6 +92,8 @@ def main():
     ap.add_argument("--levels", type=int, default=4)
     ap.add_argument("--quant", default="medium")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--xgmi-scatter", action="store_true",
+                    help="also time the labelled variant where all frames start and end on GPU 0 (scatter, code, gather)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -175,6 +177,41 @@ def main():
         dec.decode_batch(grids, levels, out=outs)      # restore the decoded frames the checks below read
         torch.cuda.synchronize(dev)
 
+    # ---- optional, separately labelled: every frame starts and ends on GPU 0.  Bound by the
+    # source GPU's xGMI links, not by the codec; never part of `value`.
+    xgmi = None
+    if args.xgmi_scatter:
+        allf = torch.empty((world * F, S, S), dtype=torch.uint8, device=dev) if rank == 0 else None
+        allo = torch.empty_like(allf) if rank == 0 else None
+        if rank == 0:
+            _ffi.check(_ffi.lib().hgi_synth_u8_dev(ctx.handle, _ffi.SYNTH_RAMP, SEED0 + 3, 0, S, S,
+                                                   allf.data_ptr(), world * F, S * S))
+        mine_in = torch.empty_like(imgs)
+
+        def xstep():
+            batch.scatter_frames(dist, allf, mine_in)
+            enc.encode_batch(mine_in, out=grids)
+            dec.decode_batch(grids, levels, out=outs)
+            batch.gather_frames(dist, outs, allo)
+
+        xstep()
+        fence()
+        t1 = time.perf_counter()
+        nx = max(1, min(args.steps, 5))
+        for _ in range(nx):
+            xstep()
+        fence()
+        xs = batch.max_over_ranks(dist, time.perf_counter() - t1, dev) / nx
+        if rank == 0:
+            same = bool(torch.equal(allo[:F], outs)) and int((allf[:F].to(torch.int16) - allo[:F].to(torch.int16)).abs().max()) <= err
+            xgmi = {"ms_per_step": round(xs * 1e3, 4), "value": round(world * F * S * S / xs / 1e6, 1), "unit": "Mpixels/s",
+                    "bytes_over_links_per_step": 2 * (world - 1) * F * S * S, "roundtrip_ok": same,
+                    "note": "frames scattered from and gathered to GPU 0 (torch.distributed scatter/gather over RCCL); "
+                            "per-link bound, reported beside the sharded number, never as it"}
+        del allf, allo, mine_in
+        dec.decode_batch(grids, levels, out=outs)
+        torch.cuda.synchronize(dev)
+
     # ---- per-rank checks + stats gather (RCCL all-gather) ----
     stats = torch.zeros(3 * F, dtype=torch.int64, device=dev)
     _ffi.check(_ffi.lib().hgi_diff_stats_dev(ctx.handle, imgs.data_ptr(), outs.data_ptr(), S, S, F, S * S,
@@ -215,6 +252,8 @@ def main():
                                            "avg_launch_ms": round(copy_ms, 4),
                                            "note": "16-B/lane copy kernel moving the same bytes"}},
         }
+        if xgmi is not None:
+            line["xgmi_scatter_gather"] = xgmi
         if world == 1 and not args.no_cpu:
             check = {"grid": grids[:2].cpu().numpy(), "out": outs[:2].cpu().numpy()}
             line["cpu_baseline"] = cpu_baseline(args, lut, check)

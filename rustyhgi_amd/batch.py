@@ -7,7 +7,9 @@ tests) carry only what the split itself needs:
   * broadcast of the coding parameters -- quantizer table, its error bound, levels -- from rank 0;
   * all-gather of small per-rank statistics at the end.
 Moving pixels between GPUs would cost more than coding them where they are (xGMI ~1 TB/s out of
-one GPU versus ~5 TB/s of HBM per GPU), so it is never done for throughput.
+one GPU versus ~5 TB/s of HBM per GPU), so it is never done for throughput.  scatter_frames /
+gather_frames exist for the one case where the frames really do start on a single GPU, and for the
+separately labelled "xgmi_scatter_gather" measurement of bench.py --xgmi-scatter.
 """
 import numpy as np
 
@@ -60,3 +62,31 @@ def max_over_ranks(dist, value, device):
     if dist is not None:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
+
+
+def scatter_frames(dist, all_frames, mine, src=0):
+    """Rank `src` holds `all_frames` (world * F frames, rank-major); every rank receives its F frames in `mine`.
+    Point-to-point under the hood (one xGMI link per peer), so the source GPU's links bound it."""
+    if dist is None:
+        mine.copy_(all_frames)
+        return
+    world, rank = dist.get_world_size(), dist.get_rank()
+    chunks = None
+    if rank == src:
+        assert all_frames.shape[0] == world * mine.shape[0], "all_frames must hold world * F frames"
+        chunks = [c.contiguous() for c in all_frames.chunk(world)]
+    dist.scatter(mine, chunks, src=src)
+
+
+def gather_frames(dist, mine, all_frames, dst=0):
+    """Inverse of scatter_frames: rank `dst` ends up with every rank's frames, rank-major."""
+    if dist is None:
+        all_frames.copy_(mine)
+        return
+    world, rank = dist.get_world_size(), dist.get_rank()
+    if rank == dst:
+        parts = [c for c in all_frames.chunk(world)]
+        assert all(p.is_contiguous() for p in parts)
+        dist.gather(mine, parts, dst=dst)
+    else:
+        dist.gather(mine, None, dst=dst)

@@ -650,21 +650,52 @@ __device__ __forceinline__ void stage_issue(Stage &st, const Buf &b, Tile tl, in
     }
 }
 
-__device__ __forceinline__ void stage_commit(u8 *buf, const Stage &st, int nh)
+// the even bytes of a 16-B row chunk: its eight even/even lattice points
+__device__ __forceinline__ v2u even_bytes(v4u a)
+{
+    v2u r = {__builtin_amdgcn_perm(a.y, a.x, 0x06040200u), __builtin_amdgcn_perm(a.w, a.z, 0x06040200u)};
+    return r;
+}
+
+// LATTICE (encode): the half-resolution plane starts as a copy of the even/even pixels -- originals, i.e.
+// the reconstruction of the base lattice (src/encoder.rs:26-37), zeros beyond the image -- written from the
+// same registers.  Points of finer lattices hold originals until their level codes them; nothing reads
+// them earlier.
+template <bool LATTICE>
+__device__ __forceinline__ void stage_commit(u8 *buf, u8 *rbuf, const Stage &st, int nh)
 {
     const int lane = threadIdx.x, c = lane & (CH - 1), r = lane >> LCH;
 #pragma unroll
-    for (int j = 0; j < TH / 16; ++j) *reinterpret_cast<v4u *>(buf + (r + 8 * j) * S + 16 * c) = st.e[j];
-    if (lane < nh * CH) *reinterpret_cast<v4u *>(buf + (TH / 2 + r) * S + 16 * c) = st.hv;
+    for (int j = 0; j < TH / 16; ++j) {
+        *reinterpret_cast<v4u *>(buf + (r + 8 * j) * S + 16 * c) = st.e[j];
+        if (LATTICE) *reinterpret_cast<v2u *>(rbuf + (r + 8 * j) * S2 + 8 * c) = even_bytes(st.e[j]);
+    }
+    if (lane < nh * CH) {
+        *reinterpret_cast<v4u *>(buf + (TH / 2 + r) * S + 16 * c) = st.hv;
+        if (LATTICE) *reinterpret_cast<v2u *>(rbuf + (TH / 2 + r) * S2 + 8 * c) = even_bytes(st.hv);
+    }
     if (lane < TH / 2 + nh) {
         // transposed halo columns: slot {0..5} <- offsets {0, 4, 8, 16, 32, 64}, one byte per LDS row
-        u8 *h = buf + HCOL + lane;
-        h[0 * HP] = (u8)st.x0.x;
-        h[1 * HP] = (u8)st.x0.y;
-        h[2 * HP] = (u8)st.x0.z;
-        h[3 * HP] = (u8)st.d16;
-        h[4 * HP] = (u8)st.d32;
-        h[5 * HP] = (u8)st.d64;
+        const u32 v[HR] = {st.x0.x, st.x0.y, st.x0.z, st.d16, st.d32, st.d64};
+        u8 *h = buf + HCOL + lane, *h2 = rbuf + RCOL + lane;
+#pragma unroll
+        for (int i = 0; i < HR; ++i) {
+            h[i * HP] = (u8)v[i];
+            if (LATTICE) h2[i * HP2] = (u8)v[i];
+        }
+    }
+}
+
+// the same initialisation out of LDS, for tiles staged by stage_tile_generic
+__device__ __forceinline__ void lattice_from_buf(const u8 *buf, u8 *rbuf, int nh)
+{
+    for (int i = threadIdx.x; i < (TH / 2 + nh) * CH; i += NL) {
+        const int rr = i >> LCH, c = i & (CH - 1);
+        *reinterpret_cast<v2u *>(rbuf + rr * S2 + 8 * c) = even_bytes(*reinterpret_cast<const v4u *>(buf + rr * S + 16 * c));
+    }
+    for (int i = threadIdx.x; i < HR * (TH / 2 + nh); i += NL) {
+        const int hc = i / (TH / 2 + nh), rr = i - hc * (TH / 2 + nh);
+        rbuf[RCOL + hc * HP2 + rr] = buf[HCOL + hc * HP + rr];
     }
 }
 
@@ -1068,7 +1099,7 @@ __global__ __launch_bounds__(NL) __attribute__((amdgpu_waves_per_eu(HGI_DEC_WAVE
         SeedRegs seeds;
         stage_issue<false>(st, cur.b, cur.tl, (int)k, nh);
         if (SEEDED) seeds = seed_issue<false>(sd, cur.tl, k);
-        stage_commit(buf, st, nh);
+        stage_commit<false>(buf, nullptr, st, nh);
         LDS_ORDER();
         if (SEEDED) dec_seed_commit(buf, seeds, k);
         dec_tile_fast<INTERP>(buf, cur, st.o, k, W, H);
@@ -1083,7 +1114,7 @@ __global__ __launch_bounds__(NL) __attribute__((amdgpu_waves_per_eu(HGI_DEC_WAVE
     if (aligned & 2u) {   // aligned rows and 32-bit offsets: the buffer-load staging of the fast path
         Stage st;
         stage_issue<true>(st, make_buf(fr, out, W, H, tl), tl, (int)k, nh);
-        stage_commit(buf, st, nh);
+        stage_commit<false>(buf, nullptr, st, nh);
     } else {
         stage_tile_generic(buf, fr, W, H, tl, nh, (aligned & 1u) != 0);
     }
@@ -1098,33 +1129,17 @@ __global__ __launch_bounds__(NL) __attribute__((amdgpu_waves_per_eu(HGI_DEC_WAVE
 }
 
 // ---- encode ---------------------------------------------------------------------------------------
-// lattice points = 0 (mod 2^k): reconstruction == original (src/encoder.rs:26-37), or -- when this
-// launch is the lower part of a deeper pyramid -- the coarser pyramid's reconstruction, with its
-// residuals taking the place of the originals in the output.
+// lattice points = 0 (mod 2^k): reconstruction == original (src/encoder.rs:26-37) -- which is what staging
+// left in rbuf -- or, when this launch is the lower part of a deeper pyramid, the coarser pyramid's
+// reconstruction, with its residuals taking the place of the originals in the output.
 template <bool SEEDED>
 __device__ __forceinline__ void enc_seed_commit(u8 *buf, u8 *rbuf, const SeedRegs &r, u32 k)
 {
-    if (SEEDED) {
-        if (r.on) {
-            buf[laddr(r.bx << k, r.by << k)] = (u8)r.q;
-            rbuf[laddr2(r.bx << k, r.by << k)] = (u8)r.rec;
-        }
-    } else {
-        const int ext = k >= 2 ? 2 : 1;
-        const int nbx = (TW >> k) + ext, nby = (TH >> k) + ext;
-        for (int i = threadIdx.x; i < nbx * nby; i += NL) {
-            int by = i / nbx, bx = i - by * nbx;
-            rbuf[laddr2(bx << k, by << k)] = buf[laddr(bx << k, by << k)];
-        }
+    if (SEEDED && r.on) {
+        buf[laddr(r.bx << k, r.by << k)] = (u8)r.q;
+        rbuf[laddr2(r.bx << k, r.by << k)] = (u8)r.rec;
     }
     LDS_ORDER();
-}
-
-// lattice points outside the image must read as 0 (src/interpolator.rs:75-82) and are never written
-__device__ __forceinline__ void clear_lattice(u8 *rbuf, int nh)
-{
-    uint2 *base = reinterpret_cast<uint2 *>(rbuf + RCOL);
-    for (int i = threadIdx.x; i < rbuf_bytes(nh) / 8; i += NL) base[i] = make_uint2(0, 0);
 }
 
 template <int INTERP, bool IDENT>
@@ -1165,8 +1180,7 @@ __global__ __launch_bounds__(NL) __attribute__((amdgpu_waves_per_eu(IDENT ? HGI_
         SeedRegs seeds;
         stage_issue<false>(st, cur.b, cur.tl, (int)k, nh);
         if (SEEDED) seeds = seed_issue<true>(sd, cur.tl, k);
-        clear_lattice(rbuf, nh);
-        stage_commit(buf, st, nh);
+        stage_commit<true>(buf, rbuf, st, nh);
         LDS_ORDER();
         enc_seed_commit<SEEDED>(buf, rbuf, seeds, k);
         enc_tile_fast<INTERP, IDENT>(buf, rbuf, slut, cur, st.o, k, W, H);
@@ -1177,13 +1191,14 @@ __global__ __launch_bounds__(NL) __attribute__((amdgpu_waves_per_eu(IDENT ? HGI_
     u8 *out = dst + (size_t)tl.frame * f.frame_stride;
     SeedRegs seeds;
     if (SEEDED) seeds = seed_issue<true>(sd, tl, k);
-    clear_lattice(rbuf, nh);
     if (aligned & 2u) {
         Stage st;
         stage_issue<true>(st, make_buf(fr, out, W, H, tl), tl, (int)k, nh);
-        stage_commit(buf, st, nh);
+        stage_commit<true>(buf, rbuf, st, nh);
     } else {
         stage_tile_generic(buf, fr, W, H, tl, nh, (aligned & 1u) != 0);
+        LDS_ORDER();
+        lattice_from_buf(buf, rbuf, nh);
     }
     LDS_ORDER();
     enc_seed_commit<SEEDED>(buf, rbuf, seeds, k);

@@ -83,3 +83,47 @@ def test_two_rank_batch_matches_single_process(tmp_path, oracle):
         s, _, m = oracle.sq_error(img, oracle.decode(grid, 4))
         sq, mx, chk = sq + s, max(mx, m), chk + int(grid.astype(np.int64).sum())
     assert int(stats[:, 0].sum()) == sq and int(stats[:, 1].max()) == mx <= 20 and int(stats[:, 2].sum()) == chk
+
+
+def _scatter_worker(rank, world, port, F, w, h, out):
+    import torch
+    import torch.distributed as dist
+    from oracle import hgi_oracle as O
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        lut = O.linear_lut(O.MEDIUM)[0]
+        allf = allo = None
+        if rank == 0:      # every frame starts and ends on rank 0 (the labelled xGMI variant of bench.py)
+            allf = torch.from_numpy(np.stack([O.synth(O.SYNTH_RAMP, SEED0 + 3, f, w, h) for f in range(world * F)]))
+            allo = torch.zeros_like(allf)
+        mine = torch.zeros((F, h, w), dtype=torch.uint8)
+        batch.scatter_frames(dist, allf, mine)
+        coded = torch.from_numpy(np.stack([O.decode(O.encode(m.numpy(), 4, lut), 4) for m in mine]))
+        batch.gather_frames(dist, coded, allo)
+        if rank == 0:
+            np.save(out, allo.numpy())
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_scatter_code_gather_two_ranks(tmp_path, oracle):
+    """frames scattered from rank 0, coded where they land, gathered back in rank-major order"""
+    import torch
+    import torch.multiprocessing as mp
+    F, w, h, world = 2, 96, 64, 2
+    out = str(tmp_path / "gathered.npy")
+    mp.spawn(_scatter_worker, args=(world, _free_port(), F, w, h, out), nprocs=world, join=True)
+    got = np.load(out)
+    lut = oracle.linear_lut(oracle.MEDIUM)[0]
+    for f in range(world * F):
+        img = oracle.synth(oracle.SYNTH_RAMP, SEED0 + 3, f, w, h)
+        assert np.array_equal(got[f], oracle.decode(oracle.encode(img, 4, lut), 4)), f
+    # single process: plain copies
+    a = torch.arange(24, dtype=torch.uint8).reshape(2, 3, 4)
+    b, c = torch.zeros_like(a), torch.zeros_like(a)
+    batch.scatter_frames(None, a, b)
+    batch.gather_frames(None, b, c)
+    assert torch.equal(a, c)

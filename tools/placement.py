@@ -1,7 +1,7 @@
 """Does the decode/encode time depend on where the buffers sit?  Times the C3 shard (64 x 4096^2, L4, Medium)
 for several relative placements of input and output inside one big allocation, in one process."""
 import sys, torch
-sys.path.insert(0, '.')
+sys.path.insert(0, __import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.abspath(__file__))))
 import rustyhgi_amd as H
 from rustyhgi_amd import _ffi
 L = _ffi.lib()

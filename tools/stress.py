@@ -2,7 +2,7 @@
 oracle is described by its position inside the tile (library selectable with HGI_LIB_PATH).
 usage: stress.py [tile_h] [reps] [frames] [levels] [q]"""
 import sys, numpy as np, torch
-sys.path.insert(0, '.')
+sys.path.insert(0, __import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.abspath(__file__))))
 from oracle import hgi_oracle as O
 import rustyhgi_amd as H
 from rustyhgi_amd import _ffi
