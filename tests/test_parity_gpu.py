@@ -400,3 +400,66 @@ def test_extreme_shapes_and_levels(ctxs, oracle, w, h, levels):
         want = oracle.encode(img, levels, lut)
         assert_same(gpu_encode(ctxs["fused"], img, levels, lut), want, "encode %dx%d L%d q%d" % (w, h, levels, q))
         assert_same(gpu_decode(ctxs["fused"], want, levels), oracle.decode(want, levels), "decode %dx%d L%d q%d" % (w, h, levels, q))
+
+
+def test_fuzz_batches_against_oracle(H, ctxs, oracle):
+    """Seeded fuzz through the device-pointer batch entry points: 150 random (batch, width, height, levels, table,
+    interpolator, frame padding, pointer shift) cases, widths biased to multiples of 16 / 128 and their neighbours
+    so that interior, ragged and fully checked tiles all occur, every frame compared with the oracle in both
+    directions; the fused path and the level-wise path must also agree with each other."""
+    import torch
+    from rustyhgi_amd import _ffi
+    L = _ffi.lib()
+    fused, lw = ctxs["fused"], ctxs["levelwise"]
+    stream = torch.cuda.current_stream().cuda_stream
+    fused.set_stream(stream)
+    lw.set_stream(stream)
+    rng = np.random.default_rng(20261004)
+    tables = [oracle.noop_lut()] + [oracle.linear_lut(q)[0] for q in range(4)]
+    for case in range(150):
+        kind = rng.integers(0, 4)
+        if kind == 0:      # multiples of the tile
+            W, Hh = 128 * int(rng.integers(1, 6)), 64 * int(rng.integers(1, 5))
+        elif kind == 1:    # 16-B aligned rows, ragged tiles
+            W, Hh = 16 * int(rng.integers(1, 50)), int(rng.integers(1, 300))
+        elif kind == 2:    # one off a tile boundary
+            W, Hh = 128 * int(rng.integers(1, 5)) + int(rng.integers(-1, 2)), 64 * int(rng.integers(1, 4)) + int(rng.integers(-1, 2))
+        else:              # anything
+            W, Hh = int(rng.integers(1, 700)), int(rng.integers(1, 400))
+        B = int(rng.integers(1, 4))
+        levels = int(rng.choice([0, 1, 2, 3, 4, 4, 5, 6, 7, 9, 13]))
+        interp = int(rng.integers(0, 2))
+        lut = tables[int(rng.integers(0, 5))] if rng.integers(0, 3) else rng.integers(0, 256, 256, dtype=np.uint8)
+        pad = int(rng.choice([0, 0, 16, 48, 5, 4096]))
+        shift = int(rng.choice([0, 0, 0, 16, 1, 7]))
+        stride = Hh * W + pad
+        smooth = rng.integers(0, 2)
+        host = rng.integers(0, 256, (B, Hh, W), dtype=np.uint8)
+        if smooth:         # smooth + texture: small residuals, other table entries than noise exercises
+            yy, xx = np.mgrid[0:Hh, 0:W]
+            host = (((3 * xx + 5 * yy) // 16)[None] + (host & 15) + np.arange(B)[:, None, None]).astype(np.uint8)
+        total = shift + B * stride + 64
+        src = torch.zeros(total, dtype=torch.uint8, device="cuda")
+        dst = torch.full((total,), 0xEE, dtype=torch.uint8, device="cuda")
+        dst2 = torch.full((total,), 0xEE, dtype=torch.uint8, device="cuda")
+        out = torch.full((total,), 0xDD, dtype=torch.uint8, device="cuda")
+        for f in range(B):
+            src[shift + f * stride: shift + f * stride + Hh * W] = torch.from_numpy(host[f].reshape(-1)).cuda()
+        what = "case %d: B%d %dx%d L%d interp%d pad%d shift%d" % (case, B, W, Hh, levels, interp, pad, shift)
+        _ffi.check(L.hgi_encode_u8_dev(fused.handle, src.data_ptr() + shift, W, Hh, levels, interp, lut.ctypes.data,
+                                       dst.data_ptr() + shift, B, stride))
+        _ffi.check(L.hgi_encode_u8_dev(lw.handle, src.data_ptr() + shift, W, Hh, levels, interp, lut.ctypes.data,
+                                       dst2.data_ptr() + shift, B, stride))
+        _ffi.check(L.hgi_decode_u8_dev(fused.handle, dst.data_ptr() + shift, W, Hh, levels, interp, out.data_ptr() + shift, B, stride))
+        torch.cuda.synchronize()
+        assert torch.equal(dst, dst2), what + ": fused and level-wise grids differ"
+        d, o = dst.cpu().numpy(), out.cpu().numpy()
+        for f in range(B):
+            want = oracle.encode(host[f], levels, lut, interp)
+            a = shift + f * stride
+            assert_same(d[a:a + Hh * W].reshape(Hh, W), want, what + " encode frame %d" % f)
+            assert_same(o[a:a + Hh * W].reshape(Hh, W), oracle.decode(want, levels, interp), what + " decode frame %d" % f)
+            assert (d[a + Hh * W:a + stride] == 0xEE).all() and (o[a + Hh * W:a + stride] == 0xDD).all(), what + ": padding written"
+        assert (d[:shift] == 0xEE).all() and (o[:shift] == 0xDD).all(), what + ": bytes before the batch written"
+    fused.use_own_stream()
+    lw.use_own_stream()
