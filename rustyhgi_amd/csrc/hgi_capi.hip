@@ -105,6 +105,38 @@ size_t ws_need(const hgi_ctx *c, uint32_t w, uint32_t h, uint32_t levels, size_t
     return need;
 }
 
+// Tile geometry of a fused launch.  128 x 64 tiles are the throughput shape; a call whose 64-row tiles would not
+// fill the GPU (256 CUs x 20-32 resident waves) finishes sooner with 128 x 32 tiles -- four times the waves, half
+// the dependent chain per wave.  Measured crossover on MI355X at level 4 (tools/size_sweep.py): equal at ~2000
+// tiles; 32-row ahead by 15-35 % below ~1200, 64-row ahead by 12 % at 4000.  HGI_TILE_H=32|64 in the environment
+// forces one (experiments only).
+bool use_small_tiles(uint32_t w, uint32_t h, uint32_t k, size_t batch)
+{
+    static const int forced = [] {
+        const char *e = getenv("HGI_TILE_H");
+        return e ? atoi(e) : 0;
+    }();
+    if (k > (uint32_t)kFusedMaxLevelsSmall) return false;
+    if (forced == 32) return true;
+    if (forced == 64) return false;
+    const uint64_t tiles64 = (uint64_t)((w + kTileW - 1) / kTileW) * ((h + 63) / 64) * batch;
+    return tiles64 < 1536;
+}
+
+hipError_t launch_encode_fused(const uint8_t *img, uint8_t *grid, const Frames &f, uint32_t k, int interp,
+                               const Lut256 &lut, bool ident, const Seeds *seeds, hipStream_t s)
+{
+    return use_small_tiles(f.width, f.height, k, f.batch) ? launch_encode_fused_32(img, grid, f, k, interp, lut, ident, seeds, s)
+                                                          : launch_encode_fused_64(img, grid, f, k, interp, lut, ident, seeds, s);
+}
+
+hipError_t launch_decode_fused(const uint8_t *grid, uint8_t *img, const Frames &f, uint32_t k, int interp,
+                               const Seeds *seeds, hipStream_t s)
+{
+    return use_small_tiles(f.width, f.height, k, f.batch) ? launch_decode_fused_32(grid, img, f, k, interp, seeds, s)
+                                                          : launch_decode_fused_64(grid, img, f, k, interp, seeds, s);
+}
+
 Lut256 pack_lut(const uint8_t lut[256])
 {
     Lut256 l;

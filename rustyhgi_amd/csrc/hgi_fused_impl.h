@@ -33,12 +33,19 @@ namespace {
 
 using namespace dev;
 
+#ifndef HGI_TILE_H
+#define HGI_TILE_H 64
+#endif
+#define HGI_CAT2(a, b) a##_##b
+#define HGI_CAT(a, b) HGI_CAT2(a, b)
+#define HGI_TILED(name) HGI_CAT(name, HGI_TILE_H)   // launch_decode_fused -> launch_decode_fused_64
 constexpr int TW = kTileW;
-constexpr int TH = kTileH;
+constexpr int TH = HGI_TILE_H;
+constexpr int MAXK = TH == 64 ? kFusedMaxLevels : kFusedMaxLevelsSmall;   // deepest pyramid one tile holds
 constexpr int NL = kThreads;       // lanes
 constexpr int CH = TW / 16;        // 16-B chunks per tile row
 constexpr int LCH = 3;             // log2(CH)
-constexpr int HR = 6;   // halo rows / columns a tile can need (offsets 0,4,8,16,32,64); >= kFusedMaxLevels
+constexpr int HR = 6;   // halo rows / columns a tile can need (offsets 0,4,8,16,32,64); >= MAXK
 // LDS layout (bank-conflict model and measurements: DESIGN.md "LDS layout").  LDS is dynamic: a tile
 // that needs nh halo rows allocates TH / 2 + nh rows, which is what sets the waves per CU.
 //   ODD image rows never enter LDS: every level but the finest touches even coordinates only, and the
@@ -66,7 +73,7 @@ constexpr int RCOL = -(HR * HP2);
 __host__ __device__ constexpr int buf_bytes(int nh) { return HR * HP + (TH / 2 + nh) * S; }
 __host__ __device__ constexpr int rbuf_bytes(int nh) { return HR * HP2 + (TH / 2 + nh) * S2; }
 
-static_assert(NL == 64 && CH == (1 << LCH) && (TH & (TH - 1)) == 0 && (1 << kFusedMaxLevels) <= TH, "tile geometry");
+static_assert(NL == 64 && CH == (1 << LCH) && (TH & (TH - 1)) == 0 && (TH == 64 || TH == 32) && (1 << MAXK) <= TH, "tile geometry");
 // 16-B accesses on the full-resolution rows, 8-B accesses on the half-resolution rows
 static_assert(S % 16 == 0 && (HR * HP) % 16 == 0 && S2 % 8 == 0 && (HR * HP2) % 16 == 0 && HP >= TH / 2 + HR &&
                   HP2 >= TH / 2 + HR && buf_bytes(1) % 16 == 0 && rbuf_bytes(1) % 8 == 0,
@@ -1083,7 +1090,7 @@ __device__ __forceinline__ BlockRole block_role(const TileGrid &g)
 #ifndef HGI_DEC_WAVES_PER_EU
 #define HGI_DEC_WAVES_PER_EU 8
 #endif
-template <int INTERP, bool SEEDED>
+template <int INTERP, bool SEEDED, int TILE_ROWS>   // TILE_ROWS == TH: only there to name the build in profiles
 __global__ __launch_bounds__(NL) __attribute__((amdgpu_waves_per_eu(HGI_DEC_WAVES_PER_EU))) void k_dec_tiles(const u8 *__restrict__ src, u8 *__restrict__ dst, Frames f, u32 k,
                                                   Seeds sd, TileGrid g, u32 aligned)
 {
@@ -1161,7 +1168,7 @@ __device__ __forceinline__ void enc_tile_fast(u8 *buf, u8 *rbuf, const u8 *slut,
 #ifndef HGI_ENC_WAVES_PER_EU
 #define HGI_ENC_WAVES_PER_EU 5
 #endif
-template <int INTERP, bool IDENT, bool SEEDED>
+template <int INTERP, bool IDENT, bool SEEDED, int TILE_ROWS>
 __global__ __launch_bounds__(NL) __attribute__((amdgpu_waves_per_eu(IDENT ? HGI_ENC_WAVES_PER_EU - 1 : HGI_ENC_WAVES_PER_EU))) void k_enc_tiles(const u8 *__restrict__ src, u8 *__restrict__ dst, Frames f, u32 k,
                                                   Lut256 lut, Seeds sd, TileGrid g, u32 aligned)
 {
@@ -1242,18 +1249,18 @@ FusedGeom fused_geom(const void *a, const void *b, const Frames &f)
 }  // namespace
 
 #ifdef HGI_FUSED_DECODE
-hipError_t launch_decode_fused(const uint8_t *grid, uint8_t *img, const Frames &f, uint32_t k, int interp,
-                               const Seeds *seeds, hipStream_t s)
+hipError_t HGI_TILED(launch_decode_fused)(const uint8_t *grid, uint8_t *img, const Frames &f, uint32_t k, int interp,
+                                          const Seeds *seeds, hipStream_t s)
 {
     FusedGeom r = fused_geom(grid, img, f);
-    if (!r.ok || k < 1 || k > (u32)kFusedMaxLevels) return hipErrorInvalidValue;
+    if (!r.ok || k < 1 || k > (u32)MAXK) return hipErrorInvalidValue;
     const TileGrid &g = r.g;
     Seeds sd = seeds ? *seeds : Seeds{nullptr, nullptr, 0, 0, 0};
     const dim3 b(NL);
     const int nh = k >= 2 ? (int)k : 1;
     const size_t lds = (size_t)buf_bytes(nh);
     const dim3 blocks(((g.nedge + 7u) & ~7u) + g.nfast);
-#define HGI_DEC(I, SE) hipLaunchKernelGGL((k_dec_tiles<I, SE>), blocks, b, lds, s, grid, img, f, k, sd, g, r.aligned)
+#define HGI_DEC(I, SE) hipLaunchKernelGGL((k_dec_tiles<I, SE, TH>), blocks, b, lds, s, grid, img, f, k, sd, g, r.aligned)
     if (interp == kInterpCrossed) {
         if (seeds) HGI_DEC(kInterpCrossed, true); else HGI_DEC(kInterpCrossed, false);
     } else {
@@ -1266,11 +1273,11 @@ hipError_t launch_decode_fused(const uint8_t *grid, uint8_t *img, const Frames &
 #endif  // HGI_FUSED_DECODE
 
 #ifdef HGI_FUSED_ENCODE
-hipError_t launch_encode_fused(const uint8_t *img, uint8_t *grid, const Frames &f, uint32_t k, int interp,
-                               const Lut256 &lut, bool ident, const Seeds *seeds, hipStream_t s)
+hipError_t HGI_TILED(launch_encode_fused)(const uint8_t *img, uint8_t *grid, const Frames &f, uint32_t k, int interp,
+                                          const Lut256 &lut, bool ident, const Seeds *seeds, hipStream_t s)
 {
     FusedGeom r = fused_geom(img, grid, f);
-    if (!r.ok || k < 1 || k > (u32)kFusedMaxLevels) return hipErrorInvalidValue;
+    if (!r.ok || k < 1 || k > (u32)MAXK) return hipErrorInvalidValue;
     const TileGrid &g = r.g;
     Seeds sd = seeds ? *seeds : Seeds{nullptr, nullptr, 0, 0, 0};
     const dim3 b(NL);
@@ -1278,7 +1285,7 @@ hipError_t launch_encode_fused(const uint8_t *img, uint8_t *grid, const Frames &
     const size_t lds = (size_t)buf_bytes(nh) + rbuf_bytes(nh) + 256;
     const dim3 blocks(((g.nedge + 7u) & ~7u) + g.nfast);
 #define HGI_ENC(I, ID, SE) \
-    hipLaunchKernelGGL((k_enc_tiles<I, ID, SE>), blocks, b, lds, s, img, grid, f, k, lut, sd, g, r.aligned)
+    hipLaunchKernelGGL((k_enc_tiles<I, ID, SE, TH>), blocks, b, lds, s, img, grid, f, k, lut, sd, g, r.aligned)
 #define HGI_ENC_I(I)                                                          \
     do {                                                                      \
         if (ident) { if (seeds) HGI_ENC(I, true, true); else HGI_ENC(I, true, false); } \

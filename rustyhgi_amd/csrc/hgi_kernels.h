@@ -9,13 +9,12 @@ namespace hgi {
 constexpr int kInterpLeftTop = 0;
 constexpr int kInterpCrossed = 1;
 
-// Fused tile geometry (see DESIGN.md "Kernels").
-#ifndef HGI_TILE_H
-#define HGI_TILE_H 64         // tile rows (experiments: 32)
-#endif
+// Fused tile geometry (see DESIGN.md "Kernels").  Two builds of the same source live in the library:
+// 128 x 64 tiles (throughput: batches, large frames) and 128 x 32 tiles (latency: four times the waves and
+// half the chain per wave when a call has too few tiles to fill the GPU).  hgi_capi.hip picks per call.
 constexpr int kTileW = 128;   // pixels per tile row: 8 lanes x 16 B = one 128-B line
-constexpr int kTileH = HGI_TILE_H;
-constexpr int kFusedMaxLevels = HGI_TILE_H == 64 ? 6 : 5;  // 2^k <= kTileH: deepest pyramid one tile can hold
+constexpr int kFusedMaxLevels = 6;        // 2^k <= 64: deepest pyramid a 64-row tile can hold
+constexpr int kFusedMaxLevelsSmall = 5;   // ... and a 32-row tile
 constexpr int kThreads = 64;  // ONE wave owns a tile: no workgroup barriers anywhere
 
 // 256-entry quantizer table passed BY VALUE in the kernarg segment: no device-side table to
@@ -48,11 +47,15 @@ hipError_t launch_encode_level(uint8_t *rec, uint8_t *grid, const Frames &f, uin
                                int interp, const Lut256 &lut, hipStream_t s);
 
 // ---- fused path: the last k <= kFusedMaxLevels levels of every tile in one launch ------------
-hipError_t launch_decode_fused(const uint8_t *grid, uint8_t *img, const Frames &f, uint32_t k,
-                               int interp, const Seeds *seeds, hipStream_t s);
-hipError_t launch_encode_fused(const uint8_t *img, uint8_t *grid, const Frames &f, uint32_t k,
-                               int interp, const Lut256 &lut, bool lut_is_identity,
-                               const Seeds *seeds, hipStream_t s);
+// (_64 / _32 = tile rows; k <= kFusedMaxLevels resp. kFusedMaxLevelsSmall)
+#define HGI_DECLARE_FUSED(TH)                                                                                      \
+    hipError_t launch_decode_fused_##TH(const uint8_t *grid, uint8_t *img, const Frames &f, uint32_t k, int interp, \
+                                        const Seeds *seeds, hipStream_t s);                                        \
+    hipError_t launch_encode_fused_##TH(const uint8_t *img, uint8_t *grid, const Frames &f, uint32_t k, int interp, \
+                                        const Lut256 &lut, bool lut_is_identity, const Seeds *seeds, hipStream_t s);
+HGI_DECLARE_FUSED(64)
+HGI_DECLARE_FUSED(32)
+#undef HGI_DECLARE_FUSED
 
 // dst[f][j][i] = src[f][j << k][i << k]  (the stride-2^k lattice as a dense plane)
 hipError_t launch_gather_lattice(const uint8_t *src, const Frames &f, uint32_t k, uint8_t *dst,

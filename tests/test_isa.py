@@ -33,9 +33,8 @@ def test_fused_kernels_isa_is_hazard_free(tmp_path):
         assert r["scratch_bytes"] == 0 and r["vgpr_spills"] == 0, (tu, r)
         assert r["store_data_overwritten"] == 0, (tu, "data VGPR of a wide store redefined too early", r)
         assert r["dpp"] == 0, (tu, "DPP next to opaque SDWA asm is not allowed", r)
-    # same rules on other schedules of the same source, and on the level-wise / harness kernels
-    for tu, extra in (("hgi_fused_dec.hip", ["-DHGI_TILE_H=32"]), ("hgi_fused_enc.hip", ["-DHGI_TILE_H=32"]),
-                      ("hgi_kernels.hip", [])):
+    # the 128 x 32 tile build that ships next to it (a second schedule of the same source), and the level-wise kernels
+    for tu, extra in (("hgi_fused_dec32.hip", []), ("hgi_fused_enc32.hip", []), ("hgi_kernels.hip", [])):
         out = str(tmp_path / (tu + ".alt.s"))
         subprocess.check_call([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "--cuda-device-only", "-S"] + extra +
                               [os.path.join(ROOT, "rustyhgi_amd", "csrc", tu), "-o", out], stderr=subprocess.DEVNULL)
