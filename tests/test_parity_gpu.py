@@ -463,3 +463,41 @@ def test_fuzz_batches_against_oracle(H, ctxs, oracle):
         assert (d[:shift] == 0xEE).all() and (o[:shift] == 0xDD).all(), what + ": bytes before the batch written"
     fused.use_own_stream()
     lw.use_own_stream()
+
+
+def test_hip_graph_capture_and_replay(H, ctxs, oracle):
+    """The device entry points only enqueue work on the ctx stream (table by value in the kernarg, scratch reserved
+    up front with hgi_ctx_reserve), so an encode + decode pair -- including a deep pyramid, whose lattice recursion
+    is several launches -- can be captured into a HIP graph once and replayed on new pixels."""
+    import torch
+    from rustyhgi_amd import _ffi
+    L = _ffi.lib()
+    ctx = H.Context(0)
+    side = torch.cuda.Stream()
+    for (B, W, Hh, levels) in [(3, 640, 384, 4), (2, 1024, 512, 8)]:
+        lut = oracle.linear_lut(2)[0]
+        n = W * Hh
+        src = torch.zeros((B, Hh, W), dtype=torch.uint8, device="cuda")
+        grid = torch.zeros_like(src)
+        out = torch.zeros_like(src)
+        _ffi.check(L.hgi_ctx_reserve(ctx.handle, W, Hh, levels, B))
+        with torch.cuda.stream(side):
+            ctx.set_stream(side.cuda_stream)
+            g = torch.cuda.CUDAGraph()
+            torch.cuda.synchronize()
+            with torch.cuda.graph(g, stream=side):
+                _ffi.check(L.hgi_encode_u8_dev(ctx.handle, src.data_ptr(), W, Hh, levels, 1, lut.ctypes.data, grid.data_ptr(), B, n))
+                _ffi.check(L.hgi_decode_u8_dev(ctx.handle, grid.data_ptr(), W, Hh, levels, 1, out.data_ptr(), B, n))
+        rng = np.random.default_rng(levels)
+        for rep in range(3):       # new pixels in the captured buffers, then replay
+            host = rng.integers(0, 256, (B, Hh, W), dtype=np.uint8)
+            src.copy_(torch.from_numpy(host).cuda())
+            torch.cuda.synchronize()
+            g.replay()
+            torch.cuda.synchronize()
+            gd, od = grid.cpu().numpy(), out.cpu().numpy()
+            for f in range(B):
+                want = oracle.encode(host[f], levels, lut)
+                assert_same(gd[f], want, "graph replay %d encode frame %d L%d" % (rep, f, levels))
+                assert_same(od[f], oracle.decode(want, levels), "graph replay %d decode frame %d L%d" % (rep, f, levels))
+    ctx.close()
