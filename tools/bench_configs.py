@@ -32,6 +32,15 @@ def gpu_time(fn, reps):
     return e0.elapsed_time(e1) / reps * 1e3   # us
 
 
+def graph_time(fn, reps, stream):
+    """the same call captured once into a HIP graph and replayed: what a caller with a fixed shape pays per call"""
+    g = torch.cuda.CUDAGraph()
+    torch.cuda.synchronize()
+    with torch.cuda.graph(g, stream=stream):
+        fn()
+    return gpu_time(g.replay, reps)
+
+
 def main():
     dev = torch.device("cuda", 0)
     stream = torch.cuda.Stream(dev)
@@ -49,8 +58,8 @@ def main():
         ("C3 ramp(3) 64x4096x4096 L4 Medium (one GPU's shard)", None, 4, QuantizationLevel.Medium, 20),
         ("C4 ramp(4) 16384x16384 L8 High", O.synth(O.SYNTH_RAMP, SEED0 + 4, 0, 16384, 16384)[None], 8, QuantizationLevel.High, 20),
     ]
-    print("| config | frames x WxH | GPU encode us | GPU decode us | GPU enc+dec Mpx/s | algorithmic GB/s (enc / dec) | oracle 1 thread Mpx/s | bit-exact vs oracle |")
-    print("|---|---|---|---|---|---|---|---|")
+    print("| config | frames x WxH | GPU encode us | GPU decode us | as HIP graph (enc / dec us) | GPU enc+dec Mpx/s | algorithmic GB/s (enc / dec) | oracle 1 thread Mpx/s | bit-exact vs oracle |")
+    print("|---|---|---|---|---|---|---|---|---|")
     for name, host, levels, level, reps in cases:
         q = Linear.from_level(level)
         if host is None:
@@ -68,14 +77,16 @@ def main():
         grids, outs = torch.empty_like(imgs), torch.empty_like(imgs)
         te = gpu_time(lambda: enc.encode_batch(imgs, out=grids), reps)
         td = gpu_time(lambda: dec.decode_batch(grids, levels, out=outs), reps)
+        ge = graph_time(lambda: enc.encode_batch(imgs, out=grids), reps, stream)
+        gd = graph_time(lambda: dec.decode_batch(grids, levels, out=outs), reps, stream)
         t0 = time.perf_counter()
         want = O.encode(host_check[0], levels, q.table())
         wdec = O.decode(want, levels)
         tcpu = time.perf_counter() - t0
         ok = bool((grids[0].cpu().numpy() == want).all() and (outs[0].cpu().numpy() == wdec).all())
         px = F * Hh * W
-        print("| %s | %d x %dx%d | %.1f | %.1f | %.0f | %.0f / %.0f | %.1f | %s |" % (
-            name, F, W, Hh, te, td, px / (te + td), 2 * px / te / 1e3, 2 * px / td / 1e3, Hh * W / tcpu / 1e6,
+        print("| %s | %d x %dx%d | %.1f | %.1f | %.1f / %.1f | %.0f | %.0f / %.0f | %.1f | %s |" % (
+            name, F, W, Hh, te, td, ge, gd, px / (te + td), 2 * px / te / 1e3, 2 * px / td / 1e3, Hh * W / tcpu / 1e6,
             "yes" if ok else "NO"))
         del imgs, grids, outs
     ctx.close()
