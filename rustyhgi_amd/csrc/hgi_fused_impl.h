@@ -1,29 +1,31 @@
 // gfx950 (MI355X / CDNA4) fused HGI kernels: all levels of a tile in one launch, LDS-resident.
 //
-// This is the implementation, included by hgi_fused_dec.hip and hgi_fused_enc.hip: the two directions
-// are separate translation units because they want different LDS layouts (HGI_S_PAD / HGI_S2_PAD below):
-// decode is at the HBM floor and prefers padded rows (fewer bank conflicts), encode is bound by LDS
-// latency chains and prefers the extra wave per CU that unpadded rows buy.
+// This is the implementation.  It is compiled four times -- per direction (hgi_fused_dec.hip / hgi_fused_enc.hip:
+// the directions want different LDS pitches and register budgets) and per tile height (128 x 64 tiles for
+// throughput, 128 x 32 tiles for calls too small to fill the GPU; hgi_fused_*32.hip) -- and hgi_capi.hip picks the
+// build per launch.
 //
 // Reference algorithm (paths relative to pl0q1n/RustyHGI):
 //   src/encoder.rs:39-71, src/decoder.rs:18-46, src/interpolator.rs:15-28 / :41-90, src/utils.rs:12-41
 //
 // Work decomposition
-//   * ONE WAVE (64 lanes) owns one 128x64 tile.  A tile row is one 128-B line = 8 lanes x 16 B, so a
-//     wave-wide load/store instruction moves 8 full lines.  No workgroup barrier exists anywhere: all
-//     cross-lane traffic goes through the wave's own LDS slice, ordered by the wave's in-order LDS
-//     queue; the other waves of the CU (other tiles, other phases) hide the latency.
-//   * The tile plus a sparse one-sided halo (offsets {0,4,8,...,2^k} to the right and below,
-//     SURVEY.md A.6) is staged in LDS once; halo pixels are recomputed bit-identically instead of
-//     exchanged.  Every image byte is fetched from HBM once and every output byte written once.
+//   * ONE WAVE (64 lanes) owns one tile.  A tile row is one 128-B line = 8 lanes x 16 B, so a wave-wide
+//     load/store instruction moves 8 full lines.  No workgroup barrier exists anywhere: all cross-lane traffic
+//     goes through the wave's own LDS slice, ordered by the wave's in-order LDS queue; the other waves of the
+//     CU (other tiles, other phases) hide the latency.
+//   * The tile plus a sparse one-sided halo (offsets {0,4,8,...,2^k} to the right and below) is
+//     loaded once; halo pixels are recomputed bit-identically instead of exchanged.  Every image byte is
+//     fetched from HBM once and every output byte written once.
+//   * Only the EVEN rows go to LDS.  Every level but the finest touches even coordinates only; the finest
+//     level reads each odd row once, in the lane that loaded it, so odd rows stay in registers.
 //   * Levels sub >= 4 (6 % of the pixels): one lane per step-cell, byte LDS accesses.
 //     Level sub == 2 (19 %): four cells per lane, packed v_lerp_u8 predictor, 16-B LDS accesses.
-//     Level sub == 1 (75 %): 16 px x 2 rows per lane from LDS through packed-u8 VALU arithmetic
-//     straight to 16-B buffer stores.
-//   * Interior tiles (tile body inside the image) take a check-free kernel built on buffer loads whose
-//     hardware range check returns 0 beyond the frame -- exactly the reference's out-of-image rule
-//     (src/interpolator.rs:75-82).  Ragged tiles and unaligned widths go to a separate, fully checked
-//     per-tile kernel (k_*_edge) launched next to it.
+//     Level sub == 1 (75 %): 16 px x 2 rows per lane through packed-u8 / SDWA arithmetic straight to 16-B
+//     buffer stores.
+//   * Interior tiles (tile body inside the image) take a check-free path built on buffer loads whose hardware
+//     range check returns 0 beyond the frame -- exactly the reference's out-of-image rule
+//     (src/interpolator.rs:75-82).  Ragged tiles and unaligned widths take a fully checked path in the SAME
+//     launch (their blocks come first).
 //
 // All arithmetic is u8/integer; there is no MFMA-shaped work on this path.
 #include "hgi_dev.h"
@@ -454,11 +456,11 @@ __device__ __forceinline__ void enc_fine_generic(const u8 *buf, const u8 *rbuf, 
 // ---------------------------------------------------------------------------------------------
 // encode, coarse levels, split-phase: one LDS dependency chain per level
 // ---------------------------------------------------------------------------------------------
-// At 12 waves per CU a dependent LDS round trip costs a few hundred cycles, and a level used to be
-// two or three of them back to back (cells, second half of the cells, halo cells).  Within a level
-// nothing depends on anything of that level, so all the reads of a level are issued first
-// (unconditionally: an idle lane reads offset 0), then the predictions, then all table look-ups, and
-// only the writes are conditional.
+// A dependent LDS round trip costs a few hundred cycles when the CU is busy.  Within a level nothing
+// depends on anything of that level, so a pass issues all its reads first (unconditionally: an idle lane
+// reads offset 0), then the predictions, then all table look-ups, and only the writes are conditional.
+// How many cells a pass keeps in flight per lane is a register-budget decision (the kernel is held to
+// 96 VGPRs = 5 waves per SIMD): two body cells at sub == 4, the halo cells in passes of their own.
 struct CellAddr {
     int lt, rt, lb, rb;      // corners, half-resolution reconstruction plane
     int nx, ny, nxy;         // new pixels (x0+s, y0), (x0, y0+s), (x0+s, y0+s), full-resolution plane
@@ -628,7 +630,7 @@ __device__ __forceinline__ void stage_issue(Stage &st, const Buf &b, Tile tl, in
     const u32 W = __builtin_amdgcn_readfirstlane(b.W);   // soffset operands must be provably uniform
     const u32 voff = b.base + 2 * r * W + 16 * c;                       // even rows 2 * (r + 8 j)
     const u32 vodd = b.base + (2 * fine_pair0() + 1) * W + 16 * c;      // odd rows 2 * (pair0 + 8 it) + 1
-    // Interior tiles: every chunk is inside the image.  Ragged tiles (edge kernels): rows below the
+    // Interior tiles: every chunk is inside the image.  Ragged tiles (checked path): rows below the
     // image come back as 0 from the range check (the row offsets go through voffset there, which is
     // what the check sees), chunks right of it are masked.
     const bool cin = tl.X0 + 16 * c < W;
@@ -962,10 +964,10 @@ __device__ __forceinline__ Buf make_buf(const u8 *fr, u8 *out, u32 W, u32 H, Til
 // kernels
 // ---------------------------------------------------------------------------------------------
 // Tile lists.  `full_x` x `full_y` tiles per frame lie entirely inside the image: the fast kernels walk
-// those; the edge kernels take the rest (right column first, then the bottom rows).
+// those; the checked path takes the rest (right column first, then the bottom rows).
 struct TileGrid {
     u32 tiles_x, tiles_y;   // all tiles of a frame
-    u32 full_x, full_y;     // tiles whose 128x64 body is inside the image (0 x 0 when the fast path is off)
+    u32 full_x, full_y;     // tiles whose body is inside the image (0 x 0 when the fast path is off)
     u32 nfast, nedge;       // totals over the batch
 };
 
