@@ -622,8 +622,9 @@ struct Stage {
 
 // Rows below the image return 0 from the buffer range check; columns right of the image are masked
 // with wave-uniform tests.
-// RAGGED tiles finish in the generic fine level, which fetches its odd rows itself.
-template <bool RAGGED>
+// RAGGED tiles that finish in the generic fine level fetch their odd rows there; bottom-ragged tiles
+// (ODD_CHECKED) keep the fast fine level and load them here, row offsets in voffset like the even rows.
+template <bool RAGGED, bool ODD_CHECKED = false>
 __device__ __forceinline__ void stage_issue(Stage &st, const Buf &b, Tile tl, int k, int nh)
 {
     const int lane = threadIdx.x, c = lane & (CH - 1), r = lane >> LCH;
@@ -647,6 +648,7 @@ __device__ __forceinline__ void stage_issue(Stage &st, const Buf &b, Tile tl, in
     for (int j = 0; j < NFINE; ++j) {
         st.o[j] = v4u{0, 0, 0, 0};
         if (!RAGGED) st.o[j] = __builtin_amdgcn_raw_buffer_load_b128(b.rs, vodd, j * 16 * W, HGI_ODD_LOAD_AUX);
+        if (RAGGED && ODD_CHECKED && cin) st.o[j] = __builtin_amdgcn_raw_buffer_load_b128(b.rs, vodd + j * 16 * W, 0, HGI_ODD_LOAD_AUX);
     }
     st.hv = v4u{0, 0, 0, 0};
     if (lane < nh * CH && cin) st.hv = __builtin_amdgcn_raw_buffer_load_b128(b.rs, b.base + (TH + hoff(r)) * W + 16 * c, 0, 0);
@@ -718,9 +720,11 @@ __device__ __forceinline__ u32 gather_b0(v4u a)
     return __builtin_amdgcn_perm(a.y, a.x, 0x0c0c0400u) | __builtin_amdgcn_perm(a.w, a.z, 0x04000c0cu);
 }
 
-// level sub == 2 of the tile body: four 4x4 cells (16 px x rows y0, y0+2; corners also from y0+4) per lane
-template <int INTERP>
-__device__ __forceinline__ void dec_level2_fast(u8 *buf)
+// level sub == 2 of the tile body: four 4x4 cells (16 px x rows y0, y0+2; corners also from y0+4) per lane.
+// BOTTOM: the tile crosses the lower image edge after `rows` rows; rows beyond it were staged as zeros and must
+// stay zeros (they are the out-of-image corners of the rows above, src/interpolator.rs:75-82).
+template <int INTERP, bool BOTTOM = false>
+__device__ __forceinline__ void dec_level2_fast(u8 *buf, int rows = TH)
 {
 #pragma unroll
     for (int it = 0; it < (TH / 4) * CH / NL; ++it) {
@@ -745,8 +749,8 @@ __device__ __forceinline__ void dec_level2_fast(u8 *buf)
         HGI_ADDB(b0, 0, P, 0); HGI_ADDB(b1, 0, P, 1); HGI_ADDB(b2, 0, P, 2); HGI_ADDB(b3, 0, P, 3);
         HGI_ADDB(b0, 2, P, 0); HGI_ADDB(b1, 2, P, 1); HGI_ADDB(b2, 2, P, 2); HGI_ADDB(b3, 2, P, 3);
         v4u An = {a0, a1, a2, a3}, Bn = {b0, b1, b2, b3};
-        *reinterpret_cast<v4u *>(r0) = An;
-        *reinterpret_cast<v4u *>(r0 + S) = Bn;
+        if (!BOTTOM || 2 * z0 < rows) *reinterpret_cast<v4u *>(r0) = An;
+        if (!BOTTOM || 2 * z0 + 2 < rows) *reinterpret_cast<v4u *>(r0 + S) = Bn;
     }
 }
 
@@ -794,9 +798,10 @@ __device__ __forceinline__ void dec_fine_fast(const u8 *buf, const Buf &b, const
 
 // encode, level sub == 2 of the tile body: four cells per lane; corners from the half-resolution
 // reconstruction lattice (rbuf), originals in / residuals out in buf, new reconstructions into rbuf
-template <int INTERP, bool IDENT>
+template <int INTERP, bool IDENT, bool BOTTOM = false>
 __device__ __forceinline__ void enc_level2_fast(u8 *buf, u8 *rbuf, const u8 *slut, Tile tl, u32 W, u32 H)
 {
+    const int rows = BOTTOM ? (int)(H - tl.Y0) : TH;   // image rows of the tile (see dec_level2_fast)
     // One iteration (64 lanes x 4 cells) at a time, all its reads before its first write, and the level's
     // halo cells in a pass of their own afterwards: with the odd rows parked in registers the level is
     // the kernel's register high-water mark, and 96 VGPRs (5 waves per SIMD) beat the longer chains that
@@ -857,10 +862,14 @@ __device__ __forceinline__ void enc_level2_fast(u8 *buf, u8 *rbuf, const u8 *slu
             Q_REC(n1.y, 0, b2, 0, P, 2); Q_REC(n1.y, 1, b2, 2, P, 2); Q_REC(n1.y, 2, b3, 0, P, 3); Q_REC(n1.y, 3, b3, 2, P, 3);
         }
         v4u An = {a0, a1, a2, a3}, Bn = {b0, b1, b2, b3};
-        *reinterpret_cast<v4u *>(r0) = An;
-        *reinterpret_cast<v4u *>(r0 + S) = Bn;
-        *reinterpret_cast<v2u *>(q0) = n0;
-        *reinterpret_cast<v2u *>(q0 + S2) = n1;
+        if (!BOTTOM || 4 * g < rows) {
+            *reinterpret_cast<v4u *>(r0) = An;
+            *reinterpret_cast<v2u *>(q0) = n0;
+        }
+        if (!BOTTOM || 4 * g + 2 < rows) {
+            *reinterpret_cast<v4u *>(r0 + S) = Bn;
+            *reinterpret_cast<v2u *>(q0 + S2) = n1;
+        }
         __builtin_amdgcn_sched_barrier(0);   // keep the next iteration's reads behind this one's arithmetic
     }
     LDS_ORDER();
@@ -1009,6 +1018,14 @@ struct TileCtx {
     Buf b;
 };
 
+// see dec_tile_bottom: full tile width inside the image, lower edge crossed, buffer staging allowed, and an even
+// height, so that the last row pair is either entirely inside or entirely outside (the odd row's store carries its
+// row offset in soffset, which the range check does not see)
+__device__ __forceinline__ bool bottom_ragged(Tile tl, u32 W, u32 H, u32 aligned)
+{
+    return (aligned & 2u) && !(H & 1u) && tl.X0 + TW <= W && tl.Y0 + TH > H;
+}
+
 __device__ __forceinline__ TileCtx fast_ctx(u32 t, const u8 *src, u8 *dst, const Frames &f, const TileGrid &g)
 {
     TileCtx c;
@@ -1071,6 +1088,23 @@ __device__ __forceinline__ void dec_tile_fast(u8 *buf, const TileCtx &cur, const
     dec_fine_fast<INTERP>(buf, cur.b, odd);
 }
 
+// A tile whose body crosses only the LOWER image edge (full width inside, even height): the buffer range check
+// already zeroes its loads below the image and drops its stores there, so it keeps the fast staging and the fast
+// finest level; only the level passes in between must leave the out-of-image lattice rows untouched.
+template <int INTERP>
+__device__ __forceinline__ void dec_tile_bottom(u8 *buf, const TileCtx &cur, const v4u (&odd)[NFINE], u32 k, u32 W, u32 H)
+{
+    for (int s = 1 << (k - 1); s >= 2; s >>= 1) {
+        if (s == 2)
+            dec_level2_fast<INTERP, true>(buf, (int)(H - cur.tl.Y0));
+        else
+            dec_cells<INTERP, true>(buf, s, cur.tl, W, H);
+        dec_halo_cells<INTERP>(buf, s, cur.tl, W, H);
+        LDS_ORDER();
+    }
+    dec_fine_fast<INTERP>(buf, cur.b, odd);
+}
+
 // One block (= one wave) per tile, ONE launch per batch.  The first blocks take the ragged tiles
 // (their count padded to a multiple of 8 so that b % 8 keeps labelling the XCD), so the slow tiles
 // start first and overlap the interior ones; the interior tiles follow in XCD-contiguous order.
@@ -1124,6 +1158,16 @@ __global__ __launch_bounds__(NL) __attribute__((amdgpu_waves_per_eu(HGI_DEC_WAVE
     u8 *out = dst + (size_t)tl.frame * f.frame_stride;
     SeedRegs seeds;
     if (SEEDED) seeds = seed_issue<false>(sd, tl, k);
+    if (bottom_ragged(tl, W, H, aligned)) {
+        TileCtx cur = {tl, make_buf(fr, out, W, H, tl)};
+        Stage st;
+        stage_issue<true, true>(st, cur.b, tl, (int)k, nh);
+        stage_commit<false>(buf, nullptr, st, nh);
+        LDS_ORDER();
+        if (SEEDED) dec_seed_commit(buf, seeds, k);
+        dec_tile_bottom<INTERP>(buf, cur, st.o, k, W, H);
+        return;
+    }
     if (aligned & 2u) {   // aligned rows and 32-bit offsets: the buffer-load staging of the fast path
         Stage st;
         stage_issue<true>(st, make_buf(fr, out, W, H, tl), tl, (int)k, nh);
@@ -1153,6 +1197,22 @@ __device__ __forceinline__ void enc_seed_commit(u8 *buf, u8 *rbuf, const SeedReg
         rbuf[laddr2(r.bx << k, r.by << k)] = (u8)r.rec;
     }
     LDS_ORDER();
+}
+
+template <int INTERP, bool IDENT>
+__device__ __forceinline__ void enc_tile_bottom(u8 *buf, u8 *rbuf, const u8 *slut, const TileCtx &cur,
+                                                const v4u (&odd)[NFINE], u32 k, u32 W, u32 H)
+{
+    for (int s = 1 << (k - 1); s >= 2; s >>= 1) {
+        if (s == 2) {
+            enc_level2_fast<INTERP, IDENT, true>(buf, rbuf, slut, cur.tl, W, H);
+        } else {
+            enc_cells<INTERP, IDENT, true>(buf, rbuf, slut, s, cur.tl, W, H);
+            enc_halo_pass<INTERP, IDENT>(buf, rbuf, slut, s, cur.tl, W, H);
+        }
+        LDS_ORDER();
+    }
+    enc_fine_fast<INTERP, IDENT>(buf, rbuf, slut, cur.b, odd);
 }
 
 template <int INTERP, bool IDENT>
@@ -1204,6 +1264,16 @@ __global__ __launch_bounds__(NL) __attribute__((amdgpu_waves_per_eu(IDENT ? HGI_
     u8 *out = dst + (size_t)tl.frame * f.frame_stride;
     SeedRegs seeds;
     if (SEEDED) seeds = seed_issue<true>(sd, tl, k);
+    if (bottom_ragged(tl, W, H, aligned)) {
+        TileCtx cur = {tl, make_buf(fr, out, W, H, tl)};
+        Stage st;
+        stage_issue<true, true>(st, cur.b, tl, (int)k, nh);
+        stage_commit<true>(buf, rbuf, st, nh);
+        LDS_ORDER();
+        enc_seed_commit<SEEDED>(buf, rbuf, seeds, k);
+        enc_tile_bottom<INTERP, IDENT>(buf, rbuf, slut, cur, st.o, k, W, H);
+        return;
+    }
     if (aligned & 2u) {
         Stage st;
         stage_issue<true>(st, make_buf(fr, out, W, H, tl), tl, (int)k, nh);

@@ -1,5 +1,5 @@
 """Encode/decode latency over frame sizes and batch counts (Medium, Crossed), for choosing the tile geometry.
-Library selectable with HGI_LIB_PATH.  usage: size_sweep.py [levels]"""
+Library selectable with HGI_LIB_PATH.  usage: size_sweep.py [levels] [BxWxH ...]"""
 import os, sys, numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import rustyhgi_amd as H
@@ -16,7 +16,8 @@ def timed(fn, reps=30):
     for _ in range(reps): fn()
     b.record(); torch.cuda.synchronize()
     return a.elapsed_time(b) / reps * 1e3
-for (B, W, Hh) in [(1, 256, 256), (1, 512, 512), (1, 1024, 1024), (1, 1920, 1080), (1, 2048, 2048), (1, 2560, 1440), (1, 3072, 3072),
+custom = [tuple(int(v) for v in a.split("x")) for a in sys.argv[2:]]
+for (B, W, Hh) in custom or [(1, 256, 256), (1, 512, 512), (1, 1024, 1024), (1, 1920, 1080), (1, 2048, 2048), (1, 2560, 1440), (1, 3072, 3072),
                    (1, 3840, 2160), (1, 4096, 4096), (2, 4096, 4096), (4, 4096, 4096), (8, 4096, 4096), (16, 1920, 1080)]:
     n = B * W * Hh
     img = torch.empty(n, dtype=torch.uint8, device="cuda"); grid = torch.empty_like(img); out = torch.empty_like(img)
