@@ -89,20 +89,32 @@ SubGeom sub_geom(uint32_t w, uint32_t h, uint32_t k)
     return g;
 }
 
-// Scratch bytes one encode (or decode) of this shape takes, recursion included.
+// Scratch bytes one encode (or decode) of this shape takes, recursion included.  The bump allocator only resets
+// between calls, so this mirrors encode_impl / decode_impl plane for plane: a decode deeper than a tile takes two
+// lattice planes per recursion level; an encode takes three -- and then both encodes AND decodes its lattice
+// (the reconstruction feeds the tile kernel as seeds), each of which recurses on its own.
+size_t plane_bytes(const SubGeom &g, size_t batch) { return align_up(batch * g.stride, 256) + 256; }
+
+size_t ws_need_decode(uint32_t w, uint32_t h, uint32_t levels, size_t batch)
+{
+    if (levels <= (uint32_t)kFusedMaxLevels) return 0;
+    const SubGeom g = sub_geom(w, h, kFusedMaxLevels);
+    return 2 * plane_bytes(g, batch) + ws_need_decode(g.sw, g.sh, levels - kFusedMaxLevels, batch);
+}
+
+size_t ws_need_encode(uint32_t w, uint32_t h, uint32_t levels, size_t batch)
+{
+    if (levels <= (uint32_t)kFusedMaxLevels) return 0;
+    const SubGeom g = sub_geom(w, h, kFusedMaxLevels);
+    return 3 * plane_bytes(g, batch) + ws_need_encode(g.sw, g.sh, levels - kFusedMaxLevels, batch) +
+           ws_need_decode(g.sw, g.sh, levels - kFusedMaxLevels, batch);
+}
+
 size_t ws_need(const hgi_ctx *c, uint32_t w, uint32_t h, uint32_t levels, size_t batch, size_t stride)
 {
     if (levels == 0) return 0;
     if (c->path == HGI_PATH_LEVELWISE) return align_up(batch * stride, 256) + 256;
-    size_t need = 0;
-    while (levels > (uint32_t)kFusedMaxLevels) {
-        SubGeom g = sub_geom(w, h, kFusedMaxLevels);
-        need += 3 * (align_up(batch * g.stride, 256) + 256);
-        w = g.sw;
-        h = g.sh;
-        levels -= kFusedMaxLevels;
-    }
-    return need;
+    return ws_need_encode(w, h, levels, batch);   // >= the decode need
 }
 
 // Tile geometry of a fused launch.  128 x 64 tiles are the throughput shape; a call whose 64-row tiles would not

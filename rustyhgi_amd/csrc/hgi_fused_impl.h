@@ -225,6 +225,51 @@ __device__ __forceinline__ void store_row_pair(v4u r0, v4u r1, __amdgpu_buffer_r
     asm volatile("s_nop 1" ::"v"(r0), "v"(r1));
 }
 
+// Per-dword byte masks of a 16-B chunk of which only the first `nvalid` bytes lie inside the image
+// (nvalid <= 0: none, >= 16: all).
+__device__ __forceinline__ v4u chunk_mask(int nvalid)
+{
+    v4u m;
+#pragma unroll
+    for (int d = 0; d < 4; ++d) {
+        const int nb = nvalid - 4 * d;
+        m[d] = nb >= 4 ? ~0u : (nb <= 0 ? 0u : (1u << (8 * nb)) - 1u);
+    }
+    return m;
+}
+// ... and of the 8-B half-resolution chunk that goes with it (byte j <-> image column 2 j of the chunk)
+__device__ __forceinline__ v2u chunk_mask2(int nvalid)
+{
+    const v4u m = chunk_mask((nvalid + 1) >> 1);
+    v2u r = {m.x, m.y};
+    return r;
+}
+
+// The row pair of a lane of an EDGE tile: whole chunks as 16-B stores, of the chunk that straddles the right image
+// edge only the dwords inside, rows below the image not at all.  The data registers are held like in store_row_pair.
+__device__ __forceinline__ void store_rows_edge(v4u r0, v4u r1, __amdgpu_buffer_rsrc_t rd, u32 voff, u32 pitch, int nvalid,
+                                                bool row0, bool row1)
+{
+    // the width is a multiple of 4 on this path (fused_geom), so the straddling chunk holds 1..3 whole dwords
+    const u32 v1 = voff + pitch;
+    if (nvalid >= 16 && row1) {            // whole chunk, both rows inside (row1 implies row0)
+        __builtin_amdgcn_raw_buffer_store_b128(r0, rd, voff, 0, HGI_STORE_AUX);
+        __builtin_amdgcn_raw_buffer_store_b128(r1, rd, voff, pitch, HGI_STORE_AUX);
+    } else if (nvalid >= 16) {
+        if (row0) __builtin_amdgcn_raw_buffer_store_b128(r0, rd, voff, 0, HGI_STORE_AUX);
+    } else if (nvalid >= 12) {
+        if (row0) __builtin_amdgcn_raw_buffer_store_b96(v3u{r0.x, r0.y, r0.z}, rd, voff, 0, 0);
+        if (row1) __builtin_amdgcn_raw_buffer_store_b96(v3u{r1.x, r1.y, r1.z}, rd, v1, 0, 0);
+    } else if (nvalid >= 8) {
+        if (row0) __builtin_amdgcn_raw_buffer_store_b64(v2u{r0.x, r0.y}, rd, voff, 0, 0);
+        if (row1) __builtin_amdgcn_raw_buffer_store_b64(v2u{r1.x, r1.y}, rd, v1, 0, 0);
+    } else if (nvalid >= 4) {
+        if (row0) __builtin_amdgcn_raw_buffer_store_b32(r0.x, rd, voff, 0, 0);
+        if (row1) __builtin_amdgcn_raw_buffer_store_b32(r1.x, rd, v1, 0, 0);
+    }
+    asm volatile("s_nop 1" ::"v"(r0), "v"(r1));
+}
+
 // =============================================================================================
 // GENERIC PATH (ragged tiles, unaligned widths): every access checked against the image
 // =============================================================================================
@@ -236,6 +281,10 @@ __device__ __forceinline__ uint4 load16(const u8 *__restrict__ fr, u32 W, u32 H,
         const u8 *p = fr + (size_t)gy * W + gx;
         if (aligned) {
             v = *reinterpret_cast<const uint4 *>(p);
+        } else if (gx + 16 <= W) {
+            // chunk inside the row at any byte alignment: still one 16-B access (gfx9+ under ROCm runs with
+            // unaligned access enabled; the compiler emits global_load_dwordx4 for this)
+            __builtin_memcpy(&v, p, 16);
         } else {
             u32 w[4] = {0, 0, 0, 0};
 #pragma unroll
@@ -252,6 +301,8 @@ __device__ __forceinline__ void store16(u8 *__restrict__ fr, u32 W, u32 gx, u32 
     u8 *p = fr + (size_t)gy * W + gx;
     if (aligned) {
         *reinterpret_cast<uint4 *>(p) = v;
+    } else if (gx + 16 <= W) {
+        __builtin_memcpy(p, &v, 16);
     } else {
         u32 w[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
@@ -635,11 +686,16 @@ __device__ __forceinline__ void stage_issue(Stage &st, const Buf &b, Tile tl, in
     // image come back as 0 from the range check (the row offsets go through voffset there, which is
     // what the check sees), chunks right of it are masked.
     const bool cin = tl.X0 + 16 * c < W;
+    // the chunk that straddles the right edge (widths that are not multiples of 16) holds the next row's
+    // first pixels behind the image's last ones: cleared after the load, like everything else outside
+    const bool narrow = RAGGED && tl.X0 + TW > W;   // wave-uniform: this tile straddles the right edge
+    const v4u cm = narrow ? chunk_mask((int)W - (int)(tl.X0 + 16 * c)) : v4u{~0u, ~0u, ~0u, ~0u};
 #pragma unroll
     for (int j = 0; j < TH / 16; ++j) {
         st.e[j] = v4u{0, 0, 0, 0};
         if (RAGGED) {
             if (cin) st.e[j] = __builtin_amdgcn_raw_buffer_load_b128(b.rs, voff + j * 16 * W, 0, 0);
+            if (narrow) st.e[j] &= cm;
         } else {
             st.e[j] = __builtin_amdgcn_raw_buffer_load_b128(b.rs, voff, j * 16 * W, HGI_LOAD_AUX);
         }
@@ -649,9 +705,11 @@ __device__ __forceinline__ void stage_issue(Stage &st, const Buf &b, Tile tl, in
         st.o[j] = v4u{0, 0, 0, 0};
         if (!RAGGED) st.o[j] = __builtin_amdgcn_raw_buffer_load_b128(b.rs, vodd, j * 16 * W, HGI_ODD_LOAD_AUX);
         if (RAGGED && ODD_CHECKED && cin) st.o[j] = __builtin_amdgcn_raw_buffer_load_b128(b.rs, vodd + j * 16 * W, 0, HGI_ODD_LOAD_AUX);
+        if (narrow) st.o[j] &= cm;
     }
     st.hv = v4u{0, 0, 0, 0};
     if (lane < nh * CH && cin) st.hv = __builtin_amdgcn_raw_buffer_load_b128(b.rs, b.base + (TH + hoff(r)) * W + 16 * c, 0, 0);
+    if (narrow) st.hv &= cm;
     const int hy = lane < TH / 2 ? 2 * lane : TH + hoff(lane - TH / 2);
     const u32 xo = b.base + hy * W + TW;
     const u32 xr = tl.X0 + TW;              // first column right of the tile
@@ -659,6 +717,8 @@ __device__ __forceinline__ void stage_issue(Stage &st, const Buf &b, Tile tl, in
     st.d16 = st.d32 = st.d64 = 0;
     if (lane < TH / 2 + nh) {
         if (xr < W) st.x0 = __builtin_amdgcn_raw_buffer_load_b96(b.rs, xo, 0, 0);
+        if (xr + 4 >= W) st.x0.y = 0;    // offsets 4 / 8 can lie beyond the image when the width is not a multiple of 16
+        if (xr + 8 >= W) st.x0.z = 0;
         if (k >= 4 && xr + 16 < W) st.d16 = __builtin_amdgcn_raw_buffer_load_b32(b.rs, xo + 16, 0, 0);
         if (k >= 5 && xr + 32 < W) st.d32 = __builtin_amdgcn_raw_buffer_load_b32(b.rs, xo + 32, 0, 0);
         if (k >= 6 && xr + 64 < W) st.d64 = __builtin_amdgcn_raw_buffer_load_b32(b.rs, xo + 64, 0, 0);
@@ -721,10 +781,13 @@ __device__ __forceinline__ u32 gather_b0(v4u a)
 }
 
 // level sub == 2 of the tile body: four 4x4 cells (16 px x rows y0, y0+2; corners also from y0+4) per lane.
-// BOTTOM: the tile crosses the lower image edge after `rows` rows; rows beyond it were staged as zeros and must
-// stay zeros (they are the out-of-image corners of the rows above, src/interpolator.rs:75-82).
-template <int INTERP, bool BOTTOM = false>
-__device__ __forceinline__ void dec_level2_fast(u8 *buf, int rows = TH)
+// EDGE: the tile crosses the image edge after `rows` rows and / or `cols` columns (a multiple of 16: a lane's
+// chunk is entirely inside or outside).  Pixels beyond were staged as zeros and must stay zeros: they are the
+// out-of-image corners of the cells inside (src/interpolator.rs:75-82).
+// EDGE == 1: the tile crosses only the lower edge (full width inside, even height): row masks suffice.
+// EDGE == 2: any ragged tile.
+template <int INTERP, int EDGE = 0>
+__device__ __forceinline__ void dec_level2_fast(u8 *buf, int rows = TH, int cols = TW)
 {
 #pragma unroll
     for (int it = 0; it < (TH / 4) * CH / NL; ++it) {
@@ -749,15 +812,21 @@ __device__ __forceinline__ void dec_level2_fast(u8 *buf, int rows = TH)
         HGI_ADDB(b0, 0, P, 0); HGI_ADDB(b1, 0, P, 1); HGI_ADDB(b2, 0, P, 2); HGI_ADDB(b3, 0, P, 3);
         HGI_ADDB(b0, 2, P, 0); HGI_ADDB(b1, 2, P, 1); HGI_ADDB(b2, 2, P, 2); HGI_ADDB(b3, 2, P, 3);
         v4u An = {a0, a1, a2, a3}, Bn = {b0, b1, b2, b3};
-        if (!BOTTOM || 2 * z0 < rows) *reinterpret_cast<v4u *>(r0) = An;
-        if (!BOTTOM || 2 * z0 + 2 < rows) *reinterpret_cast<v4u *>(r0 + S) = Bn;
+        if (EDGE == 2 && cols < TW) {   // columns beyond the image stay zero
+            const v4u m = chunk_mask(cols - 16 * (i & (CH - 1)));
+            An &= m;
+            Bn &= m;
+        }
+        if (!EDGE || 2 * z0 < rows) *reinterpret_cast<v4u *>(r0) = An;
+        if (!EDGE || 2 * z0 + 2 < rows) *reinterpret_cast<v4u *>(r0 + S) = Bn;
     }
 }
 
 // finest level: 16 px x 2 rows per lane; even rows from LDS, odd rows from the registers they were loaded
 // into, packed VALU, 16-B buffer stores
-template <int INTERP>
-__device__ __forceinline__ void dec_fine_fast(const u8 *buf, const Buf &b, const v4u (&odd)[NFINE])
+// EDGE: only the `rows` x `cols` part of the tile that lies inside the image is stored.
+template <int INTERP, int EDGE = 0>
+__device__ __forceinline__ void dec_fine_fast(const u8 *buf, const Buf &b, const v4u (&odd)[NFINE], int rows = TH, int cols = TW)
 {
     const int lane = threadIdx.x;
     const int rp0 = fine_pair0();
@@ -792,16 +861,21 @@ __device__ __forceinline__ void dec_fine_fast(const u8 *buf, const Buf &b, const
         HGI_ADDB(o2, 0, P1, 0); HGI_ADDB(o2, 1, P1, 0); HGI_ADDB(o2, 2, P1, 1); HGI_ADDB(o2, 3, P1, 1);
         HGI_ADDB(o3, 0, P1, 2); HGI_ADDB(o3, 1, P1, 2); HGI_ADDB(o3, 2, P1, 3); HGI_ADDB(o3, 3, P1, 3);
         v4u r0v = {e0, e1, e2, e3}, r1v = {o0, o1, o2, o3};
-        store_row_pair(r0v, r1v, b.rd, voff, __builtin_amdgcn_readfirstlane(b.W));
+        if (EDGE == 2) {
+            const int y = 2 * (rp0 + it * (NL / CH));
+            store_rows_edge(r0v, r1v, b.rd, voff, __builtin_amdgcn_readfirstlane(b.W), cols - 16 * (lane & (CH - 1)), y < rows, y + 1 < rows);
+        } else {   // EDGE == 1: row pairs below the image are dropped by the buffer range check (even height)
+            store_row_pair(r0v, r1v, b.rd, voff, __builtin_amdgcn_readfirstlane(b.W));
+        }
     }
 }
 
 // encode, level sub == 2 of the tile body: four cells per lane; corners from the half-resolution
 // reconstruction lattice (rbuf), originals in / residuals out in buf, new reconstructions into rbuf
-template <int INTERP, bool IDENT, bool BOTTOM = false>
+template <int INTERP, bool IDENT, int EDGE = 0>
 __device__ __forceinline__ void enc_level2_fast(u8 *buf, u8 *rbuf, const u8 *slut, Tile tl, u32 W, u32 H)
 {
-    const int rows = BOTTOM ? (int)(H - tl.Y0) : TH;   // image rows of the tile (see dec_level2_fast)
+    const int rows = EDGE ? (int)(H - tl.Y0) : TH, cols = EDGE ? (int)(W - tl.X0) : TW;   // see dec_level2_fast
     // One iteration (64 lanes x 4 cells) at a time, all its reads before its first write, and the level's
     // halo cells in a pass of their own afterwards: with the odd rows parked in registers the level is
     // the kernel's register high-water mark, and 96 VGPRs (5 waves per SIMD) beat the longer chains that
@@ -862,11 +936,19 @@ __device__ __forceinline__ void enc_level2_fast(u8 *buf, u8 *rbuf, const u8 *slu
             Q_REC(n1.y, 0, b2, 0, P, 2); Q_REC(n1.y, 1, b2, 2, P, 2); Q_REC(n1.y, 2, b3, 0, P, 3); Q_REC(n1.y, 3, b3, 2, P, 3);
         }
         v4u An = {a0, a1, a2, a3}, Bn = {b0, b1, b2, b3};
-        if (!BOTTOM || 4 * g < rows) {
+        if (EDGE == 2 && cols < TW) {   // columns beyond the image stay zero in both planes
+            const v4u m = chunk_mask(cols - 16 * c);
+            const v2u m2 = chunk_mask2(cols - 16 * c);
+            An &= m;
+            Bn &= m;
+            n0 &= m2;
+            n1 &= m2;
+        }
+        if (!EDGE || 4 * g < rows) {
             *reinterpret_cast<v4u *>(r0) = An;
             *reinterpret_cast<v2u *>(q0) = n0;
         }
-        if (!BOTTOM || 4 * g + 2 < rows) {
+        if (!EDGE || 4 * g + 2 < rows) {
             *reinterpret_cast<v4u *>(r0 + S) = Bn;
             *reinterpret_cast<v2u *>(q0 + S2) = n1;
         }
@@ -876,9 +958,9 @@ __device__ __forceinline__ void enc_level2_fast(u8 *buf, u8 *rbuf, const u8 *slu
     enc_halo_pass<INTERP, IDENT>(buf, rbuf, slut, 2, tl, W, H);
 }
 
-template <int INTERP, bool IDENT>
+template <int INTERP, bool IDENT, int EDGE = 0>
 __device__ __forceinline__ void enc_fine_fast(const u8 *buf, const u8 *rbuf, const u8 *slut, const Buf &b,
-                                              const v4u (&odd)[NFINE])
+                                              const v4u (&odd)[NFINE], int rows = TH, int cols = TW)
 {
     const int lane = threadIdx.x;
     const int rp0 = fine_pair0();
@@ -940,7 +1022,12 @@ __device__ __forceinline__ void enc_fine_fast(const u8 *buf, const u8 *rbuf, con
             }
             v4u o0 = {e0, e1, e2, e3}, o1 = {g0, g1, g2, g3};
             const u32 vo = voff + j * 2 * (NL / CH) * Ws;
-            store_row_pair(o0, o1, b.rd, vo, Ws);
+            if (EDGE == 2) {
+                const int y = 2 * (rp0 + (it + j) * (NL / CH));
+                store_rows_edge(o0, o1, b.rd, vo, Ws, cols - 16 * (lane & (CH - 1)), y < rows, y + 1 < rows);
+            } else {
+                store_row_pair(o0, o1, b.rd, vo, Ws);
+            }
         }
         r0 += PAIR * (NL / CH) * S;
         c0 += PAIR * (NL / CH) * S2;
@@ -1018,14 +1105,6 @@ struct TileCtx {
     Buf b;
 };
 
-// see dec_tile_bottom: full tile width inside the image, lower edge crossed, buffer staging allowed, and an even
-// height, so that the last row pair is either entirely inside or entirely outside (the odd row's store carries its
-// row offset in soffset, which the range check does not see)
-__device__ __forceinline__ bool bottom_ragged(Tile tl, u32 W, u32 H, u32 aligned)
-{
-    return (aligned & 2u) && !(H & 1u) && tl.X0 + TW <= W && tl.Y0 + TH > H;
-}
-
 __device__ __forceinline__ TileCtx fast_ctx(u32 t, const u8 *src, u8 *dst, const Frames &f, const TileGrid &g)
 {
     TileCtx c;
@@ -1088,21 +1167,26 @@ __device__ __forceinline__ void dec_tile_fast(u8 *buf, const TileCtx &cur, const
     dec_fine_fast<INTERP>(buf, cur.b, odd);
 }
 
-// A tile whose body crosses only the LOWER image edge (full width inside, even height): the buffer range check
-// already zeroes its loads below the image and drops its stores there, so it keeps the fast staging and the fast
-// finest level; only the level passes in between must leave the out-of-image lattice rows untouched.
-template <int INTERP>
-__device__ __forceinline__ void dec_tile_bottom(u8 *buf, const TileCtx &cur, const v4u (&odd)[NFINE], u32 k, u32 W, u32 H)
+// A ragged tile (any width, any height, any alignment).  Staging zeroes what lies outside the image (range check
+// below it, lane and byte masks right of it), so the tile keeps the buffer staging and the fast finest level; the
+// level passes in between only have to leave the out-of-image lattice points untouched, and the finest level
+// stores just the part inside.
+// EDGE == 1 is the lean form for the commonest class -- full width inside, even height (1080 / 720 / 2160 rows under
+// widths that are multiples of 128): no column logic at all, and the range check alone disposes of the stores below
+// the image.
+template <int INTERP, int EDGE>
+__device__ __forceinline__ void dec_tile_edge(u8 *buf, const TileCtx &cur, const v4u (&odd)[NFINE], u32 k, u32 W, u32 H)
 {
+    const int rows = (int)(H - cur.tl.Y0), cols = (int)(W - cur.tl.X0);
     for (int s = 1 << (k - 1); s >= 2; s >>= 1) {
         if (s == 2)
-            dec_level2_fast<INTERP, true>(buf, (int)(H - cur.tl.Y0));
+            dec_level2_fast<INTERP, EDGE>(buf, rows, cols);
         else
             dec_cells<INTERP, true>(buf, s, cur.tl, W, H);
         dec_halo_cells<INTERP>(buf, s, cur.tl, W, H);
         LDS_ORDER();
     }
-    dec_fine_fast<INTERP>(buf, cur.b, odd);
+    dec_fine_fast<INTERP, EDGE>(buf, cur.b, odd, rows, cols);
 }
 
 // One block (= one wave) per tile, ONE launch per batch.  The first blocks take the ragged tiles
@@ -1158,23 +1242,21 @@ __global__ __launch_bounds__(NL) __attribute__((amdgpu_waves_per_eu(HGI_DEC_WAVE
     u8 *out = dst + (size_t)tl.frame * f.frame_stride;
     SeedRegs seeds;
     if (SEEDED) seeds = seed_issue<false>(sd, tl, k);
-    if (bottom_ragged(tl, W, H, aligned)) {
+    if (aligned & 2u) {   // 32-bit buffer offsets: buffer staging and the check-free levels with edge masks
         TileCtx cur = {tl, make_buf(fr, out, W, H, tl)};
         Stage st;
         stage_issue<true, true>(st, cur.b, tl, (int)k, nh);
         stage_commit<false>(buf, nullptr, st, nh);
         LDS_ORDER();
         if (SEEDED) dec_seed_commit(buf, seeds, k);
-        dec_tile_bottom<INTERP>(buf, cur, st.o, k, W, H);
+        if (tl.X0 + TW <= W && !(H & 1u))
+            dec_tile_edge<INTERP, 1>(buf, cur, st.o, k, W, H);
+        else
+            dec_tile_edge<INTERP, 2>(buf, cur, st.o, k, W, H);
         return;
     }
-    if (aligned & 2u) {   // aligned rows and 32-bit offsets: the buffer-load staging of the fast path
-        Stage st;
-        stage_issue<true>(st, make_buf(fr, out, W, H, tl), tl, (int)k, nh);
-        stage_commit<false>(buf, nullptr, st, nh);
-    } else {
-        stage_tile_generic(buf, fr, W, H, tl, nh, (aligned & 1u) != 0);
-    }
+    // frames whose byte offsets do not fit 32 bits: every access checked, 64-bit addressing
+    stage_tile_generic(buf, fr, W, H, tl, nh, (aligned & 1u) != 0);
     LDS_ORDER();
     if (SEEDED) dec_seed_commit(buf, seeds, k);
     for (int s = 1 << (k - 1); s >= 2; s >>= 1) {
@@ -1199,20 +1281,20 @@ __device__ __forceinline__ void enc_seed_commit(u8 *buf, u8 *rbuf, const SeedReg
     LDS_ORDER();
 }
 
-template <int INTERP, bool IDENT>
-__device__ __forceinline__ void enc_tile_bottom(u8 *buf, u8 *rbuf, const u8 *slut, const TileCtx &cur,
-                                                const v4u (&odd)[NFINE], u32 k, u32 W, u32 H)
+template <int INTERP, bool IDENT, int EDGE>
+__device__ __forceinline__ void enc_tile_edge(u8 *buf, u8 *rbuf, const u8 *slut, const TileCtx &cur,
+                                              const v4u (&odd)[NFINE], u32 k, u32 W, u32 H)
 {
     for (int s = 1 << (k - 1); s >= 2; s >>= 1) {
         if (s == 2) {
-            enc_level2_fast<INTERP, IDENT, true>(buf, rbuf, slut, cur.tl, W, H);
+            enc_level2_fast<INTERP, IDENT, EDGE>(buf, rbuf, slut, cur.tl, W, H);
         } else {
             enc_cells<INTERP, IDENT, true>(buf, rbuf, slut, s, cur.tl, W, H);
             enc_halo_pass<INTERP, IDENT>(buf, rbuf, slut, s, cur.tl, W, H);
         }
         LDS_ORDER();
     }
-    enc_fine_fast<INTERP, IDENT>(buf, rbuf, slut, cur.b, odd);
+    enc_fine_fast<INTERP, IDENT, EDGE>(buf, rbuf, slut, cur.b, odd, (int)(H - cur.tl.Y0), (int)(W - cur.tl.X0));
 }
 
 template <int INTERP, bool IDENT>
@@ -1264,25 +1346,22 @@ __global__ __launch_bounds__(NL) __attribute__((amdgpu_waves_per_eu(IDENT ? HGI_
     u8 *out = dst + (size_t)tl.frame * f.frame_stride;
     SeedRegs seeds;
     if (SEEDED) seeds = seed_issue<true>(sd, tl, k);
-    if (bottom_ragged(tl, W, H, aligned)) {
+    if (aligned & 2u) {   // 32-bit buffer offsets: buffer staging and the check-free levels with edge masks
         TileCtx cur = {tl, make_buf(fr, out, W, H, tl)};
         Stage st;
         stage_issue<true, true>(st, cur.b, tl, (int)k, nh);
         stage_commit<true>(buf, rbuf, st, nh);
         LDS_ORDER();
         enc_seed_commit<SEEDED>(buf, rbuf, seeds, k);
-        enc_tile_bottom<INTERP, IDENT>(buf, rbuf, slut, cur, st.o, k, W, H);
+        if (tl.X0 + TW <= W && !(H & 1u))
+            enc_tile_edge<INTERP, IDENT, 1>(buf, rbuf, slut, cur, st.o, k, W, H);
+        else
+            enc_tile_edge<INTERP, IDENT, 2>(buf, rbuf, slut, cur, st.o, k, W, H);
         return;
     }
-    if (aligned & 2u) {
-        Stage st;
-        stage_issue<true>(st, make_buf(fr, out, W, H, tl), tl, (int)k, nh);
-        stage_commit<true>(buf, rbuf, st, nh);
-    } else {
-        stage_tile_generic(buf, fr, W, H, tl, nh, (aligned & 1u) != 0);
-        LDS_ORDER();
-        lattice_from_buf(buf, rbuf, nh);
-    }
+    stage_tile_generic(buf, fr, W, H, tl, nh, (aligned & 1u) != 0);
+    LDS_ORDER();
+    lattice_from_buf(buf, rbuf, nh);
     LDS_ORDER();
     enc_seed_commit<SEEDED>(buf, rbuf, seeds, k);
     for (int s = 1 << (k - 1); s >= 2; s >>= 1) {
@@ -1310,7 +1389,13 @@ FusedGeom fused_geom(const void *a, const void *b, const Frames &f)
     const bool aligned = f.width % 16 == 0 && f.frame_stride % 16 == 0 && ptr16(a) && ptr16(b);
     // every 32-bit buffer offset the fast path forms: (Y0 + TH + 64) * W + X0 + TW + 64 + 16
     const bool fits32 = ((u64)f.height + 2 * TH + 64) * f.width + 1024 < (1ull << 32);
-    const bool fast = aligned && fits32;
+    // Buffer loads / stores take any alignment (ROCm runs gfx9+ with unaligned access enabled; rows that start
+    // mid-line only cost extra line touches), so the check-free paths do not need 16-B aligned rows.  They do need
+    // rows that are a multiple of 4 bytes: the descriptor's num_records is exactly W * H, a dword that straddles
+    // the end of the frame is range-checked away as a whole, and only with W % 4 == 0 does every dword of every
+    // load line up with that end.  (Padding num_records instead would read past the caller's last frame.)
+    static const bool force_checked = getenv("HGI_FORCE_CHECKED") != nullptr;   // tests: run every tile through the checked path
+    const bool fast = fits32 && f.width % 4 == 0 && !force_checked;
     g.full_x = fast ? f.width / TW : 0;
     g.full_y = fast ? f.height / TH : 0;
     if (g.full_x == 0 || g.full_y == 0) g.full_x = g.full_y = 0;
@@ -1318,7 +1403,8 @@ FusedGeom fused_geom(const void *a, const void *b, const Frames &f)
     r.ok = all > 0 && all + 8 < (1ull << 31);
     g.nfast = (u32)nfast;
     g.nedge = (u32)(all - nfast);
-    r.aligned = (aligned ? 1u : 0u) | (fast ? 2u : 0u);   // bit 0: 16-B rows; bit 1: buffer-load staging allowed
+    // bit 0: 16-B aligned rows and pointers (vector accesses of the byte-checked path); bit 1: 32-bit buffer offsets
+    r.aligned = (aligned ? 1u : 0u) | (fast ? 2u : 0u);
     return r;
 }
 

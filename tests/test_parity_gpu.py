@@ -501,3 +501,47 @@ def test_hip_graph_capture_and_replay(H, ctxs, oracle):
                 assert_same(gd[f], want, "graph replay %d encode frame %d L%d" % (rep, f, levels))
                 assert_same(od[f], oracle.decode(want, levels), "graph replay %d decode frame %d L%d" % (rep, f, levels))
     ctx.close()
+
+
+@pytest.mark.parametrize("mode", ["HGI_FORCE_CHECKED=1", "HGI_TILE_H=64", "HGI_TILE_H=32"])
+def test_forced_code_paths_in_a_child_process(mode):
+    """The library picks tile geometry and code path per launch: 128x32 or 128x64 tiles, and the fully checked path only
+    for widths that are not multiples of 4 or frames beyond 32-bit offsets.  Each switch is read once per process, so a
+    child process re-runs the shape-heavy parity cases with one of them forced: aligned shapes through the checked
+    path, small shapes through 64-row tiles, large ones through 32-row tiles."""
+    import os
+    import subprocess
+    import sys
+    key, val = mode.split("=")
+    env = dict(os.environ, **{key: val})
+    here = os.path.dirname(os.path.abspath(__file__))
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(here, "test_parity_gpu.py"), "-m", "gpu", "-q", "-x",
+                        "-p", "no:cacheprovider", "-k",
+                        "small_golden or lena_and_fullhd or random_shapes or smooth_images or batch_layouts or fuzz or extreme"],
+                       env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, mode + "\n" + r.stdout[-3000:] + r.stderr[-1000:]
+
+
+@pytest.mark.parametrize("w,h,levels,batch", [(1024, 1024, 31, 1), (704, 300, 13, 2), (4096, 256, 20, 1), (2048, 2048, 19, 1)])
+def test_deep_pyramid_first_call_on_fresh_context(H, oracle, w, h, levels, batch):
+    """Pyramids several tiles deep recurse on the host (lattice of the lattice ...), and the encoder's recursion also
+    decodes every lattice plane.  The scratch estimate has to cover all of it when the very first call on a context is
+    such a pyramid -- no earlier call has grown the scratch (regression: 'scratch exhausted (lattice planes)')."""
+    import torch
+    from rustyhgi_amd import _ffi
+    L = _ffi.lib()
+    ctx = H.Context(0)
+    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    lut = oracle.linear_lut(1)[0]
+    host = np.stack([oracle.synth(oracle.SYNTH_RAMP, SEED0 + 9, f, w, h) for f in range(batch)])
+    src = torch.from_numpy(host).cuda()
+    grid = torch.empty_like(src)
+    out = torch.empty_like(src)
+    _ffi.check(L.hgi_encode_u8_dev(ctx.handle, src.data_ptr(), w, h, levels, 1, lut.ctypes.data, grid.data_ptr(), batch, w * h))
+    _ffi.check(L.hgi_decode_u8_dev(ctx.handle, grid.data_ptr(), w, h, levels, 1, out.data_ptr(), batch, w * h))
+    torch.cuda.synchronize()
+    for f in range(batch):
+        want = oracle.encode(host[f], levels, lut)
+        assert_same(grid[f].cpu().numpy(), want, "encode %dx%d L%d frame %d" % (w, h, levels, f))
+        assert_same(out[f].cpu().numpy(), oracle.decode(want, levels), "decode %dx%d L%d frame %d" % (w, h, levels, f))
+    ctx.close()
