@@ -250,7 +250,7 @@ __device__ __forceinline__ v2u chunk_mask2(int nvalid)
 __device__ __forceinline__ void store_rows_edge(v4u r0, v4u r1, __amdgpu_buffer_rsrc_t rd, u32 voff, u32 pitch, int nvalid,
                                                 bool row0, bool row1)
 {
-    // the width is a multiple of 4 on this path (fused_geom), so the straddling chunk holds 1..3 whole dwords
+    // the straddling chunk: its whole dwords, then (widths that are not multiples of 4) the last 1..3 bytes
     const u32 v1 = voff + pitch;
     if (nvalid >= 16 && row1) {            // whole chunk, both rows inside (row1 implies row0)
         __builtin_amdgcn_raw_buffer_store_b128(r0, rd, voff, 0, HGI_STORE_AUX);
@@ -266,6 +266,15 @@ __device__ __forceinline__ void store_rows_edge(v4u r0, v4u r1, __amdgpu_buffer_
     } else if (nvalid >= 4) {
         if (row0) __builtin_amdgcn_raw_buffer_store_b32(r0.x, rd, voff, 0, 0);
         if (row1) __builtin_amdgcn_raw_buffer_store_b32(r1.x, rd, v1, 0, 0);
+    }
+    if (nvalid > 0 && nvalid < 16 && (nvalid & 3)) {
+        const int d = nvalid >> 2;
+        const u32 w0 = d == 0 ? r0.x : d == 1 ? r0.y : d == 2 ? r0.z : r0.w;
+        const u32 w1 = d == 0 ? r1.x : d == 1 ? r1.y : d == 2 ? r1.z : r1.w;
+        for (int j = 0; j < (nvalid & 3); ++j) {
+            if (row0) __builtin_amdgcn_raw_buffer_store_b8((u8)(w0 >> (8 * j)), rd, voff + 4 * d + j, 0, 0);
+            if (row1) __builtin_amdgcn_raw_buffer_store_b8((u8)(w1 >> (8 * j)), rd, v1 + 4 * d + j, 0, 0);
+        }
     }
     asm volatile("s_nop 1" ::"v"(r0), "v"(r1));
 }
@@ -1045,11 +1054,15 @@ __device__ __forceinline__ u8 *uniform_ptr(const u8 *p)
     return reinterpret_cast<u8 *>(((u64)hi << 32) | lo);
 }
 
-__device__ __forceinline__ Buf make_buf(const u8 *fr, u8 *out, u32 W, u32 H, Tile tl)
+// `tail` (0 or 3) extra records on the READ side: when rows are not a multiple of 4 bytes a dword of a load can
+// straddle the end of the frame, and the range check would drop it whole -- valid bytes included.  The host grants
+// the 3 bytes only when reading them is safe (fused_geom); what they hold lies right of the image and is masked.
+// Dwords that START at or beyond W * H are still out of range, so rows below the image keep reading as zero.
+__device__ __forceinline__ Buf make_buf(const u8 *fr, u8 *out, u32 W, u32 H, Tile tl, u32 tail)
 {
     Buf b;
     const u32 bytes = W * H;   // the host only selects the fast path when this (plus the halo) fits 32 bits
-    b.rs = __builtin_amdgcn_make_buffer_rsrc(uniform_ptr(fr), 0, bytes, 0x00020000);
+    b.rs = __builtin_amdgcn_make_buffer_rsrc(uniform_ptr(fr), 0, bytes + tail, 0x00020000);
     b.rd = __builtin_amdgcn_make_buffer_rsrc(uniform_ptr(out), 0, bytes, 0x00020000);
     b.W = W;
     b.base = __builtin_amdgcn_readfirstlane(tl.Y0 * W + tl.X0);
@@ -1105,12 +1118,12 @@ struct TileCtx {
     Buf b;
 };
 
-__device__ __forceinline__ TileCtx fast_ctx(u32 t, const u8 *src, u8 *dst, const Frames &f, const TileGrid &g)
+__device__ __forceinline__ TileCtx fast_ctx(u32 t, const u8 *src, u8 *dst, const Frames &f, const TileGrid &g, u32 tail)
 {
     TileCtx c;
     c.tl = fast_tile(t, g);
     c.b = make_buf(src + (size_t)c.tl.frame * f.frame_stride, dst + (size_t)c.tl.frame * f.frame_stride, f.width,
-                   f.height, c.tl);
+                   f.height, c.tl, tail);
     return c;
 }
 
@@ -1225,7 +1238,7 @@ __global__ __launch_bounds__(NL) __attribute__((amdgpu_waves_per_eu(HGI_DEC_WAVE
     const BlockRole role = block_role(g);
     if (role.idle) return;
     if (!role.edge) {
-        TileCtx cur = fast_ctx(role.index, src, dst, f, g);
+        TileCtx cur = fast_ctx(role.index, src, dst, f, g, (aligned & 4u) ? 3u : 0u);
         Stage st;
         SeedRegs seeds;
         stage_issue<false>(st, cur.b, cur.tl, (int)k, nh);
@@ -1243,7 +1256,7 @@ __global__ __launch_bounds__(NL) __attribute__((amdgpu_waves_per_eu(HGI_DEC_WAVE
     SeedRegs seeds;
     if (SEEDED) seeds = seed_issue<false>(sd, tl, k);
     if (aligned & 2u) {   // 32-bit buffer offsets: buffer staging and the check-free levels with edge masks
-        TileCtx cur = {tl, make_buf(fr, out, W, H, tl)};
+        TileCtx cur = {tl, make_buf(fr, out, W, H, tl, (aligned & 4u) ? 3u : 0u)};
         Stage st;
         stage_issue<true, true>(st, cur.b, tl, (int)k, nh);
         stage_commit<false>(buf, nullptr, st, nh);
@@ -1330,7 +1343,7 @@ __global__ __launch_bounds__(NL) __attribute__((amdgpu_waves_per_eu(IDENT ? HGI_
     if (role.idle) return;
     if (!IDENT) reinterpret_cast<u32 *>(slut)[threadIdx.x] = lut.w[threadIdx.x];
     if (!role.edge) {
-        TileCtx cur = fast_ctx(role.index, src, dst, f, g);
+        TileCtx cur = fast_ctx(role.index, src, dst, f, g, (aligned & 4u) ? 3u : 0u);
         Stage st;
         SeedRegs seeds;
         stage_issue<false>(st, cur.b, cur.tl, (int)k, nh);
@@ -1347,7 +1360,7 @@ __global__ __launch_bounds__(NL) __attribute__((amdgpu_waves_per_eu(IDENT ? HGI_
     SeedRegs seeds;
     if (SEEDED) seeds = seed_issue<true>(sd, tl, k);
     if (aligned & 2u) {   // 32-bit buffer offsets: buffer staging and the check-free levels with edge masks
-        TileCtx cur = {tl, make_buf(fr, out, W, H, tl)};
+        TileCtx cur = {tl, make_buf(fr, out, W, H, tl, (aligned & 4u) ? 3u : 0u)};
         Stage st;
         stage_issue<true, true>(st, cur.b, tl, (int)k, nh);
         stage_commit<true>(buf, rbuf, st, nh);
@@ -1390,12 +1403,16 @@ FusedGeom fused_geom(const void *a, const void *b, const Frames &f)
     // every 32-bit buffer offset the fast path forms: (Y0 + TH + 64) * W + X0 + TW + 64 + 16
     const bool fits32 = ((u64)f.height + 2 * TH + 64) * f.width + 1024 < (1ull << 32);
     // Buffer loads / stores take any alignment (ROCm runs gfx9+ with unaligned access enabled; rows that start
-    // mid-line only cost extra line touches), so the check-free paths do not need 16-B aligned rows.  They do need
-    // rows that are a multiple of 4 bytes: the descriptor's num_records is exactly W * H, a dword that straddles
-    // the end of the frame is range-checked away as a whole, and only with W % 4 == 0 does every dword of every
-    // load line up with that end.  (Padding num_records instead would read past the caller's last frame.)
+    // mid-line only cost extra line touches), so the check-free paths do not need 16-B aligned rows.  With rows that
+    // are a multiple of 4 bytes every dword of every load lines up with the end of the frame (num_records = W * H).
+    // Otherwise the read descriptors get 3 extra records -- if the caller's memory allows it: the over-read of every
+    // frame but the last lands in the next frame (or the stride padding), that of the last frame must stay in the
+    // 4-KiB page that holds the frame's last byte.
     static const bool force_checked = getenv("HGI_FORCE_CHECKED") != nullptr;   // tests: run every tile through the checked path
-    const bool fast = fits32 && f.width % 4 == 0 && !force_checked;
+    const uintptr_t end = reinterpret_cast<uintptr_t>(a) + (uintptr_t)(f.batch - 1) * f.frame_stride + (uintptr_t)f.width * f.height;
+    const bool dword_rows = f.width % 4 == 0;
+    const bool tail_ok = ((end - 1) >> 12) == ((end + 2) >> 12) && (f.batch == 1 || f.frame_stride >= (u64)f.width * f.height);
+    const bool fast = fits32 && (dword_rows || tail_ok) && !force_checked;
     g.full_x = fast ? f.width / TW : 0;
     g.full_y = fast ? f.height / TH : 0;
     if (g.full_x == 0 || g.full_y == 0) g.full_x = g.full_y = 0;
@@ -1403,8 +1420,9 @@ FusedGeom fused_geom(const void *a, const void *b, const Frames &f)
     r.ok = all > 0 && all + 8 < (1ull << 31);
     g.nfast = (u32)nfast;
     g.nedge = (u32)(all - nfast);
-    // bit 0: 16-B aligned rows and pointers (vector accesses of the byte-checked path); bit 1: 32-bit buffer offsets
-    r.aligned = (aligned ? 1u : 0u) | (fast ? 2u : 0u);
+    // bit 0: 16-B aligned rows and pointers (vector accesses of the byte-checked path); bit 1: check-free paths allowed
+    // (32-bit buffer offsets); bit 2: read descriptors carry 3 extra records (rows not a multiple of 4 bytes)
+    r.aligned = (aligned ? 1u : 0u) | (fast ? 2u : 0u) | (fast && !dword_rows ? 4u : 0u);
     return r;
 }
 

@@ -545,3 +545,46 @@ def test_deep_pyramid_first_call_on_fresh_context(H, oracle, w, h, levels, batch
         assert_same(grid[f].cpu().numpy(), want, "encode %dx%d L%d frame %d" % (w, h, levels, f))
         assert_same(out[f].cpu().numpy(), oracle.decode(want, levels), "decode %dx%d L%d frame %d" % (w, h, levels, f))
     ctx.close()
+
+
+@pytest.mark.parametrize("w,h,levels", [(1001, 97, 4), (255, 64, 3), (1366, 70, 5), (130, 33, 7)])
+def test_odd_width_tail_guard(H, ctxs, oracle, w, h, levels):
+    """Rows that are not a multiple of 4 bytes: the check-free paths read up to 3 bytes past the last frame, which the
+    host only allows when those bytes share a 4-KiB page with the frame's last byte.  Both placements -- the batch ending
+    exactly on a page boundary (guard: byte-checked path) and in mid-page (tail path) -- must be bit-exact, and
+    nothing around the buffers may be written."""
+    import torch
+    from rustyhgi_amd import _ffi
+    L = _ffi.lib()
+    ctx = ctxs["fused"]
+    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    B, n = 2, w * h
+    lut = oracle.linear_lut(2)[0]
+    host = np.stack([oracle.synth(oracle.SYNTH_NOISE, SEED0 + 11, f, w, h) for f in range(B)])
+    pool = torch.zeros(3 * (B * n + 3 * 8192), dtype=torch.uint8, device="cuda")
+    for end_mod in (0, 2048, 4095, 1):
+        views = []
+        at = pool.data_ptr()
+        for _ in range(3):                       # src, grid, out: each batch ends at `end_mod` within its page
+            at += 4096
+            start = at + (-(at + B * n - end_mod)) % 4096
+            assert (start + B * n) % 4096 == end_mod
+            views.append(start - pool.data_ptr())
+            at = start + B * n
+        so, go, oo = views
+        pool.fill_(0x77)
+        pool[so:so + B * n] = torch.from_numpy(host.reshape(-1)).cuda()
+        base = pool.data_ptr()
+        _ffi.check(L.hgi_encode_u8_dev(ctx.handle, base + so, w, h, levels, 1, lut.ctypes.data, base + go, B, n))
+        _ffi.check(L.hgi_decode_u8_dev(ctx.handle, base + go, w, h, levels, 1, base + oo, B, n))
+        torch.cuda.synchronize()
+        p = pool.cpu().numpy()
+        for f in range(B):
+            want = oracle.encode(host[f], levels, lut)
+            assert_same(p[go + f * n: go + (f + 1) * n].reshape(h, w), want, "encode %dx%d end%%4096=%d frame %d" % (w, h, end_mod, f))
+            assert_same(p[oo + f * n: oo + (f + 1) * n].reshape(h, w), oracle.decode(want, levels), "decode end%%4096=%d frame %d" % (end_mod, f))
+        untouched = np.ones(p.size, bool)
+        for o in views:
+            untouched[o:o + B * n] = False
+        assert (p[untouched] == 0x77).all(), "bytes outside the buffers were written (end%%4096=%d)" % end_mod
+    ctx.use_own_stream()
