@@ -1,6 +1,7 @@
 // C++ counterpart of the reference's criterion harness (benches/bench.rs): the same cases on the same
 // 1920x1080 `(x*y) as u8` image at levels = 4, throughput in bytes of image per second
 // (`Throughput::Bytes(width*height)`, benches/bench.rs:33-36).  Each codec case is timed twice:
+//   host-c -- hgi_encode_u8 called directly with reused caller-owned buffers (two PCIe transfers + kernel),
 //   host   -- through hgi_encode_u8 / hgi_decode_u8 (host pointers; PCIe transfers included), the
 //             drop-in equivalent of `encoder.encode(image)`;
 //   device -- through the *_dev entry points on device-resident buffers (what the roofline numbers use).
@@ -54,6 +55,14 @@ static void bench_encode(const char *name, Q quantizator, const GrayImage &image
     const size_t size = image.data.size();
     report(name, "host", median_seconds(25, [&] { (void)encoder.encode(image); }), size);
     auto table = quantizator::tabulate(quantizator);
+    {   // the C ABI itself with caller-owned, reused host buffers: what remains once the by-value image copy and the
+        // fresh Grid allocation of the crate-shaped API (src/encoder.rs:39) are taken out -- two PCIe transfers + kernel
+        std::vector<uint8_t> out(size);
+        report(name, "host-c", median_seconds(25, [&] {
+                   check(hgi_encode_u8(ctx.get(), image.data.data(), image.width, image.height, (uint32_t)levels, I::kernel_id,
+                                       table.data(), out.data()));
+               }), size);
+    }
     const int reps = 20;
     double sec = median_seconds(25, [&] {
         for (int r = 0; r < reps; ++r)
