@@ -106,6 +106,14 @@ hgi_status hgi_decode_u8_dev(hgi_ctx *ctx, const void *d_grid, uint32_t width, u
                              uint32_t levels, hgi_interp interp, void *d_img, size_t batch,
                              size_t frame_stride);
 
+/* ---- entropy front end (no counterpart in the reference, would precede the   */
+/* DEFLATE of src/archive.rs:36) ---------------------------------------------------------- */
+/* Byte histogram of each frame of a grid batch, on the device, async on the ctx stream:     */
+/* d_hist[256*f + v] = number of pixels of frame f equal to v.  d_hist: 256*batch uint64 of  */
+/* device memory (overwritten).  Any width, stride and alignment.                            */
+hgi_status hgi_histogram_u8_dev(hgi_ctx *ctx, const void *d_grid, uint32_t width, uint32_t height,
+                                size_t batch, size_t frame_stride, void *d_hist);
+
 /* ---- harness helpers (not part of the reference surface) ------------------------------ */
 /* Fill `batch` frames with a synthetic pattern; frame f uses index first_frame + f.        */
 hgi_status hgi_synth_u8_dev(hgi_ctx *ctx, hgi_synth_kind kind, uint64_t seed,

@@ -2,13 +2,14 @@
 
 Crate-root re-exports as in the reference's src/lib.rs:16-23:
     rustyhgi_amd.{Archive, Metadata, Decoder, Encoder}, rustyhgi_amd.interpolator, rustyhgi_amd.quantizator
+plus rustyhgi_amd.entropy (device-side byte histogram of the grid).
 All computation happens in libhgi_hip.so (hand-written HIP kernels); see include/hgi.h.
 """
-from . import interpolator, quantizator
+from . import entropy, interpolator, quantizator
 from ._ffi import Context, HgiError, default_context
 from .archive import Archive, Metadata
 from .codec import Decoder, Encoder
 from .grid import Grid
 
 __all__ = ["Encoder", "Decoder", "Grid", "Archive", "Metadata", "Context", "HgiError", "default_context", "interpolator",
-           "quantizator"]
+           "quantizator", "entropy"]

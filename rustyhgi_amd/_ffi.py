@@ -24,6 +24,7 @@ SYMBOLS = [
     ("hgi_ctx_use_own_stream", _int, [_vp]),
     ("hgi_ctx_set_path", _int, [_vp, _int]),
     ("hgi_ctx_reserve", _int, [_vp, _u32, _u32, _u32, _sz]),
+    ("hgi_histogram_u8_dev", _int, [_vp, _vp, _u32, _u32, _sz, _sz, _vp]),
     ("hgi_sync", _int, [_vp]),
     ("hgi_last_error", ctypes.c_char_p, []),
     ("hgi_version", ctypes.c_char_p, []),

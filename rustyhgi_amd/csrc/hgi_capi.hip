@@ -450,6 +450,20 @@ hgi_status hgi_copy_u8_dev(hgi_ctx *c, const void *d_src, void *d_dst, size_t n)
     return HGI_OK;
 }
 
+hgi_status hgi_histogram_u8_dev(hgi_ctx *c, const void *d_grid, uint32_t w, uint32_t h, size_t batch, size_t frame_stride,
+                                void *d_hist)
+{
+    if (!c) return fail(HGI_EINVAL, "ctx is NULL");
+    if (batch == 0) return HGI_OK;
+    if (!d_hist || ((w && h) && !d_grid)) return fail(HGI_EINVAL, "NULL buffer");
+    if (batch > 1 && frame_stride < (size_t)w * h) return fail(HGI_EINVAL, "frame_stride < width*height");
+    if (batch > 0xFFFFFFFFull) return fail(HGI_EINVAL, "batch too large");
+    HIP_TRY(hipSetDevice(c->device));
+    Frames f = {w, h, (uint64_t)frame_stride, (uint32_t)batch};
+    HIP_TRY(launch_histogram(static_cast<const uint8_t *>(d_grid), f, static_cast<unsigned long long *>(d_hist), c->stream));
+    return HGI_OK;
+}
+
 hgi_status hgi_diff_stats_dev(hgi_ctx *c, const void *d_before, const void *d_after, uint32_t w, uint32_t h,
                               size_t batch, size_t frame_stride, void *d_out)
 {

@@ -65,6 +65,8 @@ hipError_t launch_gather_lattice(const uint8_t *src, const Frames &f, uint32_t k
 hipError_t launch_synth(int kind, uint64_t seed, uint64_t first_frame, uint8_t *out, const Frames &f,
                         hipStream_t s);
 hipError_t launch_copy(const uint8_t *src, uint8_t *dst, size_t n, hipStream_t s);
+// hist[f][v] = number of pixels of frame f equal to v (uint64); the entropy front end of SURVEY 8(f4)
+hipError_t launch_histogram(const uint8_t *src, const Frames &f, unsigned long long *hist, hipStream_t s);
 hipError_t launch_diff_stats(const uint8_t *a, const uint8_t *b, const Frames &f,
                              unsigned long long *out, hipStream_t s);
 

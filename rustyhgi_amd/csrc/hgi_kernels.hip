@@ -129,6 +129,44 @@ __global__ void k_copy1(const u8 *__restrict__ src, u8 *__restrict__ dst, size_t
         dst[i] = src[i];
 }
 
+// per-frame byte histogram of a grid batch -- the front end of an entropy coder (or of a rate
+// estimate) on the device.  Residual grids are dominated by a handful of values, so a plain LDS histogram would
+// serialise on them: each block keeps kHistCopies copies, value-major (h[v][copy]: the copies of one value sit in
+// different banks), a lane adds into copy (lane & 15), and the copies are folded when the block is done.
+constexpr int kHistCopies = 16;
+__global__ __launch_bounds__(256) void k_histogram(const u8 *__restrict__ src, Frames f, unsigned long long *__restrict__ hist)
+{
+    __shared__ u32 h[256 * kHistCopies];
+    const u64 n = (u64)f.width * f.height;
+    const u32 copy = threadIdx.x & (kHistCopies - 1);
+    for (u32 fr = blockIdx.y; fr < f.batch; fr += gridDim.y) {
+        for (int i = threadIdx.x; i < 256 * kHistCopies; i += blockDim.x) h[i] = 0;
+        __syncthreads();
+        const u8 *p = src + fr * f.frame_stride;
+        const u64 chunks = n >> 4;
+        for (u64 c = (u64)blockIdx.x * blockDim.x + threadIdx.x; c < chunks; c += (u64)gridDim.x * blockDim.x) {
+            uint4 v;
+            __builtin_memcpy(&v, p + (c << 4), 16);     // any alignment: one 16-B load
+            const u32 w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int d = 0; d < 4; ++d) {
+#pragma unroll
+                for (int b = 0; b < 4; ++b) atomicAdd(&h[((w[d] >> (8 * b)) & 255u) * kHistCopies + copy], 1u);
+            }
+        }
+        if (blockIdx.x == 0)                            // the last n % 16 bytes of the frame
+            for (u64 i = (chunks << 4) + threadIdx.x; i < n; i += blockDim.x) atomicAdd(&h[(u32)p[i] * kHistCopies + copy], 1u);
+        __syncthreads();
+        if (threadIdx.x < 256) {
+            u32 sum = 0;
+#pragma unroll
+            for (int k = 0; k < kHistCopies; ++k) sum += h[threadIdx.x * kHistCopies + ((k + threadIdx.x) & (kHistCopies - 1))];
+            if (sum) atomicAdd(&hist[(size_t)fr * 256 + threadIdx.x], (unsigned long long)sum);
+        }
+        __syncthreads();
+    }
+}
+
 // src/main.rs:84-92 per frame: sum of squared differences, max |diff|, count of differing pixels
 __global__ void k_diff_stats(const u8 *__restrict__ a, const u8 *__restrict__ b, Frames f,
                              unsigned long long *__restrict__ out)
@@ -249,6 +287,20 @@ hipError_t launch_copy(const uint8_t *src, uint8_t *dst, size_t n, hipStream_t s
         if (blocks > 8192) blocks = 8192;
         hipLaunchKernelGGL(k_copy1, dim3((u32)blocks), dim3(256), 0, s, src, dst, n);
     }
+    return hipGetLastError();
+}
+
+hipError_t launch_histogram(const uint8_t *src, const Frames &f, unsigned long long *hist, hipStream_t s)
+{
+    hipError_t e = hipMemsetAsync(hist, 0, 256 * sizeof(unsigned long long) * f.batch, s);
+    if (e != hipSuccess) return e;
+    const u64 n = (u64)f.width * f.height;
+    if (n == 0) return hipSuccess;
+    // a block sweeps >= 64 KiB so that zeroing and folding its copies stays small; at most ~8 blocks per CU in all
+    u64 blocks = (n + 65535) / 65536;
+    const u64 per_frame_cap = 2048 / (batch_grid_y(f) ? batch_grid_y(f) : 1) + 1;
+    if (blocks > per_frame_cap) blocks = per_frame_cap;
+    hipLaunchKernelGGL(k_histogram, dim3((u32)blocks, batch_grid_y(f)), dim3(256), 0, s, src, f, hist);
     return hipGetLastError();
 }
 

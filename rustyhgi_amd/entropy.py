@@ -1,0 +1,43 @@
+"""Entropy front end on the device (the reference has no counterpart -- it hands the grid to DEFLATE
+on the CPU, src/archive.rs:36).  A per-frame byte histogram of the residual grid is what an entropy coder, or a
+rate estimate for choosing the quantization level, starts from; it is computed where the grid already lives.
+"""
+import numpy as np
+
+from . import _ffi
+from .codec import _torch_ctx
+
+
+def histogram(grids, context=None):
+    """(B, H, W) uint8 CUDA tensor (or (H, W)) -> (B, 256) int64 CUDA tensor: counts of each residual value per frame.
+    Asynchronous on the current stream, like the codec's batch calls."""
+    import torch
+    if grids.dim() == 2:
+        grids = grids.unsqueeze(0)
+    if grids.dtype != torch.uint8 or not grids.is_cuda or not grids.is_contiguous():
+        raise TypeError("histogram() takes a contiguous uint8 CUDA tensor of shape (B, H, W)")
+    ctx = _torch_ctx(grids, context)
+    b, h, w = grids.shape
+    hist = torch.empty((b, 256), dtype=torch.int64, device=grids.device)
+    _ffi.check(_ffi.lib().hgi_histogram_u8_dev(ctx.handle, grids.data_ptr(), w, h, b, h * w, hist.data_ptr()))
+    return hist
+
+
+def entropy_bits_per_pixel(hist):
+    """Order-0 entropy of each frame from its histogram: the bits per pixel an ideal memoryless coder would spend."""
+    h = np.asarray(hist.cpu() if hasattr(hist, "cpu") else hist, dtype=np.float64)
+    if h.ndim == 1:
+        h = h[None]
+    n = h.sum(axis=1, keepdims=True)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        p = np.where(n > 0, h / n, 0.0)
+        e = -(np.where(p > 0, p * np.log2(p), 0.0)).sum(axis=1)
+    return e
+
+
+def estimated_bytes(hist):
+    """ceil(pixels * entropy / 8) per frame: what the grid would take under an ideal order-0 coder."""
+    h = np.asarray(hist.cpu() if hasattr(hist, "cpu") else hist, dtype=np.float64)
+    if h.ndim == 1:
+        h = h[None]
+    return np.ceil(h.sum(axis=1) * entropy_bits_per_pixel(h) / 8.0).astype(np.int64)

@@ -55,6 +55,13 @@ def test_argument_checks_need_no_device():
     assert L.hgi_decode_u8(None, None, 4, 4, 2, 1, None) == _ffi.EINVAL
 
 
+def test_histogram_argument_checks_need_no_device():
+    L = _ffi.lib()
+    out = (ctypes.c_uint64 * 256)()
+    assert L.hgi_histogram_u8_dev(None, None, 8, 8, 1, 64, out) == _ffi.EINVAL      # NULL ctx
+    assert b"ctx" in L.hgi_last_error()
+
+
 def test_no_cpu_fallback_without_gpu():
     """Without a usable HIP device the product path must fail loudly, never compute on the host."""
     import torch

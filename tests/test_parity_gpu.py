@@ -588,3 +588,51 @@ def test_odd_width_tail_guard(H, ctxs, oracle, w, h, levels):
             untouched[o:o + B * n] = False
         assert (p[untouched] == 0x77).all(), "bytes outside the buffers were written (end%%4096=%d)" % end_mod
     ctx.use_own_stream()
+
+
+def test_device_histogram_matches_bincount(H, ctxs, oracle):
+    """the per-frame byte histogram of a grid batch computed on the device equals numpy.bincount of the
+    oracle's grid -- for real residual grids (dominated by a few values), uniform noise, a constant plane, sizes that
+    are not multiples of 16, padded strides and unaligned base pointers; the entropy estimate follows from it."""
+    import torch
+    from rustyhgi_amd import _ffi, entropy
+    L = _ffi.lib()
+    ctx = ctxs["fused"]
+    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    rng = np.random.default_rng(7)
+    lut = oracle.linear_lut(2)[0]
+    # 1. through the Python front end, on what the encoder produced
+    imgs = np.stack([oracle.synth(oracle.SYNTH_RAMP, SEED0 + 3, f, 1920, 1080) for f in range(3)])
+    enc = H.Encoder(H.interpolator.Crossed(), H.quantizator.Linear.from_level(H.quantizator.QuantizationLevel.Medium), 4, context=ctx)
+    grids = enc.encode_batch(torch.from_numpy(imgs).cuda())
+    hist = entropy.histogram(grids, context=ctx)
+    torch.cuda.synchronize()
+    got = hist.cpu().numpy()
+    for f in range(3):
+        want = np.bincount(oracle.encode(imgs[f], 4, lut).reshape(-1), minlength=256)
+        assert (got[f] == want).all(), "frame %d" % f
+    bpp = entropy.entropy_bits_per_pixel(hist)
+    assert bpp.shape == (3,) and (bpp > 0.5).all() and (bpp < 4.0).all()      # Medium on ramp+texture: a few bits
+    assert (entropy.estimated_bytes(hist) < 1920 * 1080 // 2).all()
+    # 2. through the C ABI under awkward layouts
+    for (B, W, Hh, pad, shift, kind) in [(2, 1001, 37, 5, 1, "noise"), (3, 16, 1, 0, 0, "noise"), (1, 7, 3, 0, 3, "noise"),
+                                          (2, 640, 480, 4096, 0, "const"), (1, 4096, 4096, 0, 0, "skew")]:
+        n, stride = W * Hh, W * Hh + pad
+        if kind == "noise":
+            host = rng.integers(0, 256, (B, n), dtype=np.uint8)
+        elif kind == "const":
+            host = np.full((B, n), 41, np.uint8)
+        else:
+            host = rng.choice(np.array([0, 41, 215, 3], np.uint8), size=(B, n), p=[0.9, 0.05, 0.04, 0.01])
+        buf = torch.full((shift + B * stride + 32,), 0x99, dtype=torch.uint8, device="cuda")
+        for f in range(B):
+            buf[shift + f * stride: shift + f * stride + n] = torch.from_numpy(host[f]).cuda()
+        out = torch.full((B, 256), -1, dtype=torch.int64, device="cuda")
+        _ffi.check(L.hgi_histogram_u8_dev(ctx.handle, buf.data_ptr() + shift, W, Hh, B, stride, out.data_ptr()))
+        torch.cuda.synchronize()
+        o = out.cpu().numpy()
+        for f in range(B):
+            assert (o[f] == np.bincount(host[f], minlength=256)).all(), (B, W, Hh, pad, shift, kind, f)
+    assert L.hgi_histogram_u8_dev(ctx.handle, None, 8, 8, 1, 64, out.data_ptr()) == _ffi.EINVAL
+    assert L.hgi_histogram_u8_dev(ctx.handle, buf.data_ptr(), 8, 8, 2, 10, out.data_ptr()) == _ffi.EINVAL
+    ctx.use_own_stream()
