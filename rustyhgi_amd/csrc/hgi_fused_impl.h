@@ -119,6 +119,11 @@ typedef u32 v3u __attribute__((ext_vector_type(3)));
 //   actual overflow    p + q > 255  <=>  q > ~p  Q_GT    (np = 255 - p per byte)
 //   residual = (expected != actual) ? d : q      Q_SEL   (s_xor + v_cndmask straight into byte K)
 typedef unsigned long long lanemask;
+// The encoder keeps the quantizer table at LDS offset 0 (k_enc_tiles checks it), so the clean residual byte d IS the
+// LDS address of table[d]: an address-space-3 pointer made from the integer gives a bare `ds_read_u8 q, d` -- no
+// per-pixel address add -- and stays visible to the compiler's s_waitcnt bookkeeping.
+typedef __attribute__((address_space(3))) const u8 lds_cu8;
+__device__ __forceinline__ u32 lut_at(u32 d) { return *(lds_cu8 *)(size_t)d; }
 #define Q_SUB(d, a, K, p, J)                                                                                   \
     asm("v_sub_u16_sdwa %0, %1, %2 dst_sel:BYTE_0 dst_unused:UNUSED_PAD src0_sel:BYTE_" #K " src1_sel:BYTE_" #J \
         : "=v"(d) : "v"(a), "v"(p))
@@ -136,7 +141,7 @@ typedef unsigned long long lanemask;
         u32 d0_, d1_, d2_, d3_;                                                                        \
         lanemask b0_, b1_, b2_, b3_, c0_, c1_, c2_, c3_;                                               \
         Q_SUB(d0_, O0, K0, P, J0); Q_SUB(d1_, O1, K1, P, J1); Q_SUB(d2_, O2, K2, P, J2); Q_SUB(d3_, O3, K3, P, J3); \
-        u32 q0_ = slut[d0_], q1_ = slut[d1_], q2_ = slut[d2_], q3_ = slut[d3_];                        \
+        u32 q0_ = lut_at(d0_), q1_ = lut_at(d1_), q2_ = lut_at(d2_), q3_ = lut_at(d3_);                \
         Q_LT(b0_, O0, K0, P, J0); Q_LT(b1_, O1, K1, P, J1); Q_LT(b2_, O2, K2, P, J2); Q_LT(b3_, O3, K3, P, J3); \
         Q_GT(c0_, q0_, NP, J0); Q_GT(c1_, q1_, NP, J1); Q_GT(c2_, q2_, NP, J2); Q_GT(c3_, q3_, NP, J3); \
         Q_SEL(O0, K0, b0_, c0_, q0_, d0_); Q_SEL(O1, K1, b1_, c1_, q1_, d1_);                          \
@@ -148,7 +153,7 @@ typedef unsigned long long lanemask;
         u32 d_, np_ = ~(p);                                                                            \
         lanemask b_, c_;                                                                               \
         Q_SUB(d_, a, 0, p, 0);                                                                         \
-        u32 q_ = slut[d_];                                                                             \
+        u32 q_ = lut_at(d_);                                                                           \
         Q_LT(b_, a, 0, p, 0);                                                                          \
         Q_GT(c_, q_, np_, 0);                                                                          \
         asm("s_xor_b64 vcc, %1, %2\n\tv_cndmask_b32_e32 %0, %3, %4, vcc"                               \
@@ -1335,9 +1340,12 @@ __global__ __launch_bounds__(NL) __attribute__((amdgpu_waves_per_eu(IDENT ? HGI_
 {
     extern __shared__ __attribute__((aligned(16))) u8 smem[];
     const int nh = k >= 2 ? (int)k : 1;
-    u8 *buf = smem - HCOL;
-    u8 *rbuf = smem + buf_bytes(nh) - RCOL;
-    u8 *slut = smem + buf_bytes(nh) + rbuf_bytes(nh);
+    // the table first, at LDS offset 0: a residual byte then IS the address of its table entry (lut_at(); the
+    // planes behind it have a size that depends on k).  Dynamic LDS starts at 0 because the kernel has no static LDS.
+    u8 *slut = smem;
+    if ((u32)reinterpret_cast<uintptr_t>(smem) != 0u) __builtin_trap();
+    u8 *buf = smem + 256 - HCOL;
+    u8 *rbuf = smem + 256 + buf_bytes(nh) - RCOL;
     const u32 W = f.width, H = f.height;
     const BlockRole role = block_role(g);
     if (role.idle) return;
