@@ -135,6 +135,14 @@ bool use_small_tiles(uint32_t w, uint32_t h, uint32_t k, size_t batch)
     return tiles64 < 1536;
 }
 
+// Deep pyramids: the one-workgroup-per-frame kernel for the levels above the fused depth, when the lattice plane is
+// small (hgi_kernels.hip).  HGI_NO_LATTICE_KERNEL in the environment keeps the recursive path (tests).
+bool use_lattice_kernel(const SubGeom &g, size_t batch)
+{
+    static const bool off = getenv("HGI_NO_LATTICE_KERNEL") != nullptr;
+    return !off && lattice_pyramid_fits(g.sw, g.sh, batch);
+}
+
 hipError_t launch_encode_fused(const uint8_t *img, uint8_t *grid, const Frames &f, uint32_t k, int interp,
                                const Lut256 &lut, bool ident, const Seeds *seeds, hipStream_t s)
 {
@@ -195,9 +203,14 @@ hgi_status encode_impl(hgi_ctx *c, const uint8_t *img, uint32_t w, uint32_t h, u
         uint8_t *sub_grid = ws_take(c, batch * g.stride);
         uint8_t *sub_rec = ws_take(c, batch * g.stride);
         if (!sub_img || !sub_grid || !sub_rec) return fail(HGI_ENOMEM, "scratch exhausted (lattice planes)");
-        HIP_TRY(launch_gather_lattice(img, f, k, sub_img, g.sw, g.sh, g.stride, c->stream));
-        HGI_TRY(encode_impl(c, sub_img, g.sw, g.sh, levels - k, interp, lut, sub_grid, batch, g.stride));
-        HGI_TRY(decode_impl(c, sub_grid, g.sw, g.sh, levels - k, interp, sub_rec, batch, g.stride));
+        if (use_lattice_kernel(g, batch)) {   // small planes: gather + all upper levels + both seed planes in one launch
+            HIP_TRY(launch_lattice_pyramid(img, f, k, levels - k, interp, l, is_identity(lut), true, sub_grid, sub_rec, g.sw,
+                                           g.sh, g.stride, c->stream));
+        } else {
+            HIP_TRY(launch_gather_lattice(img, f, k, sub_img, g.sw, g.sh, g.stride, c->stream));
+            HGI_TRY(encode_impl(c, sub_img, g.sw, g.sh, levels - k, interp, lut, sub_grid, batch, g.stride));
+            HGI_TRY(decode_impl(c, sub_grid, g.sw, g.sh, levels - k, interp, sub_rec, batch, g.stride));
+        }
         Seeds sd = {sub_rec, sub_grid, g.sw, g.sh, g.stride};
         HIP_TRY(launch_encode_fused(img, grid, f, k, interp, l, is_identity(lut), &sd, c->stream));
     } else {
@@ -227,8 +240,13 @@ hgi_status decode_impl(hgi_ctx *c, const uint8_t *grid, uint32_t w, uint32_t h, 
         uint8_t *sub_grid = ws_take(c, batch * g.stride);
         uint8_t *sub_rec = ws_take(c, batch * g.stride);
         if (!sub_grid || !sub_rec) return fail(HGI_ENOMEM, "scratch exhausted (lattice planes)");
-        HIP_TRY(launch_gather_lattice(grid, f, k, sub_grid, g.sw, g.sh, g.stride, c->stream));
-        HGI_TRY(decode_impl(c, sub_grid, g.sw, g.sh, levels - k, interp, sub_rec, batch, g.stride));
+        if (use_lattice_kernel(g, batch)) {
+            HIP_TRY(launch_lattice_pyramid(grid, f, k, levels - k, interp, Lut256{}, true, false, nullptr, sub_rec, g.sw, g.sh,
+                                           g.stride, c->stream));
+        } else {
+            HIP_TRY(launch_gather_lattice(grid, f, k, sub_grid, g.sw, g.sh, g.stride, c->stream));
+            HGI_TRY(decode_impl(c, sub_grid, g.sw, g.sh, levels - k, interp, sub_rec, batch, g.stride));
+        }
         Seeds sd = {sub_rec, nullptr, g.sw, g.sh, g.stride};
         HIP_TRY(launch_decode_fused(grid, img, f, k, interp, &sd, c->stream));
     } else {

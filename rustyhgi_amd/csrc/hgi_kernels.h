@@ -61,6 +61,14 @@ HGI_DECLARE_FUSED(32)
 hipError_t launch_gather_lattice(const uint8_t *src, const Frames &f, uint32_t k, uint8_t *dst,
                                  uint32_t sw, uint32_t sh, uint64_t dst_stride, hipStream_t s);
 
+// The whole upper pyramid (levels above the fused depth k) of every frame in ONE launch, one workgroup per frame, when
+// the lattice plane is small enough (lattice_pyramid_fits): gathers the lattice from `src` (image when encoding, grid
+// when decoding), codes `up` levels in LDS, writes the seed planes (out_q only when encoding).
+bool lattice_pyramid_fits(uint32_t sw, uint32_t sh, size_t batch);
+hipError_t launch_lattice_pyramid(const uint8_t *src, const Frames &f, uint32_t k, uint32_t up, int interp, const Lut256 &lut,
+                                  bool lut_is_identity, bool encode, uint8_t *out_q, uint8_t *out_rec, uint32_t sw,
+                                  uint32_t sh, uint64_t dst_stride, hipStream_t s);
+
 // ---- harness kernels --------------------------------------------------------------------------
 hipError_t launch_synth(int kind, uint64_t seed, uint64_t first_frame, uint8_t *out, const Frames &f,
                         hipStream_t s);

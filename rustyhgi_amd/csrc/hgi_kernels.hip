@@ -87,6 +87,67 @@ __global__ void k_gather_lattice(const u8 *__restrict__ src, Frames f, u32 k, u8
         dst[fr * dst_stride + i] = src[fr * f.frame_stride + (sy << k) * f.width + (sx << k)];
 }
 
+// ---------------------------------------------------------------------------------------------
+// upper part of a deep pyramid, one workgroup per frame
+// ---------------------------------------------------------------------------------------------
+// The lattice = 0 (mod 2^k) of a frame is itself an HGI image with `up` = levels - k levels (same out-of-image rule).
+// When it is small it is not worth three launches (gather, encode, decode -- the encoder needs the lattice's
+// reconstruction as seeds): one workgroup gathers it straight from the frame, runs the `up` levels closed-loop in
+// LDS (src/encoder.rs:45-68 / src/decoder.rs:30-43, cells of a level in parallel) and writes the residual and the
+// reconstruction planes the tile kernels take as seeds.  LDS: [originals -> residuals][reconstruction][table].
+template <int INTERP, bool ENCODE>
+__global__ __launch_bounds__(1024) void k_lattice_pyramid(const u8 *__restrict__ src, Frames f, u32 k, u32 up, Lut256 lut,
+                                                          u32 ident, u8 *__restrict__ out_q, u8 *__restrict__ out_rec,
+                                                          u32 sw, u32 sh, u64 dst_stride)
+{
+    extern __shared__ __attribute__((aligned(16))) u8 lds[];
+    const u32 n = sw * sh, n_al = (n + 15u) & ~15u;
+    u8 *qa = lds, *rec = lds + n_al, *slut = lds + 2 * n_al;
+    const u32 tid = threadIdx.x, nt = blockDim.x;
+    const u8 *fr = src + (size_t)blockIdx.x * f.frame_stride;
+    const u32 bmask = up >= 32 ? ~0u : (1u << up) - 1u;          // base lattice of the sub-image: x, y = 0 (mod 2^up)
+    if (ENCODE && tid < 64) reinterpret_cast<u32 *>(slut)[tid] = lut.w[tid];
+    for (u32 i = tid; i < n; i += nt) {
+        const u32 y = i / sw, x = i - y * sw;
+        const u8 v = fr[((size_t)y << k) * f.width + ((size_t)x << k)];
+        qa[i] = v;
+        rec[i] = (ENCODE || !((x | y) & bmask)) ? v : (u8)0;      // encode: originals; decode: base samples, rest built below
+    }
+    __syncthreads();
+    for (u32 l = 0; l < up; ++l) {
+        const u32 e = up - l, sub = 1u << (e - 1);
+        if (sub >= sw && sub >= sh) continue;                      // no pixel of this level lies inside the plane (uniform)
+        const u32 ncx = ((sw - 1) >> e) + 1, ncy = ((sh - 1) >> e) + 1;
+        for (u32 c = tid; c < ncx * ncy; c += nt) {
+            const u32 cy = c / ncx, cx = c - cy * ncx;
+            const u32 x0 = cx << e, y0 = cy << e, x1 = x0 + (sub << 1), y1 = y0 + (sub << 1);
+            const bool xi = x1 < sw, yi = y1 < sh;                 // src/interpolator.rs:75-82: corners outside read 0
+            const u32 lt = rec[y0 * sw + x0], rt = yi ? rec[y1 * sw + x0] : 0u;
+            const u32 lb = xi ? rec[y0 * sw + x1] : 0u, rb = (xi && yi) ? rec[y1 * sw + x1] : 0u;
+            const u32 p = pred1<INTERP>(lt, rt, lb, rb);
+            const bool xn = x0 + sub < sw, yn = y0 + sub < sh;
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                const bool on = j == 0 ? xn : j == 1 ? yn : (xn && yn);
+                if (!on) continue;
+                const u32 idx = (y0 + (j >= 1 ? sub : 0u)) * sw + x0 + (j != 1 ? sub : 0u);
+                if (ENCODE) {
+                    const u32 q = ident ? ((qa[idx] - p) & 255u) : quant1<false>(qa[idx], p, slut);
+                    qa[idx] = (u8)q;
+                    rec[idx] = (u8)(p + q);
+                } else {
+                    rec[idx] = (u8)(p + qa[idx]);
+                }
+            }
+        }
+        __syncthreads();
+    }
+    for (u32 i = tid; i < n; i += nt) {
+        if (ENCODE) out_q[(size_t)blockIdx.x * dst_stride + i] = qa[i];
+        out_rec[(size_t)blockIdx.x * dst_stride + i] = rec[i];
+    }
+}
+
 __device__ __forceinline__ u64 mix64(u64 z)
 {
     z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
@@ -261,6 +322,42 @@ hipError_t launch_gather_lattice(const uint8_t *src, const Frames &f, uint32_t k
     u64 n = (u64)sw * sh;
     hipLaunchKernelGGL(k_gather_lattice, dim3((u32)((n + 255) / 256), batch_grid_y(f)), dim3(256), 0, s, src, f,
                        k, dst, sw, sh, dst_stride);
+    return hipGetLastError();
+}
+
+bool lattice_pyramid_fits(uint32_t sw, uint32_t sh, size_t batch)
+{
+    const uint64_t n = (uint64_t)sw * sh;
+    // two byte planes + table within 160 KiB of LDS; one workgroup per frame gathers one cache line per lattice point,
+    // so a lone frame with a big plane is better off with the wide gather kernel and the tile kernels
+    if (n > 64 * 1024 || batch > 0x7FFFFFFFull) return false;
+    return n <= 8192 || batch >= 8;
+}
+
+hipError_t launch_lattice_pyramid(const uint8_t *src, const Frames &f, uint32_t k, uint32_t up, int interp, const Lut256 &lut,
+                                  bool ident, bool encode, uint8_t *out_q, uint8_t *out_rec, uint32_t sw, uint32_t sh,
+                                  uint64_t dst_stride, hipStream_t s)
+{
+    const size_t n_al = ((size_t)sw * sh + 15) & ~(size_t)15, lds = 2 * n_al + 256;
+    const dim3 grid(f.batch), block(1024);
+#define HGI_LATTICE(I, E)                                                                                                  \
+    do {                                                                                                                    \
+        static bool big_lds = false;   /* more than 64 KiB of dynamic LDS has to be asked for once per kernel */             \
+        if (lds > 64 * 1024 && !big_lds) {                                                                                  \
+            hipError_t e_ = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_lattice_pyramid<I, E>),                   \
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                    \
+            if (e_ != hipSuccess) return e_;                                                                                \
+            big_lds = true;                                                                                                 \
+        }                                                                                                                   \
+        hipLaunchKernelGGL((k_lattice_pyramid<I, E>), grid, block, lds, s, src, f, k, up, lut, ident ? 1u : 0u, out_q, out_rec, \
+                           sw, sh, dst_stride);                                                                             \
+    } while (0)
+    if (interp == kInterpCrossed) {
+        if (encode) HGI_LATTICE(kInterpCrossed, true); else HGI_LATTICE(kInterpCrossed, false);
+    } else {
+        if (encode) HGI_LATTICE(kInterpLeftTop, true); else HGI_LATTICE(kInterpLeftTop, false);
+    }
+#undef HGI_LATTICE
     return hipGetLastError();
 }
 

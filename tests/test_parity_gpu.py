@@ -503,12 +503,13 @@ def test_hip_graph_capture_and_replay(H, ctxs, oracle):
     ctx.close()
 
 
-@pytest.mark.parametrize("mode", ["HGI_FORCE_CHECKED=1", "HGI_TILE_H=64", "HGI_TILE_H=32"])
+@pytest.mark.parametrize("mode", ["HGI_FORCE_CHECKED=1", "HGI_TILE_H=64", "HGI_TILE_H=32", "HGI_NO_LATTICE_KERNEL=1"])
 def test_forced_code_paths_in_a_child_process(mode):
     """The library picks tile geometry and code path per launch: 128x32 or 128x64 tiles, and the fully checked path only
     for widths that are not multiples of 4 or frames beyond 32-bit offsets.  Each switch is read once per process, so a
     child process re-runs the shape-heavy parity cases with one of them forced: aligned shapes through the checked
-    path, small shapes through 64-row tiles, large ones through 32-row tiles."""
+    path, small shapes through 64-row tiles, large ones through 32-row tiles, deep pyramids through the host recursion
+    instead of the one-workgroup lattice kernel."""
     import os
     import subprocess
     import sys
@@ -517,7 +518,7 @@ def test_forced_code_paths_in_a_child_process(mode):
     here = os.path.dirname(os.path.abspath(__file__))
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(here, "test_parity_gpu.py"), "-m", "gpu", "-q", "-x",
                         "-p", "no:cacheprovider", "-k",
-                        "small_golden or lena_and_fullhd or random_shapes or smooth_images or batch_layouts or fuzz or extreme"],
+                        "small_golden or lena_and_fullhd or random_shapes or smooth_images or batch_layouts or fuzz or extreme or deep_pyramid"],
                        env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, mode + "\n" + r.stdout[-3000:] + r.stderr[-1000:]
 
