@@ -327,11 +327,10 @@ hipError_t launch_gather_lattice(const uint8_t *src, const Frames &f, uint32_t k
 
 bool lattice_pyramid_fits(uint32_t sw, uint32_t sh, size_t batch)
 {
-    const uint64_t n = (uint64_t)sw * sh;
-    // two byte planes + table within 160 KiB of LDS; one workgroup per frame gathers one cache line per lattice point,
-    // so a lone frame with a big plane is better off with the wide gather kernel and the tile kernels
-    if (n > 64 * 1024 || batch > 0x7FFFFFFFull) return false;
-    return n <= 8192 || batch >= 8;
+    // One workgroup per frame: worth it for small planes only (64 x 64 per 4K frame: three launches become one).  At
+    // 256 x 256 -- a lone 16384^2 frame -- the single workgroup takes longer than the tile kernels it would replace
+    // (measured 164 / 140 us against 139 / 114 us for the whole call), so larger planes keep the host recursion.
+    return (uint64_t)sw * sh <= 8192 && batch <= 0x7FFFFFFFull;
 }
 
 hipError_t launch_lattice_pyramid(const uint8_t *src, const Frames &f, uint32_t k, uint32_t up, int interp, const Lut256 &lut,
