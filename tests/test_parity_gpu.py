@@ -416,7 +416,8 @@ def test_fuzz_batches_against_oracle(H, ctxs, oracle):
     lw.set_stream(stream)
     rng = np.random.default_rng(20261004)
     tables = [oracle.noop_lut()] + [oracle.linear_lut(q)[0] for q in range(4)]
-    for case in range(150):
+    import os
+    for case in range(int(os.environ.get("HGI_FUZZ_CASES", "150"))):   # HGI_FUZZ_CASES=1500 for a longer soak
         kind = rng.integers(0, 4)
         if kind == 0:      # multiples of the tile
             W, Hh = 128 * int(rng.integers(1, 6)), 64 * int(rng.integers(1, 5))
