@@ -83,6 +83,19 @@ def cpu_baseline(args, lut, gpu_check):
 
 
 def main():
+    # stdout carries exactly ONE line, the JSON result of rank 0.  Native libraries write there too (RCCL prints a
+    # five-line version banner when a communicator is created), so file descriptor 1 points at stderr for the whole
+    # run and is switched back only around that one print.
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
+
+    def emit(line):
+        sys.stdout.flush()
+        os.dup2(real_stdout, 1)
+        print(line, flush=True)
+        os.dup2(2, 1)
+
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
@@ -100,7 +113,8 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     dist = None
-    if world > 1:
+    # HGI_BENCH_FORCE_DIST=1: take the RCCL code path (init, broadcast, barrier, all-reduce, all-gather) with one rank too
+    if world > 1 or os.environ.get("HGI_BENCH_FORCE_DIST"):
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
@@ -257,7 +271,7 @@ def main():
         if world == 1 and not args.no_cpu:
             check = {"grid": grids[:2].cpu().numpy(), "out": outs[:2].cpu().numpy()}
             line["cpu_baseline"] = cpu_baseline(args, lut, check)
-        print(json.dumps(line), flush=True)
+        emit(json.dumps(line))
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
