@@ -246,16 +246,18 @@ def test_full_size_properties(H, ctxs, oracle, golden):
     ctx.use_own_stream()
 
 
-def test_saturated_device_repeat(H, ctxs, oracle):
+@pytest.mark.parametrize("W,Hh,nf", [(4096, 4096, 18), (1080, 1922, 144), (1001, 999, 300)])
+def test_saturated_device_repeat(H, ctxs, oracle, W, Hh, nf):
     """Every CU busy with many resident waves, noise input (every quantizer branch taken), repeated:
     the configuration that exposed the wide-store data hazard in an experimental build
-    (DESIGN.md 4.5).  18 frames of 4096^2 per launch, 4 launches per direction, bit-exact each time."""
+    (DESIGN.md 4.5).  18 frames of 4096^2 per launch (interior tiles), 144 of 1080x1922 (rows 8 mod 16, a narrow right
+    column and a ragged bottom row: the edge paths and their partial stores) and 300 of 1001x999 (rows not a multiple
+    of 4: the read tail), 4 launches per direction, bit-exact each time."""
     import torch
     from rustyhgi_amd import _ffi
     L, ctx = _ffi.lib(), ctxs["fused"]
     ctx.set_stream(torch.cuda.current_stream().cuda_stream)
-    W = Hh = 4096
-    levels, nf = 4, 18
+    levels = 4
     img = oracle.synth(oracle.SYNTH_NOISE, SEED0, 0, W, Hh)
     lut = oracle.linear_lut(2)[0]
     grid = oracle.encode(img, levels, lut)

@@ -1,6 +1,6 @@
 """Saturation stress: many frames of noise per launch, both directions, repeated; any mismatch against the
 oracle is described by its position inside the tile (library selectable with HGI_LIB_PATH).
-usage: stress.py [tile_h] [reps] [frames] [levels] [q]"""
+usage: stress.py [tile_h] [reps] [frames] [levels] [q]   (STRESS_W / STRESS_H: frame size, default 4096 x 4096)"""
 import sys, numpy as np, torch
 sys.path.insert(0, __import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.abspath(__file__))))
 from oracle import hgi_oracle as O
@@ -13,7 +13,7 @@ NF = int(sys.argv[3]) if len(sys.argv) > 3 else 18
 LEVELS = int(sys.argv[4]) if len(sys.argv) > 4 else 4
 Q = int(sys.argv[5]) if len(sys.argv) > 5 else 2
 ctx = H.Context(0); ctx.set_stream(torch.cuda.current_stream().cuda_stream)
-W = Hh = 4096
+W = int(__import__('os').environ.get("STRESS_W", "4096")); Hh = int(__import__('os').environ.get("STRESS_H", "4096"))
 img = O.synth(O.SYNTH_NOISE, 0x48474933, 0, W, Hh)
 lut = O.linear_lut(Q)[0]
 grid = O.encode(img, LEVELS, lut); want = O.decode(grid, LEVELS)
