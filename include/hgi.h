@@ -106,6 +106,18 @@ hgi_status hgi_decode_u8_dev(hgi_ctx *ctx, const void *d_grid, uint32_t width, u
                              uint32_t levels, hgi_interp interp, void *d_img, size_t batch,
                              size_t frame_stride);
 
+/* ---- host-pointer batch calls ------------------------------------------------------------ */
+/* `batch` frames in HOST memory, frame f at base + f * frame_stride (frame_stride >= w*h). */
+/* Synchronous like hgi_encode_u8 / hgi_decode_u8, but the frames are pipelined through the  */
+/* device in chunks on two internal streams, so uploads overlap downloads (PCIe is full      */
+/* duplex) and the kernels disappear behind the transfers.  Input and output must not alias. */
+hgi_status hgi_encode_u8_batch(hgi_ctx *ctx, const uint8_t *imgs, uint32_t width, uint32_t height,
+                               uint32_t levels, hgi_interp interp, const uint8_t lut[256],
+                               uint8_t *grids_out, size_t batch, size_t frame_stride);
+hgi_status hgi_decode_u8_batch(hgi_ctx *ctx, const uint8_t *grids, uint32_t width, uint32_t height,
+                               uint32_t levels, hgi_interp interp, uint8_t *imgs_out, size_t batch,
+                               size_t frame_stride);
+
 /* ---- entropy front end (no counterpart in the reference, would precede the   */
 /* DEFLATE of src/archive.rs:36) ---------------------------------------------------------- */
 /* Byte histogram of each frame of a grid batch, on the device, async on the ctx stream:     */

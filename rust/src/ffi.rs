@@ -25,6 +25,11 @@ extern "C" {
     pub fn hgi_decode_u8_dev(ctx: *mut HgiCtx, d_grid: *const c_void, width: u32, height: u32, levels: u32,
                              interp: c_int, d_img: *mut c_void, batch: usize, frame_stride: usize) -> c_int;
     pub fn hgi_sync(ctx: *mut HgiCtx) -> c_int;
+    /// include/hgi.h: `batch` frames in host memory, pipelined through the device (uploads overlap downloads)
+    pub fn hgi_encode_u8_batch(ctx: *mut HgiCtx, imgs: *const u8, width: u32, height: u32, levels: u32, interp: c_int,
+                               lut: *const u8, grids_out: *mut u8, batch: usize, frame_stride: usize) -> c_int;
+    pub fn hgi_decode_u8_batch(ctx: *mut HgiCtx, grids: *const u8, width: u32, height: u32, levels: u32, interp: c_int,
+                               imgs_out: *mut u8, batch: usize, frame_stride: usize) -> c_int;
     /// include/hgi.h: per-frame byte histogram of a grid batch on the device (d_hist: 256 * batch u64)
     pub fn hgi_histogram_u8_dev(ctx: *mut HgiCtx, d_grid: *const c_void, width: u32, height: u32, batch: usize,
                                 frame_stride: usize, d_hist: *mut c_void) -> c_int;

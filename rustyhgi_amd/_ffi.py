@@ -25,6 +25,8 @@ SYMBOLS = [
     ("hgi_ctx_set_path", _int, [_vp, _int]),
     ("hgi_ctx_reserve", _int, [_vp, _u32, _u32, _u32, _sz]),
     ("hgi_histogram_u8_dev", _int, [_vp, _vp, _u32, _u32, _sz, _sz, _vp]),
+    ("hgi_encode_u8_batch", _int, [_vp, _vp, _u32, _u32, _u32, _int, _vp, _vp, _sz, _sz]),
+    ("hgi_decode_u8_batch", _int, [_vp, _vp, _u32, _u32, _u32, _int, _vp, _sz, _sz]),
     ("hgi_sync", _int, [_vp]),
     ("hgi_last_error", ctypes.c_char_p, []),
     ("hgi_version", ctypes.c_char_p, []),

@@ -79,7 +79,20 @@ class Encoder:
         return Grid(grid, w)
 
     def encode_batch(self, images, out=None):
-        """(B, H, W) uint8 CUDA tensor -> (B, H, W) residual planes, asynchronous on the current stream."""
+        """(B, H, W) uint8 CUDA tensor -> (B, H, W) residual planes, asynchronous on the current stream.
+        A (B, H, W) numpy array (host memory) goes through hgi_encode_u8_batch instead: synchronous, the frames
+        pipelined through the device so that uploads overlap downloads."""
+        if not _is_torch(images):
+            imgs = np.ascontiguousarray(images, dtype=np.uint8)
+            if imgs.ndim != 3:
+                raise ValueError("expected a (batch, height, width) stack")
+            b, h, w = imgs.shape
+            if out is None:
+                out = np.empty_like(imgs)
+            ctx = self._ctx or _ffi.default_context(0)
+            _ffi.check(_ffi.lib().hgi_encode_u8_batch(ctx.handle, imgs.ctypes.data, w, h, self.scale_level, self._interp,
+                                                      self._lut.ctypes.data, out.ctypes.data, b, h * w))
+            return out
         import torch
         ctx = _torch_ctx(images, self._ctx)
         b, h, w = images.shape
@@ -115,6 +128,18 @@ class Decoder:
         return img
 
     def decode_batch(self, grids, levels, out=None):
+        """CUDA tensor: asynchronous on the current stream; numpy stack: hgi_decode_u8_batch (see Encoder.encode_batch)."""
+        if not _is_torch(grids):
+            g = np.ascontiguousarray(grids, dtype=np.uint8)
+            if g.ndim != 3:
+                raise ValueError("expected a (batch, height, width) stack")
+            b, h, w = g.shape
+            if out is None:
+                out = np.empty_like(g)
+            ctx = self._ctx or _ffi.default_context(0)
+            _ffi.check(_ffi.lib().hgi_decode_u8_batch(ctx.handle, g.ctypes.data, w, h, int(levels), self._interp,
+                                                      out.ctypes.data, b, h * w))
+            return out
         import torch
         ctx = _torch_ctx(grids, self._ctx)
         b, h, w = grids.shape

@@ -59,6 +59,8 @@ def test_histogram_argument_checks_need_no_device():
     L = _ffi.lib()
     out = (ctypes.c_uint64 * 256)()
     assert L.hgi_histogram_u8_dev(None, None, 8, 8, 1, 64, out) == _ffi.EINVAL      # NULL ctx
+    assert L.hgi_encode_u8_batch(None, None, 8, 8, 2, 1, None, None, 2, 64) == _ffi.EINVAL
+    assert L.hgi_decode_u8_batch(None, None, 8, 8, 2, 1, None, 2, 64) == _ffi.EINVAL
     assert b"ctx" in L.hgi_last_error()
 
 

@@ -640,3 +640,48 @@ def test_device_histogram_matches_bincount(H, ctxs, oracle):
     assert L.hgi_histogram_u8_dev(ctx.handle, None, 8, 8, 1, 64, out.data_ptr()) == _ffi.EINVAL
     assert L.hgi_histogram_u8_dev(ctx.handle, buf.data_ptr(), 8, 8, 2, 10, out.data_ptr()) == _ffi.EINVAL
     ctx.use_own_stream()
+
+
+def test_host_batch_calls_pipeline_and_match(H, ctxs, oracle):
+    """hgi_encode_u8_batch / hgi_decode_u8_batch: frames in host memory, pipelined through the device in chunks on two
+    streams.  Bit-exact per frame for chunk sizes of one frame and of several, a deep pyramid (per-chunk scratch
+    planes), padded strides, a single frame, and a device call on the same context right afterwards."""
+    import torch
+    from rustyhgi_amd import _ffi
+    L = _ffi.lib()
+    ctx = H.Context(0)
+    rng = np.random.default_rng(11)
+    for (B, W, Hh, levels, pad) in [(5, 1920, 1080, 4, 0), (3, 4096, 4096, 4, 0), (37, 256, 200, 5, 0), (4, 1000, 700, 9, 64),
+                                    (1, 640, 480, 3, 0), (2, 1001, 333, 7, 5)]:
+        n, stride = W * Hh, W * Hh + pad
+        lut = oracle.linear_lut(2)[0]
+        host = np.full(B * stride, 0x33, np.uint8)
+        frames = [oracle.synth(oracle.SYNTH_RAMP, SEED0 + 5, f, W, Hh) if W * Hh > 1 << 20 else rng.integers(0, 256, (Hh, W), dtype=np.uint8)
+                  for f in range(B)]
+        for f in range(B):
+            host[f * stride: f * stride + n] = frames[f].reshape(-1)
+        grids = np.full(B * stride, 0xEE, np.uint8)
+        outs = np.full(B * stride, 0xDD, np.uint8)
+        _ffi.check(L.hgi_encode_u8_batch(ctx.handle, host.ctypes.data, W, Hh, levels, 1, lut.ctypes.data, grids.ctypes.data, B, stride))
+        _ffi.check(L.hgi_decode_u8_batch(ctx.handle, grids.ctypes.data, W, Hh, levels, 1, outs.ctypes.data, B, stride))
+        for f in range(B):
+            want = oracle.encode(frames[f], levels, lut)
+            assert_same(grids[f * stride: f * stride + n].reshape(Hh, W), want, "encode batch %dx%dx%d L%d frame %d" % (B, W, Hh, levels, f))
+            assert_same(outs[f * stride: f * stride + n].reshape(Hh, W), oracle.decode(want, levels), "decode batch frame %d" % f)
+            if pad:
+                assert (grids[f * stride + n: (f + 1) * stride] == 0xEE).all() and (outs[f * stride + n: (f + 1) * stride] == 0xDD).all()
+    # the Python front end on a numpy stack, and the context is still good for device calls afterwards
+    stack = np.stack([oracle.synth(oracle.SYNTH_XY, 0, f, 800, 600) for f in range(6)])
+    enc = H.Encoder(H.interpolator.Crossed(), H.quantizator.Linear.from_level(H.quantizator.QuantizationLevel.Low), 4, context=ctx)
+    dec = H.Decoder(H.interpolator.Crossed(), context=ctx)
+    g = enc.encode_batch(stack)
+    o = dec.decode_batch(g, 4)
+    lut1 = oracle.linear_lut(1)[0]
+    for f in range(6):
+        want = oracle.encode(stack[f], 4, lut1)
+        assert_same(g[f], want, "numpy stack encode %d" % f)
+        assert_same(o[f], oracle.decode(want, 4), "numpy stack decode %d" % f)
+    t = torch.from_numpy(stack).cuda()
+    assert torch.equal(enc.encode_batch(t).cpu(), torch.from_numpy(g))
+    assert L.hgi_encode_u8_batch(ctx.handle, stack.ctypes.data, 800, 600, 4, 1, lut1.ctypes.data, stack.ctypes.data, 6, 480000) == _ffi.EINVAL
+    ctx.close()
