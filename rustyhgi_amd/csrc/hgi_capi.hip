@@ -5,6 +5,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <vector>
 
 #include "../../include/hgi.h"
 #include "hgi_kernels.h"
@@ -53,6 +54,7 @@ struct hgi_ctx {
     // three device slots, per slot one event "uploaded" and one "kernels done, input slot free"
     hipStream_t pipe[2];
     hipEvent_t ev_up[3], ev_free[3];
+    hipEvent_t ev_band[16];   // banded single-frame calls: "band uploaded"
     bool have_pipe;
 };
 
@@ -149,17 +151,19 @@ bool use_lattice_kernel(const SubGeom &g, size_t batch)
 }
 
 hipError_t launch_encode_fused(const uint8_t *img, uint8_t *grid, const Frames &f, uint32_t k, int interp,
-                               const Lut256 &lut, bool ident, const Seeds *seeds, hipStream_t s)
+                               const Lut256 &lut, bool ident, const Seeds *seeds, hipStream_t s, uint32_t row_limit = 0)
 {
-    return use_small_tiles(f.width, f.height, k, f.batch) ? launch_encode_fused_32(img, grid, f, k, interp, lut, ident, seeds, s)
-                                                          : launch_encode_fused_64(img, grid, f, k, interp, lut, ident, seeds, s);
+    const uint32_t rows = row_limit && row_limit < f.height ? row_limit : f.height;   // what this launch really covers
+    return use_small_tiles(f.width, rows, k, f.batch) ? launch_encode_fused_32(img, grid, f, k, interp, lut, ident, seeds, s, row_limit)
+                                                      : launch_encode_fused_64(img, grid, f, k, interp, lut, ident, seeds, s, row_limit);
 }
 
 hipError_t launch_decode_fused(const uint8_t *grid, uint8_t *img, const Frames &f, uint32_t k, int interp,
-                               const Seeds *seeds, hipStream_t s)
+                               const Seeds *seeds, hipStream_t s, uint32_t row_limit = 0)
 {
-    return use_small_tiles(f.width, f.height, k, f.batch) ? launch_decode_fused_32(grid, img, f, k, interp, seeds, s)
-                                                          : launch_decode_fused_64(grid, img, f, k, interp, seeds, s);
+    const uint32_t rows = row_limit && row_limit < f.height ? row_limit : f.height;
+    return use_small_tiles(f.width, rows, k, f.batch) ? launch_decode_fused_32(grid, img, f, k, interp, seeds, s, row_limit)
+                                                      : launch_decode_fused_64(grid, img, f, k, interp, seeds, s, row_limit);
 }
 
 Lut256 pack_lut(const uint8_t lut[256])
@@ -326,6 +330,7 @@ void hgi_ctx_destroy(hgi_ctx *c)
             (void)hipEventDestroy(c->ev_up[i]);
             (void)hipEventDestroy(c->ev_free[i]);
         }
+        for (int i = 0; i < 16; ++i) (void)hipEventDestroy(c->ev_band[i]);
     }
     delete c;
 }
@@ -423,6 +428,9 @@ hgi_status hgi_decode_u8_dev(hgi_ctx *c, const void *d_grid, uint32_t w, uint32_
                        static_cast<uint8_t *>(d_img), batch, frame_stride);
 }
 
+static hgi_status host_banded(hgi_ctx *c, const uint8_t *in, uint8_t *out, uint32_t w, uint32_t h, uint32_t levels,
+                              hgi_interp interp, const uint8_t *lut, bool encode);
+
 // Host-pointer forms: stage through device scratch (PCIe-bound; never the number that is benchmarked).
 static hgi_status host_roundtrip(hgi_ctx *c, const uint8_t *in, uint8_t *out, uint32_t w, uint32_t h,
                                  uint32_t levels, hgi_interp interp, const uint8_t *lut, bool encode)
@@ -432,6 +440,10 @@ static hgi_status host_roundtrip(hgi_ctx *c, const uint8_t *in, uint8_t *out, ui
     if (w == 0 || h == 0) return HGI_OK;
     HIP_TRY(hipSetDevice(c->device));
     const size_t n = (size_t)w * h, slot = align_up(n, 256) + 256;
+    // large frames with a pyramid one tile deep: band the frame so that its upload and download overlap
+    if (n >= (4u << 20) && levels >= 1 && levels <= (uint32_t)kFusedMaxLevels && c->path != HGI_PATH_LEVELWISE && h >= 256 &&
+        !getenv("HGI_NO_BANDS"))
+        return host_banded(c, in, out, w, h, levels, interp, lut, encode);
     HGI_TRY(ws_ensure(c, ws_need(c, w, h, levels, 1, n) + 2 * slot));
     c->ws_used = 0;
     uint8_t *d_in = ws_take(c, n), *d_out = ws_take(c, n);
@@ -443,6 +455,79 @@ static hgi_status host_roundtrip(hgi_ctx *c, const uint8_t *in, uint8_t *out, ui
         HGI_TRY(decode_impl(c, d_in, w, h, levels, interp, d_out, 1, n));
     HIP_TRY(hipMemcpyAsync(out, d_out, n, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
+    return HGI_OK;
+}
+
+static hgi_status pipe_ensure(hgi_ctx *c)
+{
+    if (c->have_pipe) return HGI_OK;
+    bool ok = hipStreamCreateWithFlags(&c->pipe[0], hipStreamNonBlocking) == hipSuccess;
+    ok = ok && hipStreamCreateWithFlags(&c->pipe[1], hipStreamNonBlocking) == hipSuccess;
+    for (int i = 0; i < 3 && ok; ++i)
+        ok = hipEventCreateWithFlags(&c->ev_up[i], hipEventDisableTiming) == hipSuccess &&
+             hipEventCreateWithFlags(&c->ev_free[i], hipEventDisableTiming) == hipSuccess;
+    for (int i = 0; i < 16 && ok; ++i) ok = hipEventCreateWithFlags(&c->ev_band[i], hipEventDisableTiming) == hipSuccess;
+    if (!ok) return fail(HGI_EDEVICE, "stream/event creation failed");   // (a partial set is reclaimed with the process)
+    c->have_pipe = true;
+    return HGI_OK;
+}
+
+// One LARGE frame in host memory: the same overlap inside the frame.  A tile only depends on input pixels of its own
+// rows and of the <= 64 halo rows below them, so a band of tile rows can be coded as soon as its rows and the next band
+// are on the device, and downloaded while the bands further down still upload.  No kernel change: each band is a
+// launch of the standard kernel on a row-shifted view of the frame (true remaining height, so the out-of-image rule is
+// exact) limited to the band's tile rows.  Only for pyramids one tile deep (levels <= 6): deeper ones need the whole
+// lattice first.
+static hgi_status host_banded(hgi_ctx *c, const uint8_t *in, uint8_t *out, uint32_t w, uint32_t h, uint32_t levels,
+                              hgi_interp interp, const uint8_t *lut, bool encode)
+{
+    const size_t n = (size_t)w * h;
+    HGI_TRY(pipe_ensure(c));
+    const size_t slot = align_up(n, 256) + 256;
+    HGI_TRY(ws_ensure(c, 2 * slot));
+    c->ws_used = 0;
+    uint8_t *d_in = ws_take(c, n), *d_out = ws_take(c, n);
+    if (!d_in || !d_out) return fail(HGI_ENOMEM, "scratch exhausted (host staging)");
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    // bands of about 4 MiB (per-band fixed costs: two copies, an event, a launch), whole multiples of 64 rows, 2..16 bands
+    uint32_t band = (uint32_t)(((4u << 20) / w + 63) / 64 * 64);
+    if (band < 64) band = 64;
+    if (band >= h) band = (h / 2 + 63) / 64 * 64;
+    while ((h + band - 1) / band > 16) band += 64;
+    const uint32_t nb = (h + band - 1) / band;
+    const bool reg_in = hipHostRegister(const_cast<uint8_t *>(in), n, hipHostRegisterDefault) == hipSuccess;
+    const bool reg_out = hipHostRegister(out, n, hipHostRegisterDefault) == hipSuccess;
+    (void)hipGetLastError();
+    hipStream_t up = c->pipe[0], down = c->pipe[1];
+    const Lut256 l = encode ? pack_lut(lut) : Lut256{};
+    const bool ident = encode && is_identity(lut);
+    hipError_t e = hipSuccess;
+    // upload stream: band b goes up together with its 64 halo rows (the first rows of band b + 1), so that its kernel
+    // waits for nothing else; band b + 1 then starts below them
+    for (uint32_t b = 0; b < nb && e == hipSuccess; ++b) {
+        const size_t y0 = b ? (size_t)b * band + 64 : 0;
+        size_t y1 = (size_t)(b + 1) * band + 64;
+        if (y1 > h) y1 = h;
+        if (y1 > y0) e = hipMemcpyAsync(d_in + y0 * w, in + y0 * w, (y1 - y0) * w, hipMemcpyHostToDevice, up);
+        if (e == hipSuccess) e = hipEventRecord(c->ev_band[b], up);
+    }
+    // compute + download stream
+    for (uint32_t b = 0; b < nb && e == hipSuccess; ++b) {
+        const size_t y0 = (size_t)b * band, rows = y0 + band <= h ? band : h - y0;
+        e = hipStreamWaitEvent(down, c->ev_band[b], 0);
+        if (e != hipSuccess) break;
+        const Frames f = {w, (uint32_t)(h - y0), (uint64_t)((size_t)(h - y0) * w), 1};
+        const uint32_t limit = b + 1 < nb ? band : 0;
+        e = encode ? launch_encode_fused(d_in + y0 * w, d_out + y0 * w, f, levels, interp, l, ident, nullptr, down, limit)
+                   : launch_decode_fused(d_in + y0 * w, d_out + y0 * w, f, levels, interp, nullptr, down, limit);
+        if (e == hipSuccess) e = hipMemcpyAsync(out + y0 * w, d_out + y0 * w, rows * w, hipMemcpyDeviceToHost, down);
+    }
+    const hipError_t e0 = hipStreamSynchronize(up), e1 = hipStreamSynchronize(down);
+    if (reg_in) (void)hipHostUnregister(const_cast<uint8_t *>(in));
+    if (reg_out) (void)hipHostUnregister(out);
+    c->ws_used = 0;
+    if (e != hipSuccess || e0 != hipSuccess || e1 != hipSuccess)
+        return fail(HGI_EDEVICE, "%s", hipGetErrorString(e != hipSuccess ? e : e0 != hipSuccess ? e0 : e1));
     return HGI_OK;
 }
 
@@ -460,15 +545,7 @@ static hgi_status host_batch(hgi_ctx *c, const uint8_t *in, uint8_t *out, uint32
     if (batch == 1) frame_stride = n;
     HIP_TRY(hipSetDevice(c->device));
     constexpr int kSlots = 3;
-    if (!c->have_pipe) {
-        bool ok = hipStreamCreateWithFlags(&c->pipe[0], hipStreamNonBlocking) == hipSuccess;
-        ok = ok && hipStreamCreateWithFlags(&c->pipe[1], hipStreamNonBlocking) == hipSuccess;
-        for (int i = 0; i < kSlots && ok; ++i)
-            ok = hipEventCreateWithFlags(&c->ev_up[i], hipEventDisableTiming) == hipSuccess &&
-                 hipEventCreateWithFlags(&c->ev_free[i], hipEventDisableTiming) == hipSuccess;
-        if (!ok) return fail(HGI_EDEVICE, "stream/event creation failed");   // (a partial set is reclaimed with the process)
-        c->have_pipe = true;
-    }
+    HGI_TRY(pipe_ensure(c));
     // chunks of about 8 MiB (at least one frame), and at least two chunks when there are two frames to overlap
     size_t fpc = (8u << 20) / n;
     if (fpc < 1) fpc = 1;

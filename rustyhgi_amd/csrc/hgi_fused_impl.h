@@ -1401,12 +1401,16 @@ struct FusedGeom {
     bool ok;
 };
 
-FusedGeom fused_geom(const void *a, const void *b, const Frames &f)
+// row_limit (pixel rows, a multiple of 64; 0 = none): only the tile rows above it are launched.  The frame keeps its
+// true height, so the out-of-image rule is untouched -- this is how a band of a frame is coded while the rows further
+// down are still being uploaded (hgi_capi.hip, host-pointer calls).
+FusedGeom fused_geom(const void *a, const void *b, const Frames &f, u32 row_limit)
 {
     FusedGeom r;
     TileGrid &g = r.g;
     g.tiles_x = (f.width + TW - 1) / TW;
     g.tiles_y = (f.height + TH - 1) / TH;
+    if (row_limit && row_limit / TH < g.tiles_y) g.tiles_y = row_limit / TH;
     const bool aligned = f.width % 16 == 0 && f.frame_stride % 16 == 0 && ptr16(a) && ptr16(b);
     // every 32-bit buffer offset the fast path forms: (Y0 + TH + 64) * W + X0 + TW + 64 + 16
     const bool fits32 = ((u64)f.height + 2 * TH + 64) * f.width + 1024 < (1ull << 32);
@@ -1423,6 +1427,7 @@ FusedGeom fused_geom(const void *a, const void *b, const Frames &f)
     const bool fast = fits32 && (dword_rows || tail_ok) && !force_checked;
     g.full_x = fast ? f.width / TW : 0;
     g.full_y = fast ? f.height / TH : 0;
+    if (g.full_y > g.tiles_y) g.full_y = g.tiles_y;
     if (g.full_x == 0 || g.full_y == 0) g.full_x = g.full_y = 0;
     const u64 all = (u64)g.tiles_x * g.tiles_y * f.batch, nfast = (u64)g.full_x * g.full_y * f.batch;
     r.ok = all > 0 && all + 8 < (1ull << 31);
@@ -1438,9 +1443,9 @@ FusedGeom fused_geom(const void *a, const void *b, const Frames &f)
 
 #ifdef HGI_FUSED_DECODE
 hipError_t HGI_TILED(launch_decode_fused)(const uint8_t *grid, uint8_t *img, const Frames &f, uint32_t k, int interp,
-                                          const Seeds *seeds, hipStream_t s)
+                                          const Seeds *seeds, hipStream_t s, uint32_t row_limit)
 {
-    FusedGeom r = fused_geom(grid, img, f);
+    FusedGeom r = fused_geom(grid, img, f, row_limit);
     if (!r.ok || k < 1 || k > (u32)MAXK) return hipErrorInvalidValue;
     const TileGrid &g = r.g;
     Seeds sd = seeds ? *seeds : Seeds{nullptr, nullptr, 0, 0, 0};
@@ -1462,9 +1467,9 @@ hipError_t HGI_TILED(launch_decode_fused)(const uint8_t *grid, uint8_t *img, con
 
 #ifdef HGI_FUSED_ENCODE
 hipError_t HGI_TILED(launch_encode_fused)(const uint8_t *img, uint8_t *grid, const Frames &f, uint32_t k, int interp,
-                                          const Lut256 &lut, bool ident, const Seeds *seeds, hipStream_t s)
+                                          const Lut256 &lut, bool ident, const Seeds *seeds, hipStream_t s, uint32_t row_limit)
 {
-    FusedGeom r = fused_geom(img, grid, f);
+    FusedGeom r = fused_geom(img, grid, f, row_limit);
     if (!r.ok || k < 1 || k > (u32)MAXK) return hipErrorInvalidValue;
     const TileGrid &g = r.g;
     Seeds sd = seeds ? *seeds : Seeds{nullptr, nullptr, 0, 0, 0};

@@ -685,3 +685,16 @@ def test_host_batch_calls_pipeline_and_match(H, ctxs, oracle):
     assert torch.equal(enc.encode_batch(t).cpu(), torch.from_numpy(g))
     assert L.hgi_encode_u8_batch(ctx.handle, stack.ctypes.data, 800, 600, 4, 1, lut1.ctypes.data, stack.ctypes.data, 6, 480000) == _ffi.EINVAL
     ctx.close()
+
+
+@pytest.mark.parametrize("w,h,levels", [(4096, 1100, 4), (1001, 4500, 5), (8192, 600, 3), (2048, 2500, 6), (5000, 1000, 1),
+                                        (4096, 4096, 2)])
+def test_banded_host_frames(ctxs, oracle, w, h, levels):
+    """Host-pointer calls on frames of >= 4 MiB with a pyramid one tile deep are banded: the frame is uploaded, coded and
+    downloaded in bands of tile rows on two streams.  Band boundaries (64-row multiples), the halo rows a band shares
+    with the next one, ragged bottoms and odd widths must all be bit-exact."""
+    img = oracle.synth(oracle.SYNTH_NOISE, SEED0 + 13, levels, w, h)
+    lut = oracle.linear_lut(2)[0]
+    want = oracle.encode(img, levels, lut)
+    assert_same(gpu_encode(ctxs["fused"], img, levels, lut), want, "banded encode %dx%d L%d" % (w, h, levels))
+    assert_same(gpu_decode(ctxs["fused"], want, levels), oracle.decode(want, levels), "banded decode %dx%d L%d" % (w, h, levels))
