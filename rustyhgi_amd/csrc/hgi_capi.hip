@@ -441,8 +441,7 @@ static hgi_status host_roundtrip(hgi_ctx *c, const uint8_t *in, uint8_t *out, ui
     HIP_TRY(hipSetDevice(c->device));
     const size_t n = (size_t)w * h, slot = align_up(n, 256) + 256;
     // large frames with a pyramid one tile deep: band the frame so that its upload and download overlap
-    if (n >= (4u << 20) && levels >= 1 && levels <= (uint32_t)kFusedMaxLevels && c->path != HGI_PATH_LEVELWISE && h >= 256 &&
-        !getenv("HGI_NO_BANDS"))
+    if (n >= (4u << 20) && levels >= 1 && c->path != HGI_PATH_LEVELWISE && h >= 256 && !getenv("HGI_NO_BANDS"))
         return host_banded(c, in, out, w, h, levels, interp, lut, encode);
     HGI_TRY(ws_ensure(c, ws_need(c, w, h, levels, 1, n) + 2 * slot));
     c->ws_used = 0;
@@ -476,19 +475,39 @@ static hgi_status pipe_ensure(hgi_ctx *c)
 // rows and of the <= 64 halo rows below them, so a band of tile rows can be coded as soon as its rows and the next band
 // are on the device, and downloaded while the bands further down still upload.  No kernel change: each band is a
 // launch of the standard kernel on a row-shifted view of the frame (true remaining height, so the out-of-image rule is
-// exact) limited to the band's tile rows.  Only for pyramids one tile deep (levels <= 6): deeper ones need the whole
-// lattice first.
+// exact) limited to the band's tile rows.  Pyramids deeper than a tile need the stride-64 lattice of the WHOLE frame
+// first: that is gathered on the host (65 536 bytes for 16384^2) and uploaded ahead of the bands.
 static hgi_status host_banded(hgi_ctx *c, const uint8_t *in, uint8_t *out, uint32_t w, uint32_t h, uint32_t levels,
                               hgi_interp interp, const uint8_t *lut, bool encode)
 {
     const size_t n = (size_t)w * h;
     HGI_TRY(pipe_ensure(c));
     const size_t slot = align_up(n, 256) + 256;
-    HGI_TRY(ws_ensure(c, 2 * slot));
+    HGI_TRY(ws_ensure(c, 2 * slot + ws_need(c, w, h, levels, 1, n) + 1024));
     c->ws_used = 0;
     uint8_t *d_in = ws_take(c, n), *d_out = ws_take(c, n);
     if (!d_in || !d_out) return fail(HGI_ENOMEM, "scratch exhausted (host staging)");
     HIP_TRY(hipStreamSynchronize(c->stream));
+    // Pyramids deeper than a tile: the stride-2^k lattice (every 64th pixel of every 64th row) is gathered on the host --
+    // it is tiny -- and goes up first; its seeds are ready long before the first band is.
+    const uint32_t k = levels < (uint32_t)kFusedMaxLevels ? levels : (uint32_t)kFusedMaxLevels;
+    const bool deep = levels > k;
+    SubGeom g = {0, 0, 0};
+    uint8_t *sub_src = nullptr, *sub_grid = nullptr, *sub_rec = nullptr;
+    std::vector<uint8_t> lattice;
+    if (deep) {
+        g = sub_geom(w, h, k);
+        sub_src = ws_take(c, g.stride);
+        sub_grid = encode ? ws_take(c, g.stride) : sub_src;     // decoding: the gathered plane IS the lattice's grid
+        sub_rec = ws_take(c, g.stride);
+        if (!sub_src || !sub_grid || !sub_rec) return fail(HGI_ENOMEM, "scratch exhausted (lattice planes)");
+        lattice.resize((size_t)g.sw * g.sh);
+        for (uint32_t sy = 0; sy < g.sh; ++sy) {
+            const uint8_t *row = in + ((size_t)sy << k) * w;
+            uint8_t *dstp = lattice.data() + (size_t)sy * g.sw;
+            for (uint32_t sx = 0; sx < g.sw; ++sx) dstp[sx] = row[(size_t)sx << k];
+        }
+    }
     // bands of about 4 MiB (per-band fixed costs: two copies, an event, a launch), whole multiples of 64 rows, 2..16 bands
     uint32_t band = (uint32_t)(((4u << 20) / w + 63) / 64 * 64);
     if (band < 64) band = 64;
@@ -502,6 +521,22 @@ static hgi_status host_banded(hgi_ctx *c, const uint8_t *in, uint8_t *out, uint3
     const Lut256 l = encode ? pack_lut(lut) : Lut256{};
     const bool ident = encode && is_identity(lut);
     hipError_t e = hipSuccess;
+    hgi_status st = HGI_OK;
+    if (deep) {     // lattice -> seeds, ordered before the first band's kernel.  The upload goes on the upload stream:
+                    // a stream that has issued a copy in one direction tends to keep its copies on that DMA engine, and
+                    // downloads queued behind the sixteen band uploads would wait for all of them (measured: 10.4 ms
+                    // instead of 6.4 ms for 16384^2)
+        e = hipMemcpyAsync(sub_src, lattice.data(), lattice.size(), hipMemcpyHostToDevice, up);
+        if (e == hipSuccess) e = hipEventRecord(c->ev_up[0], up);
+        if (e == hipSuccess) e = hipStreamWaitEvent(down, c->ev_up[0], 0);
+        if (e == hipSuccess) {
+            hipStream_t saved = c->stream;
+            c->stream = down;
+            if (encode) st = encode_impl(c, sub_src, g.sw, g.sh, levels - k, interp, lut, sub_grid, 1, g.stride);
+            if (st == HGI_OK) st = decode_impl(c, sub_grid, g.sw, g.sh, levels - k, interp, sub_rec, 1, g.stride);
+            c->stream = saved;
+        }
+    }
     // upload stream: band b goes up together with its 64 halo rows (the first rows of band b + 1), so that its kernel
     // waits for nothing else; band b + 1 then starts below them
     for (uint32_t b = 0; b < nb && e == hipSuccess; ++b) {
@@ -512,20 +547,25 @@ static hgi_status host_banded(hgi_ctx *c, const uint8_t *in, uint8_t *out, uint3
         if (e == hipSuccess) e = hipEventRecord(c->ev_band[b], up);
     }
     // compute + download stream
-    for (uint32_t b = 0; b < nb && e == hipSuccess; ++b) {
+    for (uint32_t b = 0; b < nb && e == hipSuccess && st == HGI_OK; ++b) {
         const size_t y0 = (size_t)b * band, rows = y0 + band <= h ? band : h - y0;
         e = hipStreamWaitEvent(down, c->ev_band[b], 0);
         if (e != hipSuccess) break;
         const Frames f = {w, (uint32_t)(h - y0), (uint64_t)((size_t)(h - y0) * w), 1};
         const uint32_t limit = b + 1 < nb ? band : 0;
-        e = encode ? launch_encode_fused(d_in + y0 * w, d_out + y0 * w, f, levels, interp, l, ident, nullptr, down, limit)
-                   : launch_decode_fused(d_in + y0 * w, d_out + y0 * w, f, levels, interp, nullptr, down, limit);
+        // the view starts y0 rows down (a multiple of 64 = 2^6 >= 2^k): its seeds start y0 >> k lattice rows down
+        const size_t ly = y0 >> k;
+        const Seeds sd = {deep ? sub_rec + ly * g.sw : nullptr, deep && encode ? sub_grid + ly * g.sw : nullptr, g.sw,
+                          deep ? (uint32_t)(g.sh - ly) : 0u, g.stride};
+        e = encode ? launch_encode_fused(d_in + y0 * w, d_out + y0 * w, f, k, interp, l, ident, deep ? &sd : nullptr, down, limit)
+                   : launch_decode_fused(d_in + y0 * w, d_out + y0 * w, f, k, interp, deep ? &sd : nullptr, down, limit);
         if (e == hipSuccess) e = hipMemcpyAsync(out + y0 * w, d_out + y0 * w, rows * w, hipMemcpyDeviceToHost, down);
     }
     const hipError_t e0 = hipStreamSynchronize(up), e1 = hipStreamSynchronize(down);
     if (reg_in) (void)hipHostUnregister(const_cast<uint8_t *>(in));
     if (reg_out) (void)hipHostUnregister(out);
     c->ws_used = 0;
+    if (st != HGI_OK) return st;
     if (e != hipSuccess || e0 != hipSuccess || e1 != hipSuccess)
         return fail(HGI_EDEVICE, "%s", hipGetErrorString(e != hipSuccess ? e : e0 != hipSuccess ? e0 : e1));
     return HGI_OK;

@@ -688,11 +688,13 @@ def test_host_batch_calls_pipeline_and_match(H, ctxs, oracle):
 
 
 @pytest.mark.parametrize("w,h,levels", [(4096, 1100, 4), (1001, 4500, 5), (8192, 600, 3), (2048, 2500, 6), (5000, 1000, 1),
-                                        (4096, 4096, 2)])
+                                        (4096, 4096, 2), (4096, 1100, 8), (2048, 2500, 9), (1001, 4500, 7), (8192, 600, 13),
+                                        (4096, 4096, 31)])
 def test_banded_host_frames(ctxs, oracle, w, h, levels):
     """Host-pointer calls on frames of >= 4 MiB with a pyramid one tile deep are banded: the frame is uploaded, coded and
     downloaded in bands of tile rows on two streams.  Band boundaries (64-row multiples), the halo rows a band shares
-    with the next one, ragged bottoms and odd widths must all be bit-exact."""
+    with the next one, ragged bottoms and odd widths must all be bit-exact -- also for pyramids deeper than a tile, whose
+    lattice is gathered on the host, uploaded first, and handed to the bands as row-shifted seed planes."""
     img = oracle.synth(oracle.SYNTH_NOISE, SEED0 + 13, levels, w, h)
     lut = oracle.linear_lut(2)[0]
     want = oracle.encode(img, levels, lut)

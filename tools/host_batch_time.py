@@ -29,9 +29,9 @@ for (B, W, Hh) in [(32, 1920, 1080), (16, 4096, 4096), (64, 4096, 4096), (256, 5
         B, W, Hh, t1 * 1e3, gb / t1, t2 * 1e3, gb / t2, t1 / t2, t3 * 1e3))
 
 # one large frame at a time: the banded host path (HGI_NO_BANDS=1 in the environment turns it off)
-for (W, Hh) in [(1920, 1080), (4096, 4096), (8192, 8192), (16384, 16384)]:
+for (W, Hh, LV) in [(1920, 1080, 4), (4096, 4096, 4), (8192, 8192, 4), (16384, 16384, 4), (16384, 16384, 8)]:
     src = np.random.default_rng(2).integers(0, 256, (Hh, W), dtype=np.uint8); dst = np.empty_like(src); back = np.empty_like(src)
-    te = best(lambda: _ffi.check(L.hgi_encode_u8(ctx.handle, src.ctypes.data, W, Hh, 4, 1, lut.ctypes.data, dst.ctypes.data)))
-    td = best(lambda: _ffi.check(L.hgi_decode_u8(ctx.handle, dst.ctypes.data, W, Hh, 4, 1, back.ctypes.data)))
-    print("single host frame %5dx%5d: hgi_encode_u8 %8.3f ms (%5.1f GB/s in)  hgi_decode_u8 %8.3f ms   bands %s" % (
-        W, Hh, te * 1e3, W * Hh / te / 1e9, td * 1e3, "off" if os.environ.get("HGI_NO_BANDS") else "on"))
+    te = best(lambda: _ffi.check(L.hgi_encode_u8(ctx.handle, src.ctypes.data, W, Hh, LV, 1, lut.ctypes.data, dst.ctypes.data)))
+    td = best(lambda: _ffi.check(L.hgi_decode_u8(ctx.handle, dst.ctypes.data, W, Hh, LV, 1, back.ctypes.data)))
+    print("single host frame %5dx%5d L%d: hgi_encode_u8 %8.3f ms (%5.1f GB/s in)  hgi_decode_u8 %8.3f ms   bands %s" % (
+        W, Hh, LV, te * 1e3, W * Hh / te / 1e9, td * 1e3, "off" if os.environ.get("HGI_NO_BANDS") else "on"))
