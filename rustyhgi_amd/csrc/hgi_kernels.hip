@@ -10,6 +10,8 @@
 // Level-wise: one launch per level, one thread per step-cell, global-memory stencil.  Simple and
 // strided; kept as the on-device cross-check and for measuring single passes.
 // All arithmetic is u8/integer; there is no MFMA-shaped work on this path.
+#include <stdlib.h>
+
 #include "hgi_dev.h"
 
 namespace hgi {
@@ -330,7 +332,11 @@ bool lattice_pyramid_fits(uint32_t sw, uint32_t sh, size_t batch)
     // One workgroup per frame: worth it for small planes only (64 x 64 per 4K frame: three launches become one).  At
     // 256 x 256 -- a lone 16384^2 frame -- the single workgroup takes longer than the tile kernels it would replace
     // (measured 164 / 140 us against 139 / 114 us for the whole call), so larger planes keep the host recursion.
-    return (uint64_t)sw * sh <= 8192 && batch <= 0x7FFFFFFFull;
+    static const uint64_t limit = [] {
+        const char *e = getenv("HGI_LATTICE_MAX");     // experiments: largest plane (points) the kernel takes
+        return e ? (uint64_t)atoll(e) : (uint64_t)8192;
+    }();
+    return (uint64_t)sw * sh <= limit && (uint64_t)sw * sh <= 64 * 1024 && batch <= 0x7FFFFFFFull;
 }
 
 hipError_t launch_lattice_pyramid(const uint8_t *src, const Frames &f, uint32_t k, uint32_t up, int interp, const Lut256 &lut,
