@@ -2,64 +2,73 @@
 """Headline benchmark: Mpixels/s of HGI encode+decode on 4096x4096 u8 frames, level=4, Medium.
 
   python bench.py --gpus N --steps K --warmup W
-  (N > 1: python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...)
+
+N > 1 without a rendezvous in the environment: this process becomes a LAUNCHER -- it never touches the GPU, starts
+`python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...` as a child (one rank per GPU over
+RCCL), relays rank 0's JSON line and exits with the child's code.  Started under torchrun (WORLD_SIZE set) it is a
+rank, as before.
 
 One step = one pass of the hot path over this rank's batch: encode `frames` frames, then decode
 them (BASELINE.json config C3, sharded by frame; frames are generated in place on each GPU from the
 global frame index, so no pixel ever crosses xGMI).  Inputs are resident in HBM before the timed
 region.  RCCL is used only where the batch split needs it: broadcast of the quantizer table and
 all-gather of per-rank checksums.  Rank 0 prints ONE JSON line.
+
+--rehearse: the same launcher, rendezvous, broadcast, sharding, barrier/timing and gather code on the CPU with the
+gloo backend and NO codec work (there is no CPU codec in the product): what the CPU test suite runs to show that
+`python bench.py --gpus 2` starts two ranks and returns one line.  Its line carries "rehearsal": true and value null.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
 import numpy as np
-import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
-
-import rustyhgi_amd as H                      # noqa: E402
-from rustyhgi_amd import _ffi, batch          # noqa: E402
-from rustyhgi_amd.interpolator import Crossed  # noqa: E402
-from rustyhgi_amd.quantizator import Linear, QuantizationLevel, Quantizator  # noqa: E402
 
 SEED0 = 0x48474930
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec (guide: MI355X_MICROARCH.md, chip-level parameters)
 
 
-class TableQuantizator(Quantizator):
+def table_quantizator(table, error):
     """A quantizer received as its 256-entry table (what rank 0 broadcasts)."""
+    from rustyhgi_amd.quantizator import Quantizator
 
-    def __init__(self, table, error):
-        self._t, self._e = np.ascontiguousarray(table, np.uint8), int(error)
+    class TableQuantizator(Quantizator):
+        def __init__(self, t, e):
+            self._t, self._e = np.ascontiguousarray(t, np.uint8), int(e)
 
-    def quantize(self, value):
-        return int(self._t[value & 0xFF])
+        def quantize(self, value):
+            return int(self._t[value & 0xFF])
 
-    def error(self):
-        return self._e
+        def error(self):
+            return self._e
 
-    def table(self):
-        return self._t.copy()
+        def table(self):
+            return self._t.copy()
+
+    return TableQuantizator(table, error)
 
 
 def pmc_traffic(kernel, frames, size, levels):
     """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (FETCH_SIZE with the
     gfx950 x2 correction + WRITE_SIZE; tools/profile.sh -> profiles/*_traffic.json), if that profile was
     taken on this exact workload; else None.  bench.py cannot run the profiler on itself."""
-    path = os.path.join(ROOT, "profiles", "r01_traffic.json")
-    try:
-        with open(path) as f:
-            prof = json.load(f)
-        if prof["workload"] != {"frames": frames, "size": size, "levels": levels}:
-            return None
-        return prof["kernels"][kernel]["hbm_bytes_per_launch"]
-    except (OSError, KeyError, ValueError):
-        return None
+    for name in ("r02_traffic.json", "r01_traffic.json"):      # newest committed profile of this workload
+        try:
+            with open(os.path.join(ROOT, "profiles", name)) as f:
+                prof = json.load(f)
+            if prof["workload"] != {"frames": frames, "size": size, "levels": levels}:
+                continue
+            return prof["kernels"][kernel]["hbm_bytes_per_launch"]
+        except (OSError, KeyError, ValueError):
+            continue
+    return None
 
 
 def cpu_baseline(args, lut, gpu_check):
@@ -82,7 +91,50 @@ def cpu_baseline(args, lut, gpu_check):
             "one_thread_mpix_s": round(px / (r["enc_cpu_s"] + r["dec_cpu_s"]) / 1e6, 1)}
 
 
-def main():
+def parse_args(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--frames", type=int, default=64, help="frames per GPU per step (C3: 512 / 8)")
+    ap.add_argument("--size", type=int, default=4096)
+    ap.add_argument("--levels", type=int, default=4)
+    ap.add_argument("--quant", default="medium")
+    ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--no-pfine", action="store_true", help="skip the P_fine (levels = 1) leg")
+    ap.add_argument("--xgmi-scatter", action="store_true",
+                    help="also time the labelled variant where all frames start and end on GPU 0 (scatter, code, gather)")
+    ap.add_argument("--rehearse", action="store_true",
+                    help="CPU rehearsal of the multi-rank plumbing (gloo, no codec work, value null)")
+    return ap.parse_args(argv)
+
+
+def free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def launch(args, argv):
+    """--gpus N > 1 and no rendezvous in the environment: start the N ranks.  This process makes no HIP / torch.cuda
+    call and replaces nothing (no exec): the ranks are children of a torch.distributed.run child, their stdout is ours."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.abspath(__file__)] + list(argv)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC: what RCCL needs on this pool
+    env.setdefault("OMP_NUM_THREADS", "1")
+    return subprocess.call(cmd, env=env)
+
+
+def main(argv=None):
+    argv = sys.argv[1:] if argv is None else list(argv)
+    args = parse_args(argv)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return launch(args, argv)
+    return run_rank(args)
+
+
+def run_rank(args):
     # stdout carries exactly ONE line, the JSON result of rank 0.  Native libraries write there too (RCCL prints a
     # five-line version banner when a communicator is created), so file descriptor 1 points at stderr for the whole
     # run and is switched back only around that one print.
@@ -96,31 +148,34 @@ def main():
         print(line, flush=True)
         os.dup2(2, 1)
 
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--frames", type=int, default=64, help="frames per GPU per step (C3: 512 / 8)")
-    ap.add_argument("--size", type=int, default=4096)
-    ap.add_argument("--levels", type=int, default=4)
-    ap.add_argument("--quant", default="medium")
-    ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
-    ap.add_argument("--xgmi-scatter", action="store_true",
-                    help="also time the labelled variant where all frames start and end on GPU 0 (scatter, code, gather)")
-    args = ap.parse_args()
+    import torch
+    from rustyhgi_amd import batch
+    from rustyhgi_amd.quantizator import Linear, QuantizationLevel
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        print("bench.py: --gpus %d but WORLD_SIZE=%d" % (args.gpus, world), file=sys.stderr)
+        return 2
+    rehearse = args.rehearse
+    dev = torch.device("cpu") if rehearse else torch.device("cuda", local)
     dist = None
     # HGI_BENCH_FORCE_DIST=1: take the RCCL code path (init, broadcast, barrier, all-reduce, all-gather) with one rank too
     if world > 1 or os.environ.get("HGI_BENCH_FORCE_DIST"):
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
-    assert world == args.gpus, "--gpus %d but WORLD_SIZE=%d" % (args.gpus, world)
-    torch.cuda.set_device(local)
-    dev = torch.device("cuda", local)
+        os.environ.setdefault("MASTER_PORT", str(free_port()))
+        if rehearse:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        print("bench.py: rank %d/%d joined (%s)" % (rank, world, dist.get_backend()), file=sys.stderr)
+    if not rehearse:
+        torch.cuda.set_device(local)
+    if os.environ.get("HGI_BENCH_FAIL_RANK") == str(rank):      # tests: a rank that dies must fail the whole run
+        print("bench.py: rank %d failing on request" % rank, file=sys.stderr)
+        os._exit(3)
 
     # ---- batch split: rank 0 owns the parameters; table + levels go out by RCCL broadcast ----
     level = QuantizationLevel.parse(args.quant)
@@ -129,110 +184,71 @@ def main():
         lut, err, levels = batch.broadcast_params(dist, dev, q.table(), q.error(), args.levels)
     else:
         lut, err, levels = batch.broadcast_params(dist, dev)
+    if dist is not None:
+        print("bench.py: rank %d has the broadcast parameters (levels %d, max error %d)" % (rank, levels, err), file=sys.stderr)
 
-    # a real (non-null) stream made current for torch: the codec launches, the timing events and the
-    # torch ops around them all live on it
-    stream = torch.cuda.Stream(dev)
-    torch.cuda.set_stream(stream)
-    ctx = H.Context(local)
-    ctx.set_stream(stream.cuda_stream)
     F, S = args.frames, args.size
-    ctx.reserve(S, S, levels, F)
-    imgs = torch.empty((F, S, S), dtype=torch.uint8, device=dev)
-    grids = torch.empty_like(imgs)
-    outs = torch.empty_like(imgs)
     # frame f of rank r is global frame r*F + f of config C3 (ramp(3)): produced where it is used
     first, count = batch.shard(world * F, world, rank)
     assert count == F
-    _ffi.check(_ffi.lib().hgi_synth_u8_dev(ctx.handle, _ffi.SYNTH_RAMP, SEED0 + 3, first, S, S,
-                                           imgs.data_ptr(), F, S * S))
-    enc = H.Encoder(Crossed(), TableQuantizator(lut, err), levels, context=ctx)
-    dec = H.Decoder(Crossed(), context=ctx)
 
-    def step():
-        enc.encode_batch(imgs, out=grids)
-        dec.decode_batch(grids, levels, out=outs)
-
-    def fence():
-        torch.cuda.synchronize(dev)
-        if dist is not None:
-            dist.barrier()
+    def sync():
+        if not rehearse:
             torch.cuda.synchronize(dev)
 
+    def fence():
+        sync()
+        if dist is not None:
+            dist.barrier()
+            sync()
+
+    if rehearse:
+        codec = None
+    else:
+        codec = Codec(args, dev, local, lut, err, levels, first)
+
     for _ in range(args.warmup):
-        step()
-    ev = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(args.steps)]
+        if codec:
+            codec.step()
+    if codec:
+        codec.make_events(args.steps)
     fence()
     t0 = time.perf_counter()
     for k in range(args.steps):
-        ev[k][0].record()
-        enc.encode_batch(imgs, out=grids)
-        ev[k][1].record()
-        dec.decode_batch(grids, levels, out=outs)
-        ev[k][2].record()
+        if codec:
+            codec.timed_step(k)
     fence()
     elapsed = batch.max_over_ranks(dist, time.perf_counter() - t0, dev)
 
-    enc_ms = float(np.mean([e[0].elapsed_time(e[1]) for e in ev]))
-    dec_ms = float(np.mean([e[1].elapsed_time(e[2]) for e in ev]))
-
-    # same-run reference point: a plain 16-B/lane streaming copy of the same 2 x F frames of traffic
-    copy_ms = None
-    if rank == 0:
-        ce = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
-        n = F * S * S
-        for i in range(6):
-            if i == 1:
-                ce[0].record()
-            _ffi.check(_ffi.lib().hgi_copy_u8_dev(ctx.handle, imgs.data_ptr(), outs.data_ptr(), n))
-        ce[1].record()
-        torch.cuda.synchronize(dev)
-        copy_ms = ce[0].elapsed_time(ce[1]) / 5
-        dec.decode_batch(grids, levels, out=outs)      # restore the decoded frames the checks below read
-        torch.cuda.synchronize(dev)
-
-    # ---- optional, separately labelled: every frame starts and ends on GPU 0.  Bound by the
-    # source GPU's xGMI links, not by the codec; never part of `value`.
-    xgmi = None
-    if args.xgmi_scatter:
-        allf = torch.empty((world * F, S, S), dtype=torch.uint8, device=dev) if rank == 0 else None
-        allo = torch.empty_like(allf) if rank == 0 else None
+    if rehearse:
+        # what the ranks would gather: [squared error, max error, checksum] -- here the shard itself, so that the
+        # launcher test can see that every rank took its own block
+        mine = torch.tensor([first, count, rank], dtype=torch.int64)
+        allst = batch.gather_stats(dist, mine)
         if rank == 0:
-            _ffi.check(_ffi.lib().hgi_synth_u8_dev(ctx.handle, _ffi.SYNTH_RAMP, SEED0 + 3, 0, S, S,
-                                                   allf.data_ptr(), world * F, S * S))
-        mine_in = torch.empty_like(imgs)
+            emit(json.dumps({
+                "metric": "Mpixels/s encode+decode, 4K grayscale level=4 Medium", "value": None, "unit": "Mpixels/s",
+                "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                "ms_per_step": round(elapsed / max(args.steps, 1) * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+                "vs_baseline": None, "dtype": "u8", "data": "none", "rehearsal": True,
+                "config": {"workload": "rehearsal of the rank plumbing on the CPU (gloo): no codec work",
+                           "frames_per_gpu": F, "global_frames": world * F, "parallelism": "frames sharded x%d" % world,
+                           "levels": levels, "max_error": err, "table_sum": int(np.asarray(lut, np.int64).sum()),
+                           "shards": [[int(a), int(b)] for a, b, _ in allst]}}))
+        if dist is not None:
+            dist.barrier()
+            dist.destroy_process_group()
+        return 0
 
-        def xstep():
-            batch.scatter_frames(dist, allf, mine_in)
-            enc.encode_batch(mine_in, out=grids)
-            dec.decode_batch(grids, levels, out=outs)
-            batch.gather_frames(dist, outs, allo)
-
-        xstep()
-        fence()
-        t1 = time.perf_counter()
-        nx = max(1, min(args.steps, 5))
-        for _ in range(nx):
-            xstep()
-        fence()
-        xs = batch.max_over_ranks(dist, time.perf_counter() - t1, dev) / nx
-        if rank == 0:
-            same = bool(torch.equal(allo[:F], outs)) and int((allf[:F].to(torch.int16) - allo[:F].to(torch.int16)).abs().max()) <= err
-            xgmi = {"ms_per_step": round(xs * 1e3, 4), "value": round(world * F * S * S / xs / 1e6, 1), "unit": "Mpixels/s",
-                    "bytes_over_links_per_step": 2 * (world - 1) * F * S * S, "roundtrip_ok": same,
-                    "note": "frames scattered from and gathered to GPU 0 (torch.distributed scatter/gather over RCCL); "
-                            "per-link bound, reported beside the sharded number, never as it"}
-        del allf, allo, mine_in
-        dec.decode_batch(grids, levels, out=outs)
-        torch.cuda.synchronize(dev)
+    enc_ms, dec_ms = codec.mean_ms()
+    copy_ms = codec.copy_ms() if rank == 0 else None
+    pfine = codec.p_fine() if rank == 0 and not args.no_pfine else None
+    xgmi = codec.xgmi(dist, world, rank, fence, args.steps) if args.xgmi_scatter else None
 
     # ---- per-rank checks + stats gather (RCCL all-gather) ----
-    stats = torch.zeros(3 * F, dtype=torch.int64, device=dev)
-    _ffi.check(_ffi.lib().hgi_diff_stats_dev(ctx.handle, imgs.data_ptr(), outs.data_ptr(), S, S, F, S * S,
-                                             stats.data_ptr()))
-    st = stats.view(F, 3)
-    mine = torch.stack([st[:, 0].sum(), st[:, 1].max(), grids.view(-1)[::4099].to(torch.int64).sum()])
-    allst = batch.gather_stats(dist, mine)
+    allst = batch.gather_stats(dist, codec.stats())
+    if dist is not None:
+        print("bench.py: rank %d gathered the statistics of %d ranks" % (rank, len(allst)), file=sys.stderr)
     if not os.environ.get("HGI_BENCH_NOCHECK"):   # timing-only experiments produce wrong pixels
         assert int(allst[:, 1].max()) <= err, "reconstruction error exceeds the quantizer bound"
 
@@ -252,6 +268,7 @@ def main():
             "config": {"workload": "C3 shard: %d frames/GPU of %dx%d u8 ramp(3), level=%d %s, Crossed, "
                                    "encode then decode, HBM-resident" % (F, S, S, levels, level.name),
                        "frames_per_gpu": F, "global_frames": world * F, "parallelism": "frames sharded x%d" % world,
+                       "collectives": "none" if dist is None else "%s: broadcast(258 B) + all_reduce(max) + all_gather(24 B)" % dist.get_backend(),
                        "encode_ms": round(enc_ms, 4), "decode_ms": round(dec_ms, 4),
                        "max_abs_err": int(allst[:, 1].max()), "sq_err_sum": int(allst[:, 0].sum()),
                        "grid_checksums": [int(v) for v in allst[:, 2]]},
@@ -266,17 +283,179 @@ def main():
                                            "avg_launch_ms": round(copy_ms, 4),
                                            "note": "16-B/lane copy kernel moving the same bytes"}},
         }
+        if pfine is not None:
+            line["p_fine"] = pfine
         if xgmi is not None:
             line["xgmi_scatter_gather"] = xgmi
         if world == 1 and not args.no_cpu:
-            check = {"grid": grids[:2].cpu().numpy(), "out": outs[:2].cpu().numpy()}
-            line["cpu_baseline"] = cpu_baseline(args, lut, check)
+            line["cpu_baseline"] = cpu_baseline(args, lut, codec.sample())
         emit(json.dumps(line))
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
-    ctx.close()
+    codec.close()
+    return 0
+
+
+class Codec:
+    """This rank's frames, contexts and timed steps on its GPU."""
+
+    def __init__(self, args, dev, local, lut, err, levels, first):
+        import torch
+        import rustyhgi_amd as H
+        from rustyhgi_amd import _ffi
+        from rustyhgi_amd.interpolator import Crossed
+        self.torch, self.H, self._ffi, self.Crossed = torch, H, _ffi, Crossed
+        self.args, self.dev, self.lut, self.err, self.levels = args, dev, lut, err, levels
+        # a real (non-null) stream made current for torch: the codec launches, the timing events and the
+        # torch ops around them all live on it
+        self.stream = torch.cuda.Stream(dev)
+        torch.cuda.set_stream(self.stream)
+        self.ctx = ctx = H.Context(local)
+        ctx.set_stream(self.stream.cuda_stream)
+        F, S = args.frames, args.size
+        self.F, self.S = F, S
+        ctx.reserve(S, S, levels, F)
+        self.imgs = torch.empty((F, S, S), dtype=torch.uint8, device=dev)
+        self.grids = torch.empty_like(self.imgs)
+        self.outs = torch.empty_like(self.imgs)
+        _ffi.check(_ffi.lib().hgi_synth_u8_dev(ctx.handle, _ffi.SYNTH_RAMP, SEED0 + 3, first, S, S,
+                                               self.imgs.data_ptr(), F, S * S))
+        self.quant = table_quantizator(lut, err)
+        self.enc = H.Encoder(Crossed(), self.quant, levels, context=ctx)
+        self.dec = H.Decoder(Crossed(), context=ctx)
+        self.ev = []
+
+    def step(self):
+        self.enc.encode_batch(self.imgs, out=self.grids)
+        self.dec.decode_batch(self.grids, self.levels, out=self.outs)
+
+    def make_events(self, steps):
+        self.ev = [[self.torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(steps)]
+
+    def timed_step(self, k):
+        ev = self.ev[k]
+        ev[0].record()
+        self.enc.encode_batch(self.imgs, out=self.grids)
+        ev[1].record()
+        self.dec.decode_batch(self.grids, self.levels, out=self.outs)
+        ev[2].record()
+
+    def mean_ms(self):
+        return (float(np.mean([e[0].elapsed_time(e[1]) for e in self.ev])),
+                float(np.mean([e[1].elapsed_time(e[2]) for e in self.ev])))
+
+    def _timed(self, fn, reps, warm=1):
+        torch = self.torch
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        for _ in range(warm):
+            fn()
+        a.record()
+        for _ in range(reps):
+            fn()
+        b.record()
+        torch.cuda.synchronize(self.dev)
+        return a.elapsed_time(b) / reps
+
+    def copy_ms(self):
+        """same-run reference point: a plain 16-B/lane streaming copy of the same 2 x F frames of traffic"""
+        n = self.F * self.S * self.S
+        L, ctx = self._ffi.lib(), self.ctx
+        ms = self._timed(lambda: self._ffi.check(L.hgi_copy_u8_dev(ctx.handle, self.imgs.data_ptr(), self.outs.data_ptr(), n)), 5)
+        self._restore()
+        return ms
+
+    def _restore(self):
+        self.enc.encode_batch(self.imgs, out=self.grids)
+        self.dec.decode_batch(self.grids, self.levels, out=self.outs)      # the decoded frames the checks read
+        self.torch.cuda.synchronize(self.dev)
+
+    def p_fine(self):
+        """The finest pass alone (SURVEY 8(d) `P_fine`; the north star's "level-0 interpolation pass", reference
+        src/utils.rs:16-18 with e = 1): the product kernels at levels = 1 on the same frames.  At levels = 1 the lattice
+        is the even/even quarter of the pixels, which the launch copies through, so it MOVES 2 B/px; the pass as SURVEY
+        accounts it is 1.75 B/px (reads N, writes the 3/4 N new pixels)."""
+        H, F, S = self.H, self.F, self.S
+        enc1 = H.Encoder(self.Crossed(), self.quant, 1, context=self.ctx)
+        reps = max(5, min(self.args.steps, 20))
+        # alternating encode -> decode like the bench step (same-direction launches back to back run ~4 % faster)
+        ev = [[self.torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(reps)]
+        for i in range(2 + reps):
+            e = ev[max(i - 2, 0)]
+            e[0].record()
+            enc1.encode_batch(self.imgs, out=self.grids)
+            e[1].record()
+            self.dec.decode_batch(self.grids, 1, out=self.outs)
+            e[2].record()
+        self.torch.cuda.synchronize(self.dev)
+        e_ms = float(np.mean([e[0].elapsed_time(e[1]) for e in ev]))
+        d_ms = float(np.mean([e[1].elapsed_time(e[2]) for e in ev]))
+        err1 = int((self.imgs[:2].to(self.torch.int16) - self.outs[:2].to(self.torch.int16)).abs().max())
+        self._restore()
+        alg, moved = 1.75 * F * S * S, 2.0 * F * S * S
+        slow = max(e_ms, d_ms)
+        return {"workload": "finest pass alone: k_enc_tiles / k_dec_tiles at levels=1 on the same %d frames" % F,
+                "encode_ms": round(e_ms, 4), "decode_ms": round(d_ms, 4), "max_abs_err": err1,
+                "algorithmic_bytes_per_launch": alg, "moved_bytes_per_launch": moved,
+                "achieved": round(alg / (slow * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(alg / (slow * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                "moved_frac": round(moved / (slow * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                "note": "1.75 B/px algorithmic (3/4 of the pixels are new); the launch also copies the 1/4 lattice "
+                        "through, so 2 B/px cross HBM; frac uses the slower direction"}
+
+    def xgmi(self, dist, world, rank, fence, steps):
+        """optional, separately labelled: every frame starts and ends on GPU 0.  Bound by the
+        source GPU's xGMI links, not by the codec; never part of `value`."""
+        torch, _ffi = self.torch, self._ffi
+        from rustyhgi_amd import batch
+        F, S, dev = self.F, self.S, self.dev
+        allf = torch.empty((world * F, S, S), dtype=torch.uint8, device=dev) if rank == 0 else None
+        allo = torch.empty_like(allf) if rank == 0 else None
+        if rank == 0:
+            _ffi.check(_ffi.lib().hgi_synth_u8_dev(self.ctx.handle, _ffi.SYNTH_RAMP, SEED0 + 3, 0, S, S,
+                                                   allf.data_ptr(), world * F, S * S))
+        mine_in = torch.empty_like(self.imgs)
+
+        def xstep():
+            batch.scatter_frames(dist, allf, mine_in)
+            self.enc.encode_batch(mine_in, out=self.grids)
+            self.dec.decode_batch(self.grids, self.levels, out=self.outs)
+            batch.gather_frames(dist, self.outs, allo)
+
+        xstep()
+        fence()
+        t1 = time.perf_counter()
+        nx = max(1, min(steps, 5))
+        for _ in range(nx):
+            xstep()
+        fence()
+        xs = batch.max_over_ranks(dist, time.perf_counter() - t1, dev) / nx
+        res = None
+        if rank == 0:
+            same = bool(torch.equal(allo[:F], self.outs)) and \
+                int((allf[:F].to(torch.int16) - allo[:F].to(torch.int16)).abs().max()) <= self.err
+            res = {"ms_per_step": round(xs * 1e3, 4), "value": round(world * F * S * S / xs / 1e6, 1), "unit": "Mpixels/s",
+                   "bytes_over_links_per_step": 2 * (world - 1) * F * S * S, "roundtrip_ok": same,
+                   "note": "frames scattered from and gathered to GPU 0 (torch.distributed scatter/gather over RCCL); "
+                           "per-link bound, reported beside the sharded number, never as it"}
+        del allf, allo, mine_in
+        self._restore()
+        return res
+
+    def stats(self):
+        torch, _ffi, F, S = self.torch, self._ffi, self.F, self.S
+        stats = torch.zeros(3 * F, dtype=torch.int64, device=self.dev)
+        _ffi.check(_ffi.lib().hgi_diff_stats_dev(self.ctx.handle, self.imgs.data_ptr(), self.outs.data_ptr(), S, S, F, S * S,
+                                                 stats.data_ptr()))
+        st = stats.view(F, 3)
+        return torch.stack([st[:, 0].sum(), st[:, 1].max(), self.grids.view(-1)[::4099].to(torch.int64).sum()])
+
+    def sample(self):
+        return {"grid": self.grids[:2].cpu().numpy(), "out": self.outs[:2].cpu().numpy()}
+
+    def close(self):
+        self.ctx.close()
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

@@ -273,9 +273,15 @@ hgi_status check_common(hgi_ctx *c, const void *a, const void *b, uint32_t level
         return fail(HGI_EUNSUPPORTED, "interpolator %d not implemented (0 = LeftTop, 1 = Crossed)", interp);
     if (w == 0 || h == 0 || batch == 0) return HGI_OK;
     if (!a || !b) return fail(HGI_EINVAL, "NULL buffer");
-    if (a == b) return fail(HGI_EINVAL, "input and output must not alias");
     if (batch > 1 && stride < (size_t)w * h) return fail(HGI_EINVAL, "frame_stride %zu < width*height", stride);
     if (batch > 0x7fffffffu) return fail(HGI_EINVAL, "batch too large");
+    // The byte ranges [p, p + span) of input and output must be disjoint: the kernels read a tile's halo from frames the
+    // neighbouring tiles are writing.  (The reference consumes its input by value, src/encoder.rs:39: aliasing cannot
+    // happen there.)  Host and device pointers are compared alike -- under unified addressing they share one space.
+    const uintptr_t pa = reinterpret_cast<uintptr_t>(a), pb = reinterpret_cast<uintptr_t>(b);
+    const uintptr_t span = (uintptr_t)(batch - 1) * (batch > 1 ? stride : 0) + (uintptr_t)w * h;
+    if (pa < pb + span && pb < pa + span)
+        return fail(HGI_EINVAL, "input and output overlap (%zu bytes each): they must not alias", (size_t)span);
     return HGI_OK;
 }
 
@@ -472,7 +478,7 @@ static hgi_status pipe_ensure(hgi_ctx *c)
 }
 
 // One LARGE frame in host memory: the same overlap inside the frame.  A tile only depends on input pixels of its own
-// rows and of the <= 64 halo rows below them, so a band of tile rows can be coded as soon as its rows and the next band
+// rows and of the halo rows at offsets 0 .. 2^k <= 64 below them (65 rows), so a band of tile rows can be coded as soon as its rows and the next band
 // are on the device, and downloaded while the bands further down still upload.  No kernel change: each band is a
 // launch of the standard kernel on a row-shifted view of the frame (true remaining height, so the out-of-image rule is
 // exact) limited to the band's tile rows.  Pyramids deeper than a tile need the stride-64 lattice of the WHOLE frame
@@ -537,29 +543,49 @@ static hgi_status host_banded(hgi_ctx *c, const uint8_t *in, uint8_t *out, uint3
             c->stream = saved;
         }
     }
-    // upload stream: band b goes up together with its 64 halo rows (the first rows of band b + 1), so that its kernel
-    // waits for nothing else; band b + 1 then starts below them
-    for (uint32_t b = 0; b < nb && e == hipSuccess; ++b) {
-        const size_t y0 = b ? (size_t)b * band + 64 : 0;
-        size_t y1 = (size_t)(b + 1) * band + 64;
+    // Upload stream: band b goes up together with its halo rows -- the tiles of its last tile row read input rows down to
+    // offset 2^k <= 64 below the band INCLUSIVE (halo row TH + 64 at k = 6), i.e. 65 rows of band b + 1 -- so that its
+    // kernel waits for nothing else; band b + 1 then starts below them.
+    // HGI_TEST_BAND_HOLD (tests): d_in is poisoned with 0xFF first and band b + 1's upload is held until band b's kernel
+    // has finished, so a kernel that read a row its own upload did not cover would see poison, deterministically.
+    static const bool hold = getenv("HGI_TEST_BAND_HOLD") != nullptr;
+    constexpr size_t kHaloRows = 65;
+    auto upload = [&](uint32_t b) {
+        const size_t y0 = b ? (size_t)b * band + kHaloRows : 0;
+        size_t y1 = (size_t)(b + 1) * band + kHaloRows;
         if (y1 > h) y1 = h;
-        if (y1 > y0) e = hipMemcpyAsync(d_in + y0 * w, in + y0 * w, (y1 - y0) * w, hipMemcpyHostToDevice, up);
-        if (e == hipSuccess) e = hipEventRecord(c->ev_band[b], up);
-    }
+        hipError_t r = hipSuccess;
+        if (y1 > y0) r = hipMemcpyAsync(d_in + y0 * w, in + y0 * w, (y1 - y0) * w, hipMemcpyHostToDevice, up);
+        if (r == hipSuccess) r = hipEventRecord(c->ev_band[b], up);
+        return r;
+    };
     // compute + download stream
-    for (uint32_t b = 0; b < nb && e == hipSuccess && st == HGI_OK; ++b) {
+    auto code = [&](uint32_t b) {
         const size_t y0 = (size_t)b * band, rows = y0 + band <= h ? band : h - y0;
-        e = hipStreamWaitEvent(down, c->ev_band[b], 0);
-        if (e != hipSuccess) break;
+        hipError_t r = hipStreamWaitEvent(down, c->ev_band[b], 0);
+        if (r != hipSuccess) return r;
         const Frames f = {w, (uint32_t)(h - y0), (uint64_t)((size_t)(h - y0) * w), 1};
         const uint32_t limit = b + 1 < nb ? band : 0;
         // the view starts y0 rows down (a multiple of 64 = 2^6 >= 2^k): its seeds start y0 >> k lattice rows down
         const size_t ly = y0 >> k;
         const Seeds sd = {deep ? sub_rec + ly * g.sw : nullptr, deep && encode ? sub_grid + ly * g.sw : nullptr, g.sw,
                           deep ? (uint32_t)(g.sh - ly) : 0u, g.stride};
-        e = encode ? launch_encode_fused(d_in + y0 * w, d_out + y0 * w, f, k, interp, l, ident, deep ? &sd : nullptr, down, limit)
+        r = encode ? launch_encode_fused(d_in + y0 * w, d_out + y0 * w, f, k, interp, l, ident, deep ? &sd : nullptr, down, limit)
                    : launch_decode_fused(d_in + y0 * w, d_out + y0 * w, f, k, interp, deep ? &sd : nullptr, down, limit);
-        if (e == hipSuccess) e = hipMemcpyAsync(out + y0 * w, d_out + y0 * w, rows * w, hipMemcpyDeviceToHost, down);
+        if (r == hipSuccess && hold) r = hipEventRecord(c->ev_free[b % 3], down);
+        if (r == hipSuccess) r = hipMemcpyAsync(out + y0 * w, d_out + y0 * w, rows * w, hipMemcpyDeviceToHost, down);
+        return r;
+    };
+    if (hold) {
+        if (e == hipSuccess) e = hipMemsetAsync(d_in, 0xFF, n, up);
+        for (uint32_t b = 0; b < nb && e == hipSuccess && st == HGI_OK; ++b) {
+            if (b) e = hipStreamWaitEvent(up, c->ev_free[(b - 1) % 3], 0);
+            if (e == hipSuccess) e = upload(b);
+            if (e == hipSuccess) e = code(b);
+        }
+    } else {
+        for (uint32_t b = 0; b < nb && e == hipSuccess; ++b) e = upload(b);
+        for (uint32_t b = 0; b < nb && e == hipSuccess && st == HGI_OK; ++b) e = code(b);
     }
     const hipError_t e0 = hipStreamSynchronize(up), e1 = hipStreamSynchronize(down);
     if (reg_in) (void)hipHostUnregister(const_cast<uint8_t *>(in));

@@ -99,7 +99,18 @@ static_assert(TH != 64 || 18 * (buf_bytes(4) + rbuf_bytes(4) + 256) <= 160 * 102
 #define HGI_STORE_AUX 2   // cache policy of the output stores: nt (streamed once; measured 2-3 % faster than default)
 #endif
 #ifndef HGI_ABL
-#define HGI_ABL 0   // timing experiments: 1 no coarse levels, 2 no fine arithmetic, 4 no halo cells, 8 no sub==2 level
+#define HGI_ABL 0   // timing experiments: 1 no coarse levels, 2 no fine arithmetic, 4 no halo cells, 8 no sub==2 level,
+                    // 16 no halo-column loads, 32 no halo-row loads
+#endif
+#ifndef HGI_HALO_ALL_ROWS
+#define HGI_HALO_ALL_ROWS 0   // 1: fetch the halo-column offsets >= 16 on every even row (the round-1 behaviour)
+#endif
+// Analysis builds (tools/isa_phases.py): -DHGI_ANALYZE_K=4 compiles the interior-tile path alone with a constant
+// depth, so that it is straight-line code, and leaves phase markers in the ISA.  Never linked into the library.
+#ifdef HGI_ANALYZE_K
+#define HGI_MARK(name) asm volatile("; HGI_MARK " name)
+#else
+#define HGI_MARK(name)
 #endif
 typedef u32 v4u __attribute__((ext_vector_type(4)));
 typedef u32 v2u __attribute__((ext_vector_type(2)));
@@ -650,6 +661,7 @@ __device__ __forceinline__ void enc_level_coarse_fast(u8 *buf, u8 *rbuf, const u
         cell_finish<INTERP, IDENT>(buf, rbuf, slut, a1, v1);
         // the 25 halo cells in a pass of their own: three cells in flight per lane was the register peak
         LDS_ORDER();
+        HGI_MARK("halo");
         enc_halo_pass<INTERP, IDENT>(buf, rbuf, slut, 4, tl, W, H);
     } else {
         const int step = 2 * s, lstep = 31 - __clz(step);
@@ -722,20 +734,24 @@ __device__ __forceinline__ void stage_issue(Stage &st, const Buf &b, Tile tl, in
         if (narrow) st.o[j] &= cm;
     }
     st.hv = v4u{0, 0, 0, 0};
-    if (lane < nh * CH && cin) st.hv = __builtin_amdgcn_raw_buffer_load_b128(b.rs, b.base + (TH + hoff(r)) * W + 16 * c, 0, 0);
+    if (!(HGI_ABL & 32) && lane < nh * CH && cin) st.hv = __builtin_amdgcn_raw_buffer_load_b128(b.rs, b.base + (TH + hoff(r)) * W + 16 * c, 0, 0);
     if (narrow) st.hv &= cm;
     const int hy = lane < TH / 2 ? 2 * lane : TH + hoff(lane - TH / 2);
     const u32 xo = b.base + hy * W + TW;
     const u32 xr = tl.X0 + TW;              // first column right of the tile
     st.x0 = v3u{0, 0, 0};
     st.d16 = st.d32 = st.d64 = 0;
-    if (lane < TH / 2 + nh) {
+    if (!(HGI_ABL & 16) && lane < TH / 2 + nh) {
         if (xr < W) st.x0 = __builtin_amdgcn_raw_buffer_load_b96(b.rs, xo, 0, 0);
         if (xr + 4 >= W) st.x0.y = 0;    // offsets 4 / 8 can lie beyond the image when the width is not a multiple of 16
         if (xr + 8 >= W) st.x0.z = 0;
-        if (k >= 4 && xr + 16 < W) st.d16 = __builtin_amdgcn_raw_buffer_load_b32(b.rs, xo + 16, 0, 0);
-        if (k >= 5 && xr + 32 < W) st.d32 = __builtin_amdgcn_raw_buffer_load_b32(b.rs, xo + 32, 0, 0);
-        if (k >= 6 && xr + 64 < W) st.d64 = __builtin_amdgcn_raw_buffer_load_b32(b.rs, xo + 64, 0, 0);
+        // Column offset `off` is only ever touched on rows = 0 (mod off): level off / 2 reads it as a corner of the
+        // halo cells (rows = 0 mod step = off), level off codes it (rows = 0 mod s = off).  The other lanes do not
+        // fetch that line at all.
+        const bool all = HGI_HALO_ALL_ROWS;
+        if (k >= 4 && (all || !(hy & 15)) && xr + 16 < W) st.d16 = __builtin_amdgcn_raw_buffer_load_b32(b.rs, xo + 16, 0, 0);
+        if (k >= 5 && (all || !(hy & 31)) && xr + 32 < W) st.d32 = __builtin_amdgcn_raw_buffer_load_b32(b.rs, xo + 32, 0, 0);
+        if (k >= 6 && (all || !(hy & 63)) && xr + 64 < W) st.d64 = __builtin_amdgcn_raw_buffer_load_b32(b.rs, xo + 64, 0, 0);
     }
 }
 
@@ -969,6 +985,7 @@ __device__ __forceinline__ void enc_level2_fast(u8 *buf, u8 *rbuf, const u8 *slu
         __builtin_amdgcn_sched_barrier(0);   // keep the next iteration's reads behind this one's arithmetic
     }
     LDS_ORDER();
+    HGI_MARK("halo");
     enc_halo_pass<INTERP, IDENT>(buf, rbuf, slut, 2, tl, W, H);
 }
 
@@ -1175,13 +1192,17 @@ __device__ __forceinline__ void dec_tile_fast(u8 *buf, const TileCtx &cur, const
 {
     for (int s = 1 << (k - 1); s >= 2 && !(HGI_ABL & 1); s >>= 1) {
         if (s == 2) {
+            HGI_MARK("level2");
             if (!(HGI_ABL & 8)) dec_level2_fast<INTERP>(buf);
         } else {
+            HGI_MARK("coarse");
             dec_cells<INTERP, false>(buf, s, cur.tl, W, H);
         }
+        HGI_MARK("halo");
         if (!(HGI_ABL & 4)) dec_halo_cells<INTERP>(buf, s, cur.tl, W, H);
         LDS_ORDER();
     }
+    HGI_MARK("fine");
     dec_fine_fast<INTERP>(buf, cur.b, odd);
 }
 
@@ -1238,20 +1259,31 @@ __global__ __launch_bounds__(NL) __attribute__((amdgpu_waves_per_eu(HGI_DEC_WAVE
 {
     extern __shared__ __attribute__((aligned(16))) u8 smem[];
     u8 *buf = smem - HCOL;
+#ifdef HGI_ANALYZE_K
+    k = HGI_ANALYZE_K;
+#endif
     const int nh = k >= 2 ? (int)k : 1;
     const u32 W = f.width, H = f.height;
+#ifdef HGI_ANALYZE_K
+    BlockRole role = block_role(g);
+    role.edge = role.idle = false;
+#else
     const BlockRole role = block_role(g);
+#endif
     if (role.idle) return;
     if (!role.edge) {
         TileCtx cur = fast_ctx(role.index, src, dst, f, g, (aligned & 4u) ? 3u : 0u);
         Stage st;
         SeedRegs seeds;
+        HGI_MARK("stage_issue");
         stage_issue<false>(st, cur.b, cur.tl, (int)k, nh);
         if (SEEDED) seeds = seed_issue<false>(sd, cur.tl, k);
+        HGI_MARK("stage_commit");
         stage_commit<false>(buf, nullptr, st, nh);
         LDS_ORDER();
         if (SEEDED) dec_seed_commit(buf, seeds, k);
         dec_tile_fast<INTERP>(buf, cur, st.o, k, W, H);
+        HGI_MARK("end");
         return;
     }
     // ragged tile (body crosses the image edge), unaligned rows, or offsets beyond 32 bits: every access checked
@@ -1320,12 +1352,16 @@ __device__ __forceinline__ void enc_tile_fast(u8 *buf, u8 *rbuf, const u8 *slut,
                                               const v4u (&odd)[NFINE], u32 k, u32 W, u32 H)
 {
     for (int s = 1 << (k - 1); s >= 2 && !(HGI_ABL & 1); s >>= 1) {
-        if (s == 2)
+        if (s == 2) {
+            HGI_MARK("level2");
             enc_level2_fast<INTERP, IDENT>(buf, rbuf, slut, cur.tl, W, H);
-        else
+        } else {
+            HGI_MARK("coarse");
             enc_level_coarse_fast<INTERP, IDENT>(buf, rbuf, slut, s, cur.tl, W, H);
+        }
         LDS_ORDER();
     }
+    HGI_MARK("fine");
     enc_fine_fast<INTERP, IDENT>(buf, rbuf, slut, cur.b, odd);
 }
 
@@ -1339,27 +1375,39 @@ __global__ __launch_bounds__(NL) __attribute__((amdgpu_waves_per_eu(IDENT ? HGI_
                                                   Lut256 lut, Seeds sd, TileGrid g, u32 aligned)
 {
     extern __shared__ __attribute__((aligned(16))) u8 smem[];
+#ifdef HGI_ANALYZE_K
+    k = HGI_ANALYZE_K;
+#endif
     const int nh = k >= 2 ? (int)k : 1;
     // the table first, at LDS offset 0: a residual byte then IS the address of its table entry (lut_at(); the
-    // planes behind it have a size that depends on k).  Dynamic LDS starts at 0 because the kernel has no static LDS.
+    // planes behind it have a size that depends on k).  Dynamic LDS starts at 0 because the kernel has no static LDS:
+    // launch_encode_fused verifies that on the host (hipFuncGetAttributes) before the first launch of each
+    // instantiation and refuses to launch otherwise -- nothing on the device can abort.
     u8 *slut = smem;
-    if ((u32)reinterpret_cast<uintptr_t>(smem) != 0u) __builtin_trap();
     u8 *buf = smem + 256 - HCOL;
     u8 *rbuf = smem + 256 + buf_bytes(nh) - RCOL;
     const u32 W = f.width, H = f.height;
+#ifdef HGI_ANALYZE_K
+    BlockRole role = block_role(g);
+    role.edge = role.idle = false;
+#else
     const BlockRole role = block_role(g);
+#endif
     if (role.idle) return;
     if (!IDENT) reinterpret_cast<u32 *>(slut)[threadIdx.x] = lut.w[threadIdx.x];
     if (!role.edge) {
         TileCtx cur = fast_ctx(role.index, src, dst, f, g, (aligned & 4u) ? 3u : 0u);
         Stage st;
         SeedRegs seeds;
+        HGI_MARK("stage_issue");
         stage_issue<false>(st, cur.b, cur.tl, (int)k, nh);
         if (SEEDED) seeds = seed_issue<true>(sd, cur.tl, k);
+        HGI_MARK("stage_commit");
         stage_commit<true>(buf, rbuf, st, nh);
         LDS_ORDER();
         enc_seed_commit<SEEDED>(buf, rbuf, seeds, k);
         enc_tile_fast<INTERP, IDENT>(buf, rbuf, slut, cur, st.o, k, W, H);
+        HGI_MARK("end");
         return;
     }
     const Tile tl = edge_tile(role.index, g);
@@ -1466,6 +1514,16 @@ hipError_t HGI_TILED(launch_decode_fused)(const uint8_t *grid, uint8_t *img, con
 #endif  // HGI_FUSED_DECODE
 
 #ifdef HGI_FUSED_ENCODE
+namespace {
+hipError_t static_lds_is_empty(const void *kernel)
+{
+    hipFuncAttributes a;
+    const hipError_t e = hipFuncGetAttributes(&a, kernel);
+    if (e != hipSuccess) return e;
+    return a.sharedSizeBytes == 0 ? hipSuccess : hipErrorInvalidDeviceFunction;
+}
+}  // namespace
+
 hipError_t HGI_TILED(launch_encode_fused)(const uint8_t *img, uint8_t *grid, const Frames &f, uint32_t k, int interp,
                                           const Lut256 &lut, bool ident, const Seeds *seeds, hipStream_t s, uint32_t row_limit)
 {
@@ -1477,8 +1535,14 @@ hipError_t HGI_TILED(launch_encode_fused)(const uint8_t *img, uint8_t *grid, con
     const int nh = k >= 2 ? (int)k : 1;
     const size_t lds = (size_t)buf_bytes(nh) + rbuf_bytes(nh) + 256;
     const dim3 blocks(((g.nedge + 7u) & ~7u) + g.nfast);
-#define HGI_ENC(I, ID, SE) \
-    hipLaunchKernelGGL((k_enc_tiles<I, ID, SE, TH>), blocks, b, lds, s, img, grid, f, k, lut, sd, g, r.aligned)
+    // lut_at() addresses the table from LDS offset 0: only valid while the kernel has no static LDS in front of its
+    // dynamic segment.  Checked once per instantiation on the host; a build that breaks it fails here, not on the device.
+#define HGI_ENC(I, ID, SE)                                                                                        \
+    do {                                                                                                          \
+        static const hipError_t lds0 = static_lds_is_empty(reinterpret_cast<const void *>(&k_enc_tiles<I, ID, SE, TH>)); \
+        if (lds0 != hipSuccess) return lds0;                                                                      \
+        hipLaunchKernelGGL((k_enc_tiles<I, ID, SE, TH>), blocks, b, lds, s, img, grid, f, k, lut, sd, g, r.aligned); \
+    } while (0)
 #define HGI_ENC_I(I)                                                          \
     do {                                                                      \
         if (ident) { if (seeds) HGI_ENC(I, true, true); else HGI_ENC(I, true, false); } \

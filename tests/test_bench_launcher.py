@@ -1,0 +1,72 @@
+"""`python bench.py --gpus N` must start its N ranks by itself (the driver runs exactly that command), keep working
+under torchrun, print ONE JSON line from rank 0 and fail when a rank fails.  Run here through bench.py's own
+launcher / rank split with --rehearse: gloo on the CPU, every collective of the real run, no codec work (the product
+has no CPU codec)."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+from conftest import ROOT
+
+BENCH = os.path.join(ROOT, "bench.py")
+
+
+def _env(**extra):
+    env = {k: v for k, v in os.environ.items()
+           if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "HGI_BENCH_FAIL_RANK")}
+    env.update(extra)
+    return env
+
+
+def _one_line(stdout):
+    lines = [l for l in stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, stdout
+    return json.loads(lines[0])
+
+
+@pytest.mark.timeout(300)
+def test_plain_command_launches_two_ranks():
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--rehearse", "--steps", "2", "--warmup", "1", "--frames", "5"],
+                       env=_env(), capture_output=True, text=True, timeout=280)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = _one_line(r.stdout)
+    assert d["n_gpus"] == 2 and d["rehearsal"] is True and d["value"] is None and d["scaling"] == "weak"
+    assert d["config"]["global_frames"] == 10 and d["config"]["shards"] == [[0, 5], [5, 5]]
+    assert d["config"]["levels"] == 4 and d["config"]["max_error"] == 20       # the broadcast reached rank 0's line
+    for rank in (0, 1):
+        assert "rank %d/2 joined (gloo)" % rank in r.stderr
+
+
+@pytest.mark.timeout(300)
+def test_torchrun_wrapped_form_still_works():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+                        "127.0.0.1", "--master-port", str(port), BENCH, "--gpus", "2", "--rehearse", "--steps", "1",
+                        "--warmup", "0"], env=_env(OMP_NUM_THREADS="1"), capture_output=True, text=True, timeout=280)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert _one_line(r.stdout)["n_gpus"] == 2
+
+
+@pytest.mark.timeout(300)
+def test_failing_rank_fails_the_run_and_mismatch_is_refused():
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--rehearse", "--steps", "1", "--warmup", "0"],
+                       env=_env(HGI_BENCH_FAIL_RANK="1"), capture_output=True, text=True, timeout=280)
+    assert r.returncode != 0 and not r.stdout.strip()
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--rehearse"], env=_env(WORLD_SIZE="3", RANK="0"),
+                       capture_output=True, text=True, timeout=120)
+    assert r.returncode == 2 and "WORLD_SIZE=3" in r.stderr
+
+
+def test_launcher_parent_never_imports_the_gpu_stack():
+    """The launcher branch runs before torch / the HIP library are imported (a process that has initialised the GPU must
+    not start the ranks): bench.py imports them inside run_rank only."""
+    src = open(BENCH).read()
+    head = src[:src.index("def run_rank")]
+    assert "import torch" not in head and "import rustyhgi_amd" not in head
+    assert "os.exec" not in src

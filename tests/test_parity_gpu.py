@@ -295,6 +295,38 @@ def test_error_paths_on_device(ctxs):
     assert L.hgi_ctx_create(99, ctypes.byref(bad)) == _ffi.EDEVICE
 
 
+def test_overlapping_buffers_are_refused(ctxs):
+    """Input and output must be disjoint byte ranges, not merely different pointers (the reference consumes its input by
+    value, src/encoder.rs:39, so it can never alias there): partial overlap in either direction, host and device entry
+    points, single frames and batches; buffers that merely touch are fine."""
+    import torch
+    from rustyhgi_amd import _ffi
+    L, ctx = _ffi.lib(), ctxs["fused"]
+    lut = np.arange(256, dtype=np.uint8)
+    w, h, n = 64, 32, 64 * 32
+    host = np.zeros(3 * n, np.uint8)
+    base = host.ctypes.data
+    for a, b in ((0, n // 2), (n // 2, 0), (0, n - 1), (n - 1, 0), (0, 1)):
+        assert L.hgi_encode_u8(ctx.handle, base + a, w, h, 3, 1, lut.ctypes.data, base + b) == _ffi.EINVAL, (a, b)
+        assert L.hgi_decode_u8(ctx.handle, base + a, w, h, 3, 1, base + b) == _ffi.EINVAL, (a, b)
+    assert b"overlap" in L.hgi_last_error()
+    assert L.hgi_encode_u8(ctx.handle, base, w, h, 3, 1, lut.ctypes.data, base + n) == _ffi.OK          # adjacent
+    assert L.hgi_decode_u8(ctx.handle, base + n, w, h, 3, 1, base) == _ffi.OK
+    # batches: two frames at stride n; the second range starts inside the first one's last frame
+    assert L.hgi_encode_u8_batch(ctx.handle, base, w, h, 3, 1, lut.ctypes.data, base + n + 5, 2, n) == _ffi.EINVAL
+    assert L.hgi_decode_u8_batch(ctx.handle, base + n + 5, w, h, 3, 1, base, 2, n) == _ffi.EINVAL
+    dev = torch.zeros(5 * n, dtype=torch.uint8, device="cuda")
+    d = dev.data_ptr()
+    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    for a, b in ((0, n), (n, 0), (0, 2 * n - 1), (2 * n - 1, 0)):
+        assert L.hgi_encode_u8_dev(ctx.handle, d + a, w, h, 3, 1, lut.ctypes.data, d + b, 2, n) == _ffi.EINVAL, (a, b)
+        assert L.hgi_decode_u8_dev(ctx.handle, d + a, w, h, 3, 1, d + b, 2, n) == _ffi.EINVAL, (a, b)
+    assert L.hgi_encode_u8_dev(ctx.handle, d, w, h, 3, 1, lut.ctypes.data, d + 2 * n, 2, n) == _ffi.OK
+    assert L.hgi_decode_u8_dev(ctx.handle, d + 2 * n, w, h, 3, 1, d, 2, n) == _ffi.OK
+    torch.cuda.synchronize()
+    ctx.use_own_stream()
+
+
 def test_cpp_mirror_lib_rs_port(H):
     """The C++ host mirror (include/hgi.hpp): a port of the reference's own unit tests (src/lib.rs:45-125)
     compiled against libhgi_hip.so and run here."""
@@ -700,3 +732,18 @@ def test_banded_host_frames(ctxs, oracle, w, h, levels):
     want = oracle.encode(img, levels, lut)
     assert_same(gpu_encode(ctxs["fused"], img, levels, lut), want, "banded encode %dx%d L%d" % (w, h, levels))
     assert_same(gpu_decode(ctxs["fused"], want, levels), oracle.decode(want, levels), "banded decode %dx%d L%d" % (w, h, levels))
+
+
+def test_banded_bands_never_read_rows_of_the_next_upload():
+    """Deterministic form of the band / halo dependency (a tile of a band's last tile row reads input rows down to
+    offset 2^k = 64 below the band INCLUSIVE at levels = 6: 65 rows, not 64).  HGI_TEST_BAND_HOLD poisons the device
+    input with 0xFF and holds band b + 1's upload until band b's kernel has finished, so a kernel that depended on a row
+    outside its own upload reads poison every time instead of almost never.  One child process, run once."""
+    import os
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(here, "test_parity_gpu.py"), "-m", "gpu", "-q", "-x",
+                        "-p", "no:cacheprovider", "-k", "test_banded_host_frames"],
+                       env=dict(os.environ, HGI_TEST_BAND_HOLD="1"), capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-1000:]
