@@ -104,6 +104,8 @@ def parse_args(argv=None):
     ap.add_argument("--no-pfine", action="store_true", help="skip the P_fine (levels = 1) leg")
     ap.add_argument("--xgmi-scatter", action="store_true",
                     help="also time the labelled variant where all frames start and end on GPU 0 (scatter, code, gather)")
+    ap.add_argument("--placement", choices=("planes", "torch"), default="planes",
+                    help="frame stacks from hgi_planes_alloc (neighbouring planes in different HBM regions) or from torch")
     ap.add_argument("--rehearse", action="store_true",
                     help="CPU rehearsal of the multi-rank plumbing (gloo, no codec work, value null)")
     return ap.parse_args(argv)
@@ -243,6 +245,7 @@ def run_rank(args):
     enc_ms, dec_ms = codec.mean_ms()
     copy_ms = codec.copy_ms() if rank == 0 else None
     pfine = codec.p_fine() if rank == 0 and not args.no_pfine else None
+    placement = codec.placement() if rank == 0 else None
     xgmi = codec.xgmi(dist, world, rank, fence, args.steps) if args.xgmi_scatter else None
 
     # ---- per-rank checks + stats gather (RCCL all-gather) ----
@@ -283,6 +286,7 @@ def run_rank(args):
                                            "avg_launch_ms": round(copy_ms, 4),
                                            "note": "16-B/lane copy kernel moving the same bytes"}},
         }
+        line["config"]["placement"] = placement
         if pfine is not None:
             line["p_fine"] = pfine
         if xgmi is not None:
@@ -316,9 +320,17 @@ class Codec:
         F, S = args.frames, args.size
         self.F, self.S = F, S
         ctx.reserve(S, S, levels, F)
-        self.imgs = torch.empty((F, S, S), dtype=torch.uint8, device=dev)
-        self.grids = torch.empty_like(self.imgs)
-        self.outs = torch.empty_like(self.imgs)
+        # The three frame stacks.  Default: planes placed by the library (hgi_planes_alloc) so that each launch reads
+        # one HBM region and writes another (+4-5 % on MI355X over planes that share a region, which is
+        # what plain allocations give about half of the time).  --placement torch: plain torch allocations.
+        self.planes = None
+        if args.placement == "planes":
+            self.planes = H.Planes(ctx, F * S * S, 3)
+            self.imgs, self.grids, self.outs = (self.planes.torch(i, (F, S, S)) for i in range(3))
+        else:
+            self.imgs = torch.empty((F, S, S), dtype=torch.uint8, device=dev)
+            self.grids = torch.empty_like(self.imgs)
+            self.outs = torch.empty_like(self.imgs)
         _ffi.check(_ffi.lib().hgi_synth_u8_dev(ctx.handle, _ffi.SYNTH_RAMP, SEED0 + 3, first, S, S,
                                                self.imgs.data_ptr(), F, S * S))
         self.quant = table_quantizator(lut, err)
@@ -442,6 +454,34 @@ class Codec:
         self._restore()
         return res
 
+    def placement(self):
+        """How the frame stacks were placed, and -- for transparency -- the same step timed on plain torch allocations
+        in this process (their regions are whatever the allocator gave: either pairing may come out fast or slow)."""
+        torch, F, S = self.torch, self.F, self.S
+        info = {"mode": self.args.placement}
+        if self.planes is not None:
+            info.update({"api": "hgi_planes_alloc(bytes, 3): neighbouring planes in different HBM regions (DESIGN.md 5.1)",
+                         "separated": self.planes.separated})
+        a = torch.empty((F, S, S), dtype=torch.uint8, device=self.dev)
+        b, c = torch.empty_like(a), torch.empty_like(a)
+        a.copy_(self.imgs)
+        reps = 8
+        ev = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(reps)]
+        for i in range(2 + reps):
+            e = ev[max(i - 2, 0)]
+            e[0].record()
+            self.enc.encode_batch(a, out=b)
+            e[1].record()
+            self.dec.decode_batch(b, self.levels, out=c)
+            e[2].record()
+        torch.cuda.synchronize(self.dev)
+        same = bool(torch.equal(b, self.grids)) and bool(torch.equal(c, self.outs))
+        info["plain_torch_allocations"] = {"encode_ms": round(float(np.mean([e[0].elapsed_time(e[1]) for e in ev])), 4),
+                                           "decode_ms": round(float(np.mean([e[1].elapsed_time(e[2]) for e in ev])), 4),
+                                           "same_bytes_as_timed_run": same}
+        del a, b, c
+        return info
+
     def stats(self):
         torch, _ffi, F, S = self.torch, self._ffi, self.F, self.S
         stats = torch.zeros(3 * F, dtype=torch.int64, device=self.dev)
@@ -454,6 +494,9 @@ class Codec:
         return {"grid": self.grids[:2].cpu().numpy(), "out": self.outs[:2].cpu().numpy()}
 
     def close(self):
+        del self.imgs, self.grids, self.outs
+        if self.planes is not None:
+            self.planes.close()
         self.ctx.close()
 
 

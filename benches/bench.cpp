@@ -5,8 +5,10 @@
 //   host   -- through hgi_encode_u8 / hgi_decode_u8 (host pointers; PCIe transfers included), the
 //             drop-in equivalent of `encoder.encode(image)`;
 //   device -- through the *_dev entry points on device-resident buffers (what the roofline numbers use).
-// `serialization` / `compression` need the .hgi archive writer and are not here yet.
-//   build: hipcc -O2 -std=c++17 -Iinclude benches/bench.cpp -Lrustyhgi_amd -lhgi_hip -Wl,-rpath,$PWD/rustyhgi_amd -o bench_cpp
+// `serialization` (benches/bench.rs:112-127) and `compression` (:129-151) use the .hgi archive writer of
+// include/hgi_archive.hpp (the CLI's): they are host-side DEFLATE at the best level and dominate the codec by orders of
+// magnitude, exactly as in the reference; reported in the reference's unit (time per iteration).
+//   build: hipcc -O2 -std=c++17 -Iinclude benches/bench.cpp -Lrustyhgi_amd -lhgi_hip -lz -Wl,-rpath,$PWD/rustyhgi_amd -o bench_cpp
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -16,6 +18,7 @@
 #include <vector>
 
 #include "hgi.hpp"
+#include "hgi_archive.hpp"
 
 using namespace hgi;
 using clk = std::chrono::steady_clock;
@@ -117,6 +120,41 @@ int main()
         GrayImage back(width, height);
         (void)hipMemcpy(back.data.data(), d_b, size, hipMemcpyDeviceToHost);
         std::printf("lossless round trip exact: %s\n", back == image ? "yes" : "NO");
+    }
+    const Metadata metadata{QuantizationLevel::Medium, InterpolationType::Crossed, width, height, levels};   // benches/bench.rs:16-22
+    {   // `serialization` (benches/bench.rs:112-127): Archive::serialize_to_writer of an already coded grid into a
+        // buffer with the serialized size reserved (the setup, untimed); c.bench_function: no throughput, time only
+        Encoder<Crossed, Linear> encoder(Crossed{}, Linear::from(QuantizationLevel::Lossless), levels);
+        const Grid grid = encoder.encode(image);
+        const size_t reserve = serialized_size(metadata, grid);
+        size_t archive_bytes = 0;
+        std::vector<double> t;
+        for (int i = 0; i < 1 + 25; ++i) {
+            std::vector<uint8_t> buffer;
+            buffer.reserve(reserve);
+            auto t0 = clk::now();
+            serialize_into(buffer, metadata, grid);
+            if (i) t.push_back(std::chrono::duration<double>(clk::now() - t0).count());
+            archive_bytes = buffer.size();
+        }
+        std::sort(t.begin(), t.end());
+        report("serialization", "host", t[t.size() / 2], size);
+        std::printf("  archive: %zu bytes (%.2fx)\n", archive_bytes, double(size) / archive_bytes);
+    }
+    {   // `compression` (benches/bench.rs:129-151): encode + serialize; buffer allocation and image clone are the setup
+        Encoder<Crossed, Linear> encoder(Crossed{}, Linear::from(QuantizationLevel::Lossless), levels);
+        std::vector<double> t;
+        for (int i = 0; i < 1 + 25; ++i) {
+            std::vector<uint8_t> buffer;
+            buffer.reserve(size);
+            GrayImage input = image;
+            auto t0 = clk::now();
+            const Grid grid = encoder.encode(input);
+            serialize_into(buffer, metadata, grid);
+            if (i) t.push_back(std::chrono::duration<double>(clk::now() - t0).count());
+        }
+        std::sort(t.begin(), t.end());
+        report("compression", "host", t[t.size() / 2], size);
     }
     (void)hipFree(d_a);
     (void)hipFree(d_b);

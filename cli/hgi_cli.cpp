@@ -15,8 +15,6 @@
 // DEFLATE at level 9 where the reference uses flate2's Compression::best().
 //
 //   build: g++ -O2 -std=c++17 -Iinclude cli/hgi_cli.cpp -Lrustyhgi_amd -lhgi_hip -lz -o hgi
-#include <zlib.h>
-
 #include <algorithm>
 #include <cctype>
 #include <cmath>
@@ -29,6 +27,7 @@
 #include <string>
 
 #include "hgi.hpp"
+#include "hgi_archive.hpp"
 
 using hgi::GrayImage;
 using hgi::Grid;
@@ -39,9 +38,10 @@ using hgi::quantizator::QuantizationLevel;
 
 namespace {
 
-struct Failure : std::runtime_error {
-    using std::runtime_error::runtime_error;
-};
+using Failure = hgi::ArchiveError;   // one error type for I/O, options and the archive
+using hgi::deserialize;
+using hgi::Metadata;
+using hgi::serialize;
 
 std::vector<uint8_t> read_file(const std::string &path)
 {
@@ -138,78 +138,6 @@ void save_pgm(const GrayImage &img, const std::string &path)
     std::vector<uint8_t> out(head.begin(), head.end());
     out.insert(out.end(), img.data.begin(), img.data.end());
     write_file(path, out);
-}
-
-// ---- archive (src/archive.rs:13-56) ----------------------------------------------------------------
-constexpr uint32_t MAGIC = 0xBAADA555u;
-
-struct Metadata {   // src/archive.rs:15-22
-    QuantizationLevel quantization_level;
-    InterpolationType interpolation;
-    uint32_t width, height;
-    uint64_t scale_level;
-};
-
-void put(std::vector<uint8_t> &o, uint64_t v, int bytes)
-{
-    for (int i = 0; i < bytes; ++i) o.push_back(uint8_t(v >> (8 * i)));
-}
-uint64_t get(const std::vector<uint8_t> &b, size_t at, int bytes)
-{
-    if (at + bytes > b.size()) throw Failure("truncated archive");
-    uint64_t v = 0;
-    for (int i = 0; i < bytes; ++i) v |= uint64_t(b[at + i]) << (8 * i);
-    return v;
-}
-
-std::vector<uint8_t> serialize(const Metadata &m, const Grid &grid)   // src/archive.rs:31-41
-{
-    std::vector<uint8_t> out, body;
-    put(out, MAGIC, 4);
-    put(out, (uint32_t)m.quantization_level, 4);
-    put(out, (uint32_t)m.interpolation, 4);
-    put(out, m.width, 4);
-    put(out, m.height, 4);
-    put(out, m.scale_level, 8);
-    put(body, grid.buffer.size(), 8);   // bincode: Vec<u8> = u64 length + bytes, then usize width as u64
-    body.insert(body.end(), grid.buffer.begin(), grid.buffer.end());
-    put(body, grid.width, 8);
-    z_stream z{};
-    if (deflateInit2(&z, 9, Z_DEFLATED, -15, 9, Z_DEFAULT_STRATEGY) != Z_OK) throw Failure("deflateInit2 failed");
-    std::vector<uint8_t> comp(deflateBound(&z, (uLong)body.size()));
-    z.next_in = body.data();
-    z.avail_in = (uInt)body.size();
-    z.next_out = comp.data();
-    z.avail_out = (uInt)comp.size();
-    int rc = deflate(&z, Z_FINISH);
-    deflateEnd(&z);
-    if (rc != Z_STREAM_END) throw Failure("deflate failed");
-    out.insert(out.end(), comp.begin(), comp.begin() + z.total_out);
-    return out;
-}
-
-void deserialize(const std::vector<uint8_t> &b, Metadata &m, Grid &grid)   // src/archive.rs:43-55
-{
-    if (get(b, 0, 4) != MAGIC) throw Failure("incorrect magic number");   // :48-50
-    m.quantization_level = (QuantizationLevel)get(b, 4, 4);
-    m.interpolation = (InterpolationType)get(b, 8, 4);
-    m.width = (uint32_t)get(b, 12, 4);
-    m.height = (uint32_t)get(b, 16, 4);
-    m.scale_level = get(b, 20, 8);
-    std::vector<uint8_t> body(size_t(m.width) * m.height + 16);
-    z_stream z{};
-    if (inflateInit2(&z, -15) != Z_OK) throw Failure("inflateInit2 failed");
-    z.next_in = const_cast<uint8_t *>(b.data()) + 28;
-    z.avail_in = (uInt)(b.size() - 28);
-    z.next_out = body.data();
-    z.avail_out = (uInt)body.size();
-    int rc = inflate(&z, Z_FINISH);
-    inflateEnd(&z);
-    if (rc != Z_STREAM_END || z.total_out != body.size()) throw Failure("corrupt grid stream");
-    uint64_t n = get(body, 0, 8);
-    if (n != size_t(m.width) * m.height) throw Failure("grid size does not match the metadata");
-    grid.buffer.assign(body.begin() + 8, body.begin() + 8 + n);
-    grid.width = get(body, 8 + n, 8);
 }
 
 // ---- options (src/options.rs) ------------------------------------------------------------------------

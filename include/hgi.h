@@ -139,6 +139,22 @@ hgi_status hgi_copy_u8_dev(hgi_ctx *ctx, const void *d_src, void *d_dst, size_t 
 hgi_status hgi_diff_stats_dev(hgi_ctx *ctx, const void *d_before, const void *d_after,
                               uint32_t width, uint32_t height, size_t batch, size_t frame_stride,
                               void *d_out);
+/* ---- plane placement (no reference counterpart: the reference's buffers are Vec<u8>) ---- */
+/* MI355X serves its HBM in large physical regions; a launch that streams one buffer in and   */
+/* another out runs 4-5 % faster when the two lie in different regions.       */
+/* hgi_planes_alloc returns `count` device buffers of `bytes` each (hipMalloc; release with   */
+/* hgi_planes_free or hipFree) such that planes[i] and planes[i+1] lie in different regions:  */
+/* image -> grid -> image chains alternate through the array.  Best effort, found by timing   */
+/* the decode kernel between candidates (a few ms per plane, transient extra allocations):    */
+/* *separated (optional) is 1 when every neighbouring pair was seen to be in different        */
+/* regions, 0 when that could not be established (planes below 512 MiB are not probed: such   */
+/* streams live in the Infinity Cache) -- the planes are valid either way.                    */
+hgi_status hgi_planes_alloc(hgi_ctx *ctx, size_t bytes, uint32_t count, void **planes, int *separated);
+hgi_status hgi_planes_free(hgi_ctx *ctx, uint32_t count, void **planes);
+/* The probe itself: mean milliseconds of one decode launch streaming d_src -> d_dst over      */
+/* min(bytes, 2 GiB).  Overwrites d_dst.  Compare pairings of the caller's own buffers with it. */
+hgi_status hgi_probe_pair_u8_dev(hgi_ctx *ctx, const void *d_src, void *d_dst, size_t bytes, float *ms);
+
 /* hipEvent pair on the ctx stream: start, ...launches..., stop -> elapsed milliseconds.     */
 hgi_status hgi_timer_start(hgi_ctx *ctx);
 hgi_status hgi_timer_stop(hgi_ctx *ctx, float *elapsed_ms);

@@ -7,6 +7,10 @@ pub struct HgiCtx {
 }
 
 pub const HGI_OK: c_int = 0;
+pub const HGI_EINVAL: c_int = 1;
+pub const HGI_ENOMEM: c_int = 2;
+pub const HGI_EDEVICE: c_int = 3;
+pub const HGI_EUNSUPPORTED: c_int = 4;
 pub const HGI_INTERP_LEFTTOP: c_int = 0;
 pub const HGI_INTERP_CROSSED: c_int = 1;
 

@@ -746,6 +746,147 @@ hgi_status hgi_diff_stats_dev(hgi_ctx *c, const void *d_before, const void *d_af
     return HGI_OK;
 }
 
+// ---- plane placement ------------------------------------------------------------------------------------------
+// Measured on MI355X (profiles/r02_modes*.txt): the HBM behind one device is served in large physical
+// regions (the driver's buddy blocks of up to 64 GiB never straddle one), and a kernel that streams one buffer in while
+// streaming another out runs 4-5 % faster when the two lie in DIFFERENT regions than when they share one -- for the
+// tile kernels 0.365 against 0.382 ms per GiB, for a linear copy 1.5 %.  Physical addresses are not visible from user
+// space, so the only way to tell is to run the stream: the probe below times the decode kernel from one buffer into the
+// other (its time does not depend on the bytes).  hgi_planes_alloc uses it to hand out planes whose neighbours in the
+// array lie in different regions: what an encode -> decode chain (image -> grid -> image) wants.
+namespace {
+
+// mean time of decode launches prev -> cand over min(bytes, 2 GiB), as one frame 4096 wide
+hgi_status probe_pair_ms(hgi_ctx *c, const uint8_t *prev, uint8_t *cand, size_t bytes, float *ms)
+{
+    const uint32_t w = 4096;
+    size_t rows = bytes / w;
+    if (rows > (2u << 20) / 4) rows = (2u << 20) / 4;          // 2 GiB: every byte offset stays below 2^32
+    rows &= ~(size_t)63;
+    const uint32_t h = (uint32_t)rows;
+    constexpr int kWarm = 2, kTimed = 4;
+    for (int i = 0; i < kWarm + kTimed; ++i) {
+        if (i == kWarm) HIP_TRY(hipEventRecord(c->ev0, c->stream));
+        c->ws_used = 0;
+        HGI_TRY(decode_impl(c, prev, w, h, 4, HGI_INTERP_CROSSED, cand, 1, (size_t)w * h));
+    }
+    HIP_TRY(hipEventRecord(c->ev1, c->stream));
+    HIP_TRY(hipEventSynchronize(c->ev1));
+    HIP_TRY(hipEventElapsedTime(ms, c->ev0, c->ev1));
+    *ms /= kTimed;
+    return HGI_OK;
+}
+
+constexpr size_t kProbeMinBytes = (size_t)512 << 20;   // below this the stream lives in the 256 MiB Infinity Cache: no signal
+constexpr float kRegionSpread = 1.025f;                // same-region / other-region time ratio that counts as a signal
+constexpr int kMaxCandidates = 8;
+
+}  // namespace
+
+hgi_status hgi_probe_pair_u8_dev(hgi_ctx *c, const void *d_src, void *d_dst, size_t bytes, float *ms)
+{
+    if (!c || !d_src || !d_dst || !ms) return fail(HGI_EINVAL, "NULL argument");
+    if (bytes < 4096 * 64) return fail(HGI_EINVAL, "probe needs at least 256 KiB");
+    const uintptr_t a = reinterpret_cast<uintptr_t>(d_src), b = reinterpret_cast<uintptr_t>(d_dst);
+    if (a < b + bytes && b < a + bytes) return fail(HGI_EINVAL, "probe buffers overlap");
+    HIP_TRY(hipSetDevice(c->device));
+    HGI_TRY(ws_ensure(c, ws_need(c, 4096, 4096, 4, 1, (size_t)4096 * 4096)));
+    return probe_pair_ms(c, static_cast<const uint8_t *>(d_src), static_cast<uint8_t *>(d_dst), bytes, ms);
+}
+
+hgi_status hgi_planes_alloc(hgi_ctx *c, size_t bytes, uint32_t count, void **planes, int *separated)
+{
+    if (!c || !planes) return fail(HGI_EINVAL, "NULL argument");
+    if (separated) *separated = 0;
+    for (uint32_t i = 0; i < count; ++i) planes[i] = nullptr;
+    if (count == 0 || bytes == 0) return HGI_OK;
+    HIP_TRY(hipSetDevice(c->device));
+    auto release = [&](std::vector<void *> &v) {
+        for (void *p : v)
+            if (p) (void)hipFree(p);
+        v.clear();
+    };
+    std::vector<void *> pool, fillers;     // candidates not handed out yet; spacers that push the allocator onwards
+    auto bail = [&](hgi_status st) {
+        release(pool);
+        release(fillers);
+        for (uint32_t i = 0; i < count; ++i) {
+            if (planes[i]) (void)hipFree(planes[i]);
+            planes[i] = nullptr;
+        }
+        return st;
+    };
+    void *first = nullptr;
+    if (hipMalloc(&first, bytes) != hipSuccess) return bail(fail(HGI_ENOMEM, "hipMalloc of %zu bytes failed", bytes));
+    planes[0] = first;
+    const bool probing = bytes >= kProbeMinBytes && count > 1 && !getenv("HGI_NO_PLACEMENT");
+    if (probing) {
+        const hgi_status st = ws_ensure(c, ws_need(c, 4096, 4096, 4, 1, (size_t)4096 * 4096));
+        if (st != HGI_OK) return bail(st);
+    }
+    int all_separated = probing ? 1 : 0;
+    size_t filler_bytes = (size_t)8 << 30;
+    for (uint32_t i = 1; i < count; ++i) {
+        if (!probing) {
+            if (hipMalloc(&planes[i], bytes) != hipSuccess) return bail(fail(HGI_ENOMEM, "hipMalloc of %zu bytes failed", bytes));
+            continue;
+        }
+        // time prev -> candidate for the candidates at hand; allocate more (with spacers in between, so that the
+        // candidates spread over the device's memory) until two clearly different times have been seen
+        std::vector<float> t;
+        for (;;) {
+            while (t.size() < pool.size()) {
+                float ms = 0;
+                const hgi_status st = probe_pair_ms(c, static_cast<const uint8_t *>(planes[i - 1]),
+                                                    static_cast<uint8_t *>(pool[t.size()]), bytes, &ms);
+                if (st != HGI_OK) return bail(st);
+                t.push_back(ms);
+            }
+            float lo = 1e30f, hi = 0;
+            for (float v : t) {
+                lo = v < lo ? v : lo;
+                hi = v > hi ? v : hi;
+            }
+            if (t.size() >= 2 && hi >= lo * kRegionSpread) break;          // both kinds seen
+            if ((int)pool.size() >= kMaxCandidates) break;                  // give up: take the quickest
+            void *cand = nullptr, *fill = nullptr;
+            if (!pool.empty() && hipMalloc(&fill, filler_bytes) == hipSuccess) fillers.push_back(fill);
+            (void)hipGetLastError();
+            if (hipMalloc(&cand, bytes) != hipSuccess) {
+                (void)hipGetLastError();
+                if (pool.empty()) return bail(fail(HGI_ENOMEM, "hipMalloc of %zu bytes failed", bytes));
+                break;
+            }
+            pool.push_back(cand);
+            if (pool.size() == 4) filler_bytes = (size_t)32 << 30;          // still nothing: stride faster
+        }
+        size_t best = 0;
+        float lo = 1e30f, hi = 0;
+        for (size_t j = 0; j < t.size(); ++j) {
+            if (t[j] < lo) { lo = t[j]; best = j; }
+            hi = t[j] > hi ? t[j] : hi;
+        }
+        if (!(t.size() >= 2 && hi >= lo * kRegionSpread)) all_separated = 0;   // never saw a slower pairing: unknown
+        planes[i] = pool[best];
+        pool.erase(pool.begin() + (long)best);
+    }
+    release(pool);
+    release(fillers);
+    if (separated) *separated = all_separated;
+    return HGI_OK;
+}
+
+hgi_status hgi_planes_free(hgi_ctx *c, uint32_t count, void **planes)
+{
+    if (!c || (!planes && count)) return fail(HGI_EINVAL, "NULL argument");
+    HIP_TRY(hipSetDevice(c->device));
+    for (uint32_t i = 0; i < count; ++i) {
+        if (planes[i]) HIP_TRY(hipFree(planes[i]));
+        planes[i] = nullptr;
+    }
+    return HGI_OK;
+}
+
 hgi_status hgi_timer_start(hgi_ctx *c)
 {
     if (!c) return fail(HGI_EINVAL, "ctx is NULL");

@@ -747,3 +747,39 @@ def test_banded_bands_never_read_rows_of_the_next_upload():
                         "-p", "no:cacheprovider", "-k", "test_banded_host_frames"],
                        env=dict(os.environ, HGI_TEST_BAND_HOLD="1"), capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-1000:]
+
+
+def test_planes_alloc_places_neighbours_in_different_regions(H, oracle):
+    """hgi_planes_alloc (include/hgi.h): planes are ordinary device buffers -- the codec is bit-exact on them through
+    torch views -- and, when the probe could tell, a launch between neighbouring planes is faster than one between
+    planes two apart (which share a region in a chain of three)."""
+    import torch
+    ctx = H.Context(0)
+    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    small = H.Planes(ctx, 1 << 20, 2)                      # below the probe size: plain allocations, not separated
+    assert len(small.pointers) == 2 and all(small.pointers) and not small.separated
+    small.close()
+    F, S = 64, 4096
+    planes = H.Planes(ctx, F * S * S, 3)
+    assert len(set(planes.pointers)) == 3 and all(planes.pointers)
+    img, grid, out = (planes.torch(i, (F, S, S)) for i in range(3))
+    assert img.data_ptr() == planes.pointers[0] and grid.data_ptr() == planes.pointers[1]
+    from rustyhgi_amd import _ffi
+    _ffi.check(_ffi.lib().hgi_synth_u8_dev(ctx.handle, _ffi.SYNTH_RAMP, SEED0 + 3, 0, S, S, img.data_ptr(), F, S * S))
+    lut = oracle.linear_lut(2)[0]
+    enc = H.Encoder(H.interpolator.Crossed(), H.quantizator.Linear.from_level(H.quantizator.QuantizationLevel.Medium), 4, context=ctx)
+    dec = H.Decoder(H.interpolator.Crossed(), context=ctx)
+    enc.encode_batch(img, out=grid)
+    dec.decode_batch(grid, 4, out=out)
+    torch.cuda.synchronize()
+    for f in (0, F - 1):
+        want = oracle.encode(img[f].cpu().numpy(), 4, lut)
+        assert_same(grid[f].cpu().numpy(), want, "encode on placed planes, frame %d" % f)
+        assert_same(out[f].cpu().numpy(), oracle.decode(want, 4), "decode on placed planes, frame %d" % f)
+    if planes.separated:
+        near = min(planes.probe_ms(0, 1), planes.probe_ms(1, 2))
+        far = planes.probe_ms(0, 2)
+        assert near < far, (near, far)
+    del img, grid, out
+    planes.close()
+    ctx.close()
