@@ -102,6 +102,15 @@ static_assert(TH != 64 || 18 * (buf_bytes(4) + rbuf_bytes(4) + 256) <= 160 * 102
 #define HGI_ABL 0   // timing experiments: 1 no coarse levels, 2 no fine arithmetic, 4 no halo cells, 8 no sub==2 level,
                     // 16 no halo-column loads, 32 no halo-row loads
 #endif
+#ifndef HGI_TILE_ORDER
+#define HGI_TILE_ORDER 0      // order of the interior tiles inside a frame: 0 row-major (shipped); 1..3 experiments
+#endif
+#ifndef HGI_TILE_BAND
+#define HGI_TILE_BAND 8
+#endif
+#ifndef HGI_TILE_REVERSE_X
+#define HGI_TILE_REVERSE_X 0
+#endif
 #ifndef HGI_HALO_ALL_ROWS
 #define HGI_HALO_ALL_ROWS 0   // 1: fetch the halo-column offsets >= 16 on every even row (the round-1 behaviour)
 #endif
@@ -1108,8 +1117,29 @@ __device__ __forceinline__ Tile fast_tile(u32 t, const TileGrid &g)
     const u32 tpf = g.full_x * g.full_y;
     Tile tl;
     tl.frame = t / tpf;
-    const u32 tt = t - tl.frame * tpf, ty = tt / g.full_x;
-    tl.X0 = (tt - ty * g.full_x) * TW;
+    const u32 tt = t - tl.frame * tpf;
+    u32 ty = tt / g.full_x, tx = tt - ty * g.full_x;
+#if HGI_TILE_ORDER == 1          // right to left within a tile row
+    tx = g.full_x - 1 - tx;
+#elif HGI_TILE_ORDER == 2 || HGI_TILE_ORDER == 3
+    // bands of HGI_TILE_BAND tile rows (experiments; frames whose interior does not divide keep row-major order)
+    constexpr u32 R = HGI_TILE_BAND;
+    if (g.full_y % R == 0 && g.full_x % 2 == 0) {
+        const u32 per = R * g.full_x, band = tt / per, r = tt - band * per;
+#if HGI_TILE_ORDER == 2          // even tile columns of the band first, then the odd ones
+        const u32 half = g.full_x / 2, odd = r >= R * half, q = r - odd * R * half;
+        ty = band * R + q / half;
+        tx = 2 * (q % half) + odd;
+#else                            // column-major inside the band: x-neighbours R apart, y-neighbours adjacent
+        tx = r / R;
+        ty = band * R + r % R;
+#if HGI_TILE_REVERSE_X           // ... walking the band right to left: the right neighbour is dispatched R tiles EARLIER
+        tx = g.full_x - 1 - tx;
+#endif
+#endif
+    }
+#endif
+    tl.X0 = tx * TW;
     tl.Y0 = ty * TH;
     return tl;
 }

@@ -10,6 +10,13 @@ numpy restatement (oracle/hgi_numpy.py) before anything is written.
   fullhd_luma.png    1920x1080 luma of res/fullhd.jpg decoded by PIL convert('L')
                      -- INPUT PARITY UNPINNED: the reference decodes JPEG with the `image`
                      crate (different IDCT / luma weights); this file *is* config C1's input.
+  docs_lena_pair.npz the one input/output pair the reference itself holds: docs/static_files/lena_source.png
+                     ("source", README.md:6) and lena_hgi.png ("HGI compressed (low)", README.md:8-9), 400x400, as luma
+                     planes.  The source is a grey palette PNG; its luma is taken the way image-0.19's to_luma does it
+                     (truncated f32 0.2126 R + 0.7152 G + 0.0722 B), under which the stride-16 base lattice of the
+                     two planes is identical.  The output was made by ANOTHER REVISION of the algorithm (it is not
+                     bit-reproducible by the current source under any predictor rounding tried), so it pins
+                     properties only: tests/test_oracle.py::test_reference_held_docs_pair.
   small_cases.npz    inputs + full expected grids/reconstructions for the tiny cases
   golden.json        sha256 / fallback count / max error for every case (incl. big synthetic)
 """
@@ -66,6 +73,13 @@ def main():
     fullhd = np.array(Image.open(os.path.join(REF, "res/fullhd.jpg")).convert("L"))
     assert fullhd.shape == (1080, 1920)
     Image.fromarray(fullhd).save(os.path.join(HERE, "fullhd_luma.png"), optimize=True)
+
+    # the reference's own before / after pair (README.md:6-9)
+    rgb = np.array(Image.open(os.path.join(REF, "docs/static_files/lena_source.png")).convert("RGB")).astype(np.float32)
+    luma = np.floor(np.float32(0.2126) * rgb[..., 0] + np.float32(0.7152) * rgb[..., 1] + np.float32(0.0722) * rgb[..., 2])
+    after = np.array(Image.open(os.path.join(REF, "docs/static_files/lena_hgi.png")))
+    assert luma.shape == after.shape == (400, 400) and after.dtype == np.uint8
+    np.savez_compressed(os.path.join(HERE, "docs_lena_pair.npz"), source_luma=luma.astype(np.uint8), hgi_low=after)
 
     golden, small = {}, {}
     rng = np.random.default_rng(SEED0)
