@@ -38,6 +38,7 @@ using namespace dev;
 #ifndef HGI_TILE_H
 #define HGI_TILE_H 64
 #endif
+#define HGI_LOG2(v) ((v) == 32 ? 5 : (v) == 16 ? 4 : (v) == 8 ? 3 : (v) == 4 ? 2 : 1)
 #define HGI_CAT2(a, b) a##_##b
 #define HGI_CAT(a, b) HGI_CAT2(a, b)
 #define HGI_TILED(name) HGI_CAT(name, HGI_TILE_H)   // launch_decode_fused -> launch_decode_fused_64
@@ -107,6 +108,9 @@ static_assert(TH != 64 || 18 * (buf_bytes(4) + rbuf_bytes(4) + 256) <= 160 * 102
 #endif
 #ifndef HGI_TILE_BAND
 #define HGI_TILE_BAND 8
+#endif
+#ifndef HGI_TILE_ORDER_Y
+#define HGI_TILE_ORDER_Y 0
 #endif
 #ifndef HGI_TILE_REVERSE_X
 #define HGI_TILE_REVERSE_X 0
@@ -1121,21 +1125,40 @@ __device__ __forceinline__ Tile fast_tile(u32 t, const TileGrid &g)
     u32 ty = tt / g.full_x, tx = tt - ty * g.full_x;
 #if HGI_TILE_ORDER == 1          // right to left within a tile row
     tx = g.full_x - 1 - tx;
-#elif HGI_TILE_ORDER == 2 || HGI_TILE_ORDER == 3
-    // bands of HGI_TILE_BAND tile rows (experiments; frames whose interior does not divide keep row-major order)
+#elif HGI_TILE_ORDER == 2
+    // bands of HGI_TILE_BAND tile rows, even tile columns of the band first, then the odd ones (experiment; frames whose
+    // interior does not divide keep row-major order)
     constexpr u32 R = HGI_TILE_BAND;
     if (g.full_y % R == 0 && g.full_x % 2 == 0) {
         const u32 per = R * g.full_x, band = tt / per, r = tt - band * per;
-#if HGI_TILE_ORDER == 2          // even tile columns of the band first, then the odd ones
         const u32 half = g.full_x / 2, odd = r >= R * half, q = r - odd * R * half;
         ty = band * R + q / half;
         tx = 2 * (q % half) + odd;
-#else                            // column-major inside the band: x-neighbours R apart, y-neighbours adjacent
-        tx = r / R;
-        ty = band * R + r % R;
-#if HGI_TILE_REVERSE_X           // ... walking the band right to left: the right neighbour is dispatched R tiles EARLIER
-        tx = g.full_x - 1 - tx;
+    }
+#elif HGI_TILE_ORDER == 3
+    // Bands of HGI_TILE_BAND tile rows, column-major inside a band: x-neighbours are dispatched `rows` tiles apart,
+    // y-neighbours next to each other.  The last band of a frame takes the rows that are left.
+    {
+        constexpr u32 R = HGI_TILE_BAND;
+        const u32 per = R * g.full_x, nfull = (g.full_y / R) * per;
+        u32 rows = R, row0, r;
+        if (tt < nfull) {
+            const u32 band = tt / per;
+            r = tt - band * per;
+            row0 = band * R;
+        } else {
+            rows = g.full_y % R;
+            r = tt - nfull;
+            row0 = g.full_y - rows;
+        }
+        tx = r / rows;
+        u32 q = r - tx * rows;
+#if HGI_TILE_ORDER_Y == 1          // even rows of the band first, then the odd ones: y-neighbours rows / 2 apart as well
+        q = q < (rows + 1) / 2 ? 2 * q : 2 * (q - (rows + 1) / 2) + 1;
 #endif
+        ty = row0 + q;
+#if HGI_TILE_REVERSE_X             // ... walking the band right to left: the right neighbour is dispatched EARLIER
+        tx = g.full_x - 1 - tx;
 #endif
     }
 #endif
@@ -1220,16 +1243,25 @@ __device__ __forceinline__ void dec_seed_commit(u8 *buf, const SeedRegs &r, u32 
 template <int INTERP>
 __device__ __forceinline__ void dec_tile_fast(u8 *buf, const TileCtx &cur, const v4u (&odd)[NFINE], u32 k, u32 W, u32 H)
 {
-    for (int s = 1 << (k - 1); s >= 2 && !(HGI_ABL & 1); s >>= 1) {
-        if (s == 2) {
-            HGI_MARK("level2");
-            if (!(HGI_ABL & 8)) dec_level2_fast<INTERP>(buf);
-        } else {
-            HGI_MARK("coarse");
-            dec_cells<INTERP, false>(buf, s, cur.tl, W, H);
-        }
+    // straight-line chain, the level a compile-time constant in each link (see enc_tile_fast)
+#define HGI_DEC_COARSE(SUB)                                                                    \
+    if (k > HGI_LOG2(SUB) && !(HGI_ABL & 1)) {                                                 \
+        HGI_MARK("coarse");                                                                    \
+        dec_cells<INTERP, false>(buf, SUB, cur.tl, W, H);                                      \
+        HGI_MARK("halo");                                                                      \
+        if (!(HGI_ABL & 4)) dec_halo_cells<INTERP>(buf, SUB, cur.tl, W, H);                    \
+        LDS_ORDER();                                                                           \
+    }
+    if (MAXK >= 6) HGI_DEC_COARSE(32)
+    HGI_DEC_COARSE(16)
+    HGI_DEC_COARSE(8)
+    HGI_DEC_COARSE(4)
+#undef HGI_DEC_COARSE
+    if (k >= 2 && !(HGI_ABL & 1)) {
+        HGI_MARK("level2");
+        if (!(HGI_ABL & 8)) dec_level2_fast<INTERP>(buf);
         HGI_MARK("halo");
-        if (!(HGI_ABL & 4)) dec_halo_cells<INTERP>(buf, s, cur.tl, W, H);
+        if (!(HGI_ABL & 4)) dec_halo_cells<INTERP>(buf, 2, cur.tl, W, H);
         LDS_ORDER();
     }
     HGI_MARK("fine");
@@ -1381,14 +1413,23 @@ template <int INTERP, bool IDENT>
 __device__ __forceinline__ void enc_tile_fast(u8 *buf, u8 *rbuf, const u8 *slut, const TileCtx &cur,
                                               const v4u (&odd)[NFINE], u32 k, u32 W, u32 H)
 {
-    for (int s = 1 << (k - 1); s >= 2 && !(HGI_ABL & 1); s >>= 1) {
-        if (s == 2) {
-            HGI_MARK("level2");
-            enc_level2_fast<INTERP, IDENT>(buf, rbuf, slut, cur.tl, W, H);
-        } else {
-            HGI_MARK("coarse");
-            enc_level_coarse_fast<INTERP, IDENT>(buf, rbuf, slut, s, cur.tl, W, H);
-        }
+    // One straight-line chain with the level as a compile-time constant in each link (k only selects where the chain
+    // is entered): every LDS address of a level is then `lane-dependent base + immediate`, instead of shifts by a
+    // run-time log2(step) -- the address arithmetic was a third of the kernel's VALU instructions.
+#define HGI_ENC_COARSE(SUB)                                                                    \
+    if (k > HGI_LOG2(SUB) && !(HGI_ABL & 1)) {                                                 \
+        HGI_MARK("coarse");                                                                    \
+        enc_level_coarse_fast<INTERP, IDENT>(buf, rbuf, slut, SUB, cur.tl, W, H);              \
+        LDS_ORDER();                                                                           \
+    }
+    if (MAXK >= 6) HGI_ENC_COARSE(32)
+    HGI_ENC_COARSE(16)
+    HGI_ENC_COARSE(8)
+    HGI_ENC_COARSE(4)
+#undef HGI_ENC_COARSE
+    if (k >= 2 && !(HGI_ABL & 1)) {
+        HGI_MARK("level2");
+        enc_level2_fast<INTERP, IDENT>(buf, rbuf, slut, cur.tl, W, H);
         LDS_ORDER();
     }
     HGI_MARK("fine");
