@@ -102,6 +102,9 @@ def parse_args(argv=None):
     ap.add_argument("--quant", default="medium")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--no-pfine", action="store_true", help="skip the P_fine (levels = 1) leg")
+    ap.add_argument("--no-extras", action="store_true",
+                    help="only the timed steps and the copy yardstick: no P_fine leg, no plain-allocation comparison "
+                         "(profiling passes: every k_*_tiles launch in the trace is then a launch of the headline workload)")
     ap.add_argument("--xgmi-scatter", action="store_true",
                     help="also time the labelled variant where all frames start and end on GPU 0 (scatter, code, gather)")
     ap.add_argument("--placement", choices=("planes", "torch"), default="planes",
@@ -244,8 +247,8 @@ def run_rank(args):
 
     enc_ms, dec_ms = codec.mean_ms()
     copy_ms = codec.copy_ms() if rank == 0 else None
-    pfine = codec.p_fine() if rank == 0 and not args.no_pfine else None
-    placement = codec.placement() if rank == 0 else None
+    pfine = codec.p_fine() if rank == 0 and not (args.no_pfine or args.no_extras) else None
+    placement = codec.placement(compare=not args.no_extras) if rank == 0 else None
     xgmi = codec.xgmi(dist, world, rank, fence, args.steps) if args.xgmi_scatter else None
 
     # ---- per-rank checks + stats gather (RCCL all-gather) ----
@@ -454,7 +457,7 @@ class Codec:
         self._restore()
         return res
 
-    def placement(self):
+    def placement(self, compare=True):
         """How the frame stacks were placed, and -- for transparency -- the same step timed on plain torch allocations
         in this process (their regions are whatever the allocator gave: either pairing may come out fast or slow)."""
         torch, F, S = self.torch, self.F, self.S
@@ -462,6 +465,8 @@ class Codec:
         if self.planes is not None:
             info.update({"api": "hgi_planes_alloc(bytes, 3): neighbouring planes in different HBM regions (DESIGN.md 5.1)",
                          "separated": self.planes.separated})
+        if not compare:
+            return info
         a = torch.empty((F, S, S), dtype=torch.uint8, device=self.dev)
         b, c = torch.empty_like(a), torch.empty_like(a)
         a.copy_(self.imgs)

@@ -109,6 +109,12 @@ static_assert(TH != 64 || 18 * (buf_bytes(4) + rbuf_bytes(4) + 256) <= 160 * 102
 #ifndef HGI_TILE_BAND
 #define HGI_TILE_BAND 8
 #endif
+#ifndef HGI_TILE_REVERSE_Y
+#define HGI_TILE_REVERSE_Y 0
+#endif
+#ifndef HGI_HALO_FIRST
+#define HGI_HALO_FIRST 0
+#endif
 #ifndef HGI_TILE_ORDER_Y
 #define HGI_TILE_ORDER_Y 0
 #endif
@@ -729,6 +735,9 @@ __device__ __forceinline__ void stage_issue(Stage &st, const Buf &b, Tile tl, in
     // first pixels behind the image's last ones: cleared after the load, like everything else outside
     const bool narrow = RAGGED && tl.X0 + TW > W;   // wave-uniform: this tile straddles the right edge
     const v4u cm = narrow ? chunk_mask((int)W - (int)(tl.X0 + 16 * c)) : v4u{~0u, ~0u, ~0u, ~0u};
+    // Issue order.  HGI_HALO_FIRST: the few halo loads go out before the tile's own rows, so that they reach L2 ahead of
+    // the body loads of the tiles that own those lines (which the band order dispatches later).
+    auto issue_body = [&]() __attribute__((always_inline)) {
 #pragma unroll
     for (int j = 0; j < TH / 16; ++j) {
         st.e[j] = v4u{0, 0, 0, 0};
@@ -746,6 +755,8 @@ __device__ __forceinline__ void stage_issue(Stage &st, const Buf &b, Tile tl, in
         if (RAGGED && ODD_CHECKED && cin) st.o[j] = __builtin_amdgcn_raw_buffer_load_b128(b.rs, vodd + j * 16 * W, 0, HGI_ODD_LOAD_AUX);
         if (narrow) st.o[j] &= cm;
     }
+    };
+    auto issue_halo = [&]() __attribute__((always_inline)) {
     st.hv = v4u{0, 0, 0, 0};
     if (!(HGI_ABL & 32) && lane < nh * CH && cin) st.hv = __builtin_amdgcn_raw_buffer_load_b128(b.rs, b.base + (TH + hoff(r)) * W + 16 * c, 0, 0);
     if (narrow) st.hv &= cm;
@@ -765,6 +776,14 @@ __device__ __forceinline__ void stage_issue(Stage &st, const Buf &b, Tile tl, in
         if (k >= 4 && (all || !(hy & 15)) && xr + 16 < W) st.d16 = __builtin_amdgcn_raw_buffer_load_b32(b.rs, xo + 16, 0, 0);
         if (k >= 5 && (all || !(hy & 31)) && xr + 32 < W) st.d32 = __builtin_amdgcn_raw_buffer_load_b32(b.rs, xo + 32, 0, 0);
         if (k >= 6 && (all || !(hy & 63)) && xr + 64 < W) st.d64 = __builtin_amdgcn_raw_buffer_load_b32(b.rs, xo + 64, 0, 0);
+    }
+    };
+    if (HGI_HALO_FIRST) {
+        issue_halo();
+        issue_body();
+    } else {
+        issue_body();
+        issue_halo();
     }
 }
 
@@ -1155,6 +1174,9 @@ __device__ __forceinline__ Tile fast_tile(u32 t, const TileGrid &g)
         u32 q = r - tx * rows;
 #if HGI_TILE_ORDER_Y == 1          // even rows of the band first, then the odd ones: y-neighbours rows / 2 apart as well
         q = q < (rows + 1) / 2 ? 2 * q : 2 * (q - (rows + 1) / 2) + 1;
+#endif
+#if HGI_TILE_REVERSE_Y             // ... and bottom to top: the tile below (owner of the halo rows) is dispatched earlier too
+        q = rows - 1 - q;
 #endif
         ty = row0 + q;
 #if HGI_TILE_REVERSE_X             // ... walking the band right to left: the right neighbour is dispatched EARLIER

@@ -6,8 +6,8 @@
 # (FETCH_SIZE and WRITE_SIZE do not fit one TCC pass; never mix --pmc with API tracing).
 set -u
 TAG=${1:-r01}; shift || true
-ARGS=${@:---steps 20 --warmup 3 --no-cpu}
-PASSES=${PASSES:-trace fetch write sq1 sq2 tcc}
+ARGS=${@:---steps 20 --warmup 3 --no-cpu --no-extras}
+PASSES=${PASSES:-trace fetch write sq1 sq2 tcc pfine}
 OUT=$PWD/gpurun_out/prof/$TAG
 mkdir -p "$OUT"
 export TMPDIR=/tmp
@@ -23,6 +23,11 @@ run write --kernel-trace --pmc WRITE_SIZE
 run sq1 --kernel-trace --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_LDS
 run sq2 --kernel-trace --pmc SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAIT_INST_LDS SQ_INSTS_SALU
 run tcc --kernel-trace --pmc TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum
+# P_fine: the product kernels at levels = 1 (tools/pfine.py), kernel trace only
+case " $PASSES " in *" pfine "*)
+  ( cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/pfine" -- python3 "$OLDPWD/tools/pfine.py" ) > "$OUT/pfine.log" 2>&1
+  echo "pfine rc=$?" >> "$OUT/passes.log";;
+esac
 python3 tools/summarize_prof.py "$OUT" > "$OUT/summary.md" 2>"$OUT/summarize.err"
 python3 tools/summarize_prof.py "$OUT" --traffic 64 4096 4 > "$OUT/traffic.json" 2>>"$OUT/summarize.err"
 cat "$OUT/passes.log"

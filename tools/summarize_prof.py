@@ -29,6 +29,35 @@ def main(out):
     for k, v in sorted(dur.items(), key=lambda kv: -sum(kv[1])):
         print("| %s | %d | %.2f | %.2f | %.2f | %.3f |" % (k, len(v), sum(v) / len(v) / 1e3, min(v) / 1e3,
                                                            max(v) / 1e3, sum(v) / 1e6))
+    pf = defaultdict(list)
+    for path in glob.glob(os.path.join(out, "pfine", "**", "*kernel_trace.csv"), recursive=True):
+        for row in csv.DictReader(open(path)):
+            pf[short(row["Kernel_Name"])].append(int(row["End_Timestamp"]) - int(row["Start_Timestamp"]))
+    if pf:
+        print("\n## P_fine (pass `pfine`: tools/pfine.py under --kernel-trace --stats)\n")
+        print("`k_*_tiles` rows: the product kernels at levels = 1 on 64 x 4096^2 (the finest pass alone; 1.75 B/px algorithmic,")
+        print("2 B/px moved).  `k_*_level` rows: the level-wise path at levels = 4, one launch per level (4 per direction; the")
+        print("slowest of each is the finest pass).\n")
+        print("| kernel | launches | avg us | min us | max us | 1.75 B/px GB/s (avg) | frac of 8 TB/s |")
+        print("|---|---|---|---|---|---|---|")
+        n = 64 * 4096 * 4096
+        for k, v in sorted(pf.items(), key=lambda kv: -sum(kv[1])):
+            if not k.startswith("k_"):
+                continue
+            avg = sum(v) / len(v)
+            tiles = "_tiles" in k
+            gbs = 1.75 * n / avg if tiles else float("nan")
+            print("| %s | %d | %.2f | %.2f | %.2f | %s | %s |" % (k, len(v), avg / 1e3, min(v) / 1e3, max(v) / 1e3,
+                                                                 "%.0f" % gbs if tiles else "-", "%.3f" % (gbs / 8000) if tiles else "-"))
+        try:
+            log = open(os.path.join(out, "pfine.log")).read().splitlines()
+            print("\n```")
+            for line in log:
+                if line.startswith(("planes separated", "P_fine", "  encode", "  decode", "level-wise")):
+                    print(line)
+            print("```")
+        except OSError:
+            pass
     print("\n## PMC (one pass per group; averages per launch)\n")
     for name in ("fetch", "write", "sq1", "sq2", "tcc"):
         files = glob.glob(os.path.join(out, name, "**", "*counter_collection.csv"), recursive=True)
