@@ -212,6 +212,12 @@ def run_rank(args):
     else:
         codec = Codec(args, dev, local, lut, err, levels, first)
 
+    # The device's clocks ramp over the first ~25 ms of work after idle, and the encoder (75 % VALU utilisation at full
+    # clock) runs up to 1.4x slower until they have (tools/ramp.py, profiles/r02_ramp.txt; the decoder, 45 %, does not
+    # care).  W = 5 warm-up steps are 4 ms.  So the device is first kept busy with untimed steps of the same workload
+    # until the step time has stopped falling (bounded; reported as config.settle): the timed steps then measure the
+    # steady state a batch job runs in, not the power manager's ramp.
+    settle = codec.settle() if codec else None
     for _ in range(args.warmup):
         if codec:
             codec.step()
@@ -290,6 +296,8 @@ def run_rank(args):
                                            "note": "16-B/lane copy kernel moving the same bytes"}},
         }
         line["config"]["placement"] = placement
+        line["config"]["per_step_ms"] = codec.per_step_ms()
+        line["config"]["settle"] = settle
         if pfine is not None:
             line["p_fine"] = pfine
         if xgmi is not None:
@@ -345,6 +353,25 @@ class Codec:
         self.enc.encode_batch(self.imgs, out=self.grids)
         self.dec.decode_batch(self.grids, self.levels, out=self.outs)
 
+    def settle(self, group=8, max_steps=160, tol=0.004):
+        """Untimed steps in groups until two consecutive groups agree within `tol` (at least three groups)."""
+        torch = self.torch
+        series = []
+        while len(series) * group < max_steps:
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            for _ in range(group):
+                self.step()
+            b.record()
+            b.synchronize()
+            series.append(a.elapsed_time(b) / group)
+            if len(series) >= 3 and abs(series[-1] - series[-2]) <= tol * series[-2]:
+                break
+        return {"steps": len(series) * group, "first_group_ms_per_step": round(series[0], 4),
+                "last_group_ms_per_step": round(series[-1], 4),
+                "note": "untimed steps of the same workload before the W warm-up steps, until the step time stops "
+                        "falling: device clocks ramp for ~25 ms after idle and the encoder is clock-sensitive until then"}
+
     def make_events(self, steps):
         self.ev = [[self.torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(steps)]
 
@@ -359,6 +386,11 @@ class Codec:
     def mean_ms(self):
         return (float(np.mean([e[0].elapsed_time(e[1]) for e in self.ev])),
                 float(np.mean([e[1].elapsed_time(e[2]) for e in self.ev])))
+
+    def per_step_ms(self):
+        """every timed step's two launches, in order (shows drift inside the timed region, if any)"""
+        return {"encode": [round(e[0].elapsed_time(e[1]), 4) for e in self.ev],
+                "decode": [round(e[1].elapsed_time(e[2]), 4) for e in self.ev]}
 
     def _timed(self, fn, reps, warm=1):
         torch = self.torch

@@ -768,7 +768,9 @@ hgi_status probe_pair_ms(hgi_ctx *c, const uint8_t *prev, uint8_t *cand, size_t 
     for (int i = 0; i < kWarm + kTimed; ++i) {
         if (i == kWarm) HIP_TRY(hipEventRecord(c->ev0, c->stream));
         c->ws_used = 0;
-        HGI_TRY(decode_impl(c, prev, w, h, 4, HGI_INTERP_CROSSED, cand, 1, (size_t)w * h));
+        // LeftTop: the same memory-access structure as Crossed, and a kernel name of its own in profiles
+        // (k_dec_tiles<0, ...>), so that probe launches are never counted among the workload's k_dec_tiles<1, ...>
+        HGI_TRY(decode_impl(c, prev, w, h, 4, HGI_INTERP_LEFTTOP, cand, 1, (size_t)w * h));
     }
     HIP_TRY(hipEventRecord(c->ev1, c->stream));
     HIP_TRY(hipEventSynchronize(c->ev1));
@@ -778,7 +780,9 @@ hgi_status probe_pair_ms(hgi_ctx *c, const uint8_t *prev, uint8_t *cand, size_t 
 }
 
 constexpr size_t kProbeMinBytes = (size_t)512 << 20;   // below this the stream lives in the 256 MiB Infinity Cache: no signal
-constexpr float kRegionSpread = 1.025f;                // same-region / other-region time ratio that counts as a signal
+constexpr float kFastRatio = 0.96f;   // a pair counts as "different regions" when it streams in < 0.96 of the same-region
+                                      // yardstick's time (measured: 0.93-0.94 across regions, 0.97-1.0 within or between
+                                      // some pairs of blocks)
 constexpr int kMaxCandidates = 8;
 
 }  // namespace
@@ -801,78 +805,150 @@ hgi_status hgi_planes_alloc(hgi_ctx *c, size_t bytes, uint32_t count, void **pla
     for (uint32_t i = 0; i < count; ++i) planes[i] = nullptr;
     if (count == 0 || bytes == 0) return HGI_OK;
     HIP_TRY(hipSetDevice(c->device));
+    std::vector<void *> bufs, spacers;     // candidate planes; allocations that only push the driver onwards
+    void *ref = nullptr;                   // one allocation whose two halves are the same-region yardstick
     auto release = [&](std::vector<void *> &v) {
         for (void *p : v)
             if (p) (void)hipFree(p);
         v.clear();
+        (void)hipGetLastError();
     };
-    std::vector<void *> pool, fillers;     // candidates not handed out yet; spacers that push the allocator onwards
     auto bail = [&](hgi_status st) {
-        release(pool);
-        release(fillers);
-        for (uint32_t i = 0; i < count; ++i) {
-            if (planes[i]) (void)hipFree(planes[i]);
-            planes[i] = nullptr;
-        }
+        release(bufs);
+        release(spacers);
+        if (ref) (void)hipFree(ref);
+        for (uint32_t i = 0; i < count; ++i) planes[i] = nullptr;
         return st;
     };
-    void *first = nullptr;
-    if (hipMalloc(&first, bytes) != hipSuccess) return bail(fail(HGI_ENOMEM, "hipMalloc of %zu bytes failed", bytes));
-    planes[0] = first;
+    for (uint32_t i = 0; i < count; ++i) {
+        void *p = nullptr;
+        if (hipMalloc(&p, bytes) != hipSuccess) return bail(fail(HGI_ENOMEM, "hipMalloc of %zu bytes failed", bytes));
+        bufs.push_back(p);
+    }
+    auto hand_out = [&](const std::vector<int> &order) {
+        std::vector<char> used(bufs.size(), 0);
+        for (uint32_t i = 0; i < count; ++i) {
+            planes[i] = bufs[(size_t)order[i]];
+            used[(size_t)order[i]] = 1;
+        }
+        for (size_t j = 0; j < bufs.size(); ++j)
+            if (!used[j]) (void)hipFree(bufs[j]);
+        bufs.clear();
+        release(spacers);
+        if (ref) (void)hipFree(ref);
+        ref = nullptr;
+        (void)hipGetLastError();
+    };
+    std::vector<int> plain(count);
+    for (uint32_t i = 0; i < count; ++i) plain[i] = (int)i;
     const bool probing = bytes >= kProbeMinBytes && count > 1 && !getenv("HGI_NO_PLACEMENT");
-    if (probing) {
+    if (!probing) {
+        hand_out(plain);
+        return HGI_OK;
+    }
+    {
         const hgi_status st = ws_ensure(c, ws_need(c, 4096, 4096, 4, 1, (size_t)4096 * 4096));
         if (st != HGI_OK) return bail(st);
     }
-    int all_separated = probing ? 1 : 0;
-    size_t filler_bytes = (size_t)8 << 30;
-    for (uint32_t i = 1; i < count; ++i) {
-        if (!probing) {
-            if (hipMalloc(&planes[i], bytes) != hipSuccess) return bail(fail(HGI_ENOMEM, "hipMalloc of %zu bytes failed", bytes));
-            continue;
-        }
-        // time prev -> candidate for the candidates at hand; allocate more (with spacers in between, so that the
-        // candidates spread over the device's memory) until two clearly different times have been seen
-        std::vector<float> t;
-        for (;;) {
-            while (t.size() < pool.size()) {
-                float ms = 0;
-                const hgi_status st = probe_pair_ms(c, static_cast<const uint8_t *>(planes[i - 1]),
-                                                    static_cast<uint8_t *>(pool[t.size()]), bytes, &ms);
-                if (st != HGI_OK) return bail(st);
-                t.push_back(ms);
-            }
-            float lo = 1e30f, hi = 0;
-            for (float v : t) {
-                lo = v < lo ? v : lo;
-                hi = v > hi ? v : hi;
-            }
-            if (t.size() >= 2 && hi >= lo * kRegionSpread) break;          // both kinds seen
-            if ((int)pool.size() >= kMaxCandidates) break;                  // give up: take the quickest
-            void *cand = nullptr, *fill = nullptr;
-            if (!pool.empty() && hipMalloc(&fill, filler_bytes) == hipSuccess) fillers.push_back(fill);
-            (void)hipGetLastError();
-            if (hipMalloc(&cand, bytes) != hipSuccess) {
-                (void)hipGetLastError();
-                if (pool.empty()) return bail(fail(HGI_ENOMEM, "hipMalloc of %zu bytes failed", bytes));
-                break;
-            }
-            pool.push_back(cand);
-            if (pool.size() == 4) filler_bytes = (size_t)32 << 30;          // still nothing: stride faster
-        }
-        size_t best = 0;
-        float lo = 1e30f, hi = 0;
-        for (size_t j = 0; j < t.size(); ++j) {
-            if (t[j] < lo) { lo = t[j]; best = j; }
-            hi = t[j] > hi ? t[j] : hi;
-        }
-        if (!(t.size() >= 2 && hi >= lo * kRegionSpread)) all_separated = 0;   // never saw a slower pairing: unknown
-        planes[i] = pool[best];
-        pool.erase(pool.begin() + (long)best);
+    // The yardstick: what a stream costs when source and destination share a region.  A power-of-two request is served
+    // as ONE block, and a block never straddles a region, so the two halves of such an allocation are a same-region pair
+    // by construction.  (Comparisons among candidates alone cannot tell "all fast" from "all slow".)
+    const size_t span = bytes < ((size_t)2 << 30) ? bytes : ((size_t)2 << 30);     // what a probe streams
+    size_t ref_bytes = 1;
+    while (ref_bytes < 2 * span) ref_bytes <<= 1;
+    if (hipMalloc(&ref, ref_bytes) != hipSuccess) {
+        (void)hipGetLastError();
+        ref = nullptr;
+        hand_out(plain);
+        return HGI_OK;
     }
-    release(pool);
-    release(fillers);
-    if (separated) *separated = all_separated;
+    uint8_t *ref_lo = static_cast<uint8_t *>(ref), *ref_hi = ref_lo + ref_bytes / 2;
+    // Every pair is timed AGAINST the yardstick, interleaved with it, after the yardstick has stopped drifting: the
+    // device's clocks fall back within milliseconds of idling (an allocation in between is enough) and ramp for ~25 ms
+    // once work resumes (profiles/r02_ramp.txt), so absolute times taken at different moments do not compare.
+    auto other_region = [&](int a, int b, bool *yes) -> hgi_status {
+        float last = 0, ms = 0;
+        HGI_TRY(probe_pair_ms(c, ref_lo, ref_hi, span, &last));
+        for (int it = 0; it < 12; ++it) {
+            HGI_TRY(probe_pair_ms(c, ref_lo, ref_hi, span, &ms));
+            const bool steady = ms <= last * 1.007f && last <= ms * 1.007f;
+            last = ms;
+            if (steady) break;
+        }
+        float same = 0, pair = 0;
+        for (int rep = 0; rep < 2; ++rep) {
+            HGI_TRY(probe_pair_ms(c, ref_lo, ref_hi, span, &ms));
+            same += ms;
+            HGI_TRY(probe_pair_ms(c, static_cast<const uint8_t *>(bufs[(size_t)a]), static_cast<uint8_t *>(bufs[(size_t)b]), span, &ms));
+            pair += ms;
+        }
+        *yes = pair < same * kFastRatio;
+        return HGI_OK;
+    };
+    // Candidates are sorted into groups that share a region (a candidate joins the first group whose representative it
+    // does NOT stream fast against).  `count` planes whose neighbours differ exist as soon as no group has to supply
+    // more than every other plane.  Until then: one more candidate, behind a spacer.  The driver serves requests
+    // buddy-style from blocks of up to 64 GiB, the smallest free piece that fits first, so candidates of one size tend to
+    // come from one block until it is used up (profiles/r02_modes4.txt: runs of 16); spacers of `bytes`, 2 x, 4 x ...
+    // take that block's free buddies.  Large allocations take the driver seconds (it clears them), hence the caps.
+    std::vector<std::vector<int>> groups;
+    size_t classified = 0;
+    int spacer_shift = 0;
+    std::vector<int> order;
+    for (;;) {
+        for (; classified < bufs.size(); ++classified) {
+            bool placed = false;
+            for (auto &g : groups) {
+                bool other = false;
+                const hgi_status st = other_region(g[0], (int)classified, &other);
+                if (st != HGI_OK) return bail(st);
+                if (!other) {
+                    g.push_back((int)classified);
+                    placed = true;
+                    break;
+                }
+            }
+            if (!placed) groups.push_back(std::vector<int>{(int)classified});
+        }
+        // greedy arrangement: always take from the largest remaining group that is not the one just used
+        std::vector<size_t> left(groups.size());
+        for (size_t g = 0; g < groups.size(); ++g) left[g] = groups[g].size();
+        order.clear();
+        int prev = -1;
+        while (order.size() < count) {
+            int pick = -1;
+            for (size_t g = 0; g < groups.size(); ++g)
+                if ((int)g != prev && left[g] > 0 && (pick < 0 || left[g] > left[(size_t)pick])) pick = (int)g;
+            if (pick < 0) break;
+            order.push_back(groups[(size_t)pick][groups[(size_t)pick].size() - left[(size_t)pick]]);
+            --left[(size_t)pick];
+            prev = pick;
+        }
+        if (order.size() == count) break;                                   // neighbours all in different regions
+        if (bufs.size() >= (size_t)count + kMaxCandidates) break;           // give up
+        size_t free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && spacer_shift <= 5 && (bytes << spacer_shift) <= free_b / 3) {
+            void *fill = nullptr;
+            if (hipMalloc(&fill, bytes << spacer_shift) == hipSuccess) spacers.push_back(fill);
+            (void)hipGetLastError();
+            ++spacer_shift;
+        }
+        void *cand = nullptr;
+        if (hipMalloc(&cand, bytes) != hipSuccess) {
+            (void)hipGetLastError();
+            break;
+        }
+        bufs.push_back(cand);
+    }
+    const bool ok = order.size() == count;
+    if (!ok) {      // could not be established: still alternate between the two largest groups as far as they go
+        std::vector<char> used(bufs.size(), 0);
+        for (int j : order) used[(size_t)j] = 1;
+        for (size_t j = 0; j < bufs.size() && order.size() < count; ++j)
+            if (!used[j]) order.push_back((int)j);
+    }
+    hand_out(order);
+    if (separated) *separated = ok ? 1 : 0;
     return HGI_OK;
 }
 
