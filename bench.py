@@ -336,7 +336,17 @@ class Codec:
         # what plain allocations give about half of the time).  --placement torch: plain torch allocations.
         self.planes = None
         if args.placement == "planes":
-            self.planes = H.Planes(ctx, F * S * S, 3)
+            # best effort inside the library; if it could not establish the separation, ask again while the first set
+            # is still held (the new candidates then come from elsewhere), up to twice
+            held = []
+            for attempt in range(3):
+                self.planes = H.Planes(ctx, F * S * S, 3)
+                if self.planes.separated:
+                    break
+                if attempt < 2:
+                    held.append(self.planes)
+            for p in held:
+                p.close()
             self.imgs, self.grids, self.outs = (self.planes.torch(i, (F, S, S)) for i in range(3))
         else:
             self.imgs = torch.empty((F, S, S), dtype=torch.uint8, device=dev)

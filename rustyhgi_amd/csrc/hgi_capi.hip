@@ -783,7 +783,7 @@ constexpr size_t kProbeMinBytes = (size_t)512 << 20;   // below this the stream 
 constexpr float kFastRatio = 0.96f;   // a pair counts as "different regions" when it streams in < 0.96 of the same-region
                                       // yardstick's time (measured: 0.93-0.94 across regions, 0.97-1.0 within or between
                                       // some pairs of blocks)
-constexpr int kMaxCandidates = 8;
+constexpr int kMaxCandidates = 10;
 
 }  // namespace
 
@@ -927,9 +927,10 @@ hgi_status hgi_planes_alloc(hgi_ctx *c, size_t bytes, uint32_t count, void **pla
         if (order.size() == count) break;                                   // neighbours all in different regions
         if (bufs.size() >= (size_t)count + kMaxCandidates) break;           // give up
         size_t free_b = 0, total_b = 0;
-        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && spacer_shift <= 5 && (bytes << spacer_shift) <= free_b / 3) {
+        const size_t want = bytes << (spacer_shift < 5 ? spacer_shift : 5);      // 1, 2, 4, 8, 16, then 32 x bytes each time
+        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && want <= free_b / 3) {
             void *fill = nullptr;
-            if (hipMalloc(&fill, bytes << spacer_shift) == hipSuccess) spacers.push_back(fill);
+            if (hipMalloc(&fill, want) == hipSuccess) spacers.push_back(fill);
             (void)hipGetLastError();
             ++spacer_shift;
         }
