@@ -437,8 +437,8 @@ class Codec:
         reps = max(5, min(self.args.steps, 20))
         # alternating encode -> decode like the bench step (same-direction launches back to back run ~4 % faster)
         ev = [[self.torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(reps)]
-        for i in range(2 + reps):
-            e = ev[max(i - 2, 0)]
+        for i in range(10 + reps):
+            e = ev[max(i - 10, 0)]
             e[0].record()
             enc1.encode_batch(self.imgs, out=self.grids)
             e[1].record()
@@ -512,10 +512,10 @@ class Codec:
         a = torch.empty((F, S, S), dtype=torch.uint8, device=self.dev)
         b, c = torch.empty_like(a), torch.empty_like(a)
         a.copy_(self.imgs)
-        reps = 8
+        reps, warm = 8, 40          # 40 untimed steps first: the allocations above let the clocks fall back (see settle())
         ev = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(reps)]
-        for i in range(2 + reps):
-            e = ev[max(i - 2, 0)]
+        for i in range(warm + reps):
+            e = ev[max(i - warm, 0)]
             e[0].record()
             self.enc.encode_batch(a, out=b)
             e[1].record()
