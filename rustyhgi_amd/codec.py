@@ -43,6 +43,25 @@ def _torch_ctx(t, ctx=None):
     return ctx
 
 
+def _check_out(out, like, what):
+    """A caller-supplied output buffer goes to the C ABI as a raw pointer: it must be exactly what the call will write --
+    uint8, C-contiguous, the input's shape, on the input's device -- and must not share memory with the input."""
+    if _is_torch(like):
+        import torch
+        if not _is_torch(out) or out.dtype != torch.uint8 or not out.is_contiguous() or out.shape != like.shape \
+                or out.device != like.device:
+            raise ValueError("%s: `out` must be a contiguous uint8 tensor of shape %s on %s" % (what, tuple(like.shape), like.device))
+        a0, b0, n = like.data_ptr(), out.data_ptr(), like.numel()
+    else:
+        if not isinstance(out, np.ndarray) or out.dtype != np.uint8 or not out.flags["C_CONTIGUOUS"] \
+                or not out.flags["WRITEABLE"] or out.shape != like.shape:
+            raise ValueError("%s: `out` must be a writable C-contiguous uint8 array of shape %s" % (what, like.shape))
+        a0, b0, n = like.ctypes.data, out.ctypes.data, like.size
+    if a0 < b0 + n and b0 < a0 + n:
+        raise ValueError("%s: `out` overlaps the input" % what)
+    return out
+
+
 def _np_image(a):
     a = np.ascontiguousarray(a, dtype=np.uint8)
     if a.ndim != 2:
@@ -87,17 +106,17 @@ class Encoder:
             if imgs.ndim != 3:
                 raise ValueError("expected a (batch, height, width) stack")
             b, h, w = imgs.shape
-            if out is None:
-                out = np.empty_like(imgs)
+            out = np.empty_like(imgs) if out is None else _check_out(out, imgs, "encode_batch")
             ctx = self._ctx or _ffi.default_context(0)
             _ffi.check(_ffi.lib().hgi_encode_u8_batch(ctx.handle, imgs.ctypes.data, w, h, self.scale_level, self._interp,
                                                       self._lut.ctypes.data, out.ctypes.data, b, h * w))
             return out
         import torch
         ctx = _torch_ctx(images, self._ctx)
+        if images.dim() != 3:
+            raise ValueError("expected a (batch, height, width) stack")
         b, h, w = images.shape
-        if out is None:
-            out = torch.empty_like(images)
+        out = torch.empty_like(images) if out is None else _check_out(out, images, "encode_batch")
         _ffi.check(_ffi.lib().hgi_encode_u8_dev(ctx.handle, images.data_ptr(), w, h, self.scale_level,
                                                 self._interp, self._lut.ctypes.data,
                                                 out.data_ptr(), b, h * w))
@@ -134,17 +153,17 @@ class Decoder:
             if g.ndim != 3:
                 raise ValueError("expected a (batch, height, width) stack")
             b, h, w = g.shape
-            if out is None:
-                out = np.empty_like(g)
+            out = np.empty_like(g) if out is None else _check_out(out, g, "decode_batch")
             ctx = self._ctx or _ffi.default_context(0)
             _ffi.check(_ffi.lib().hgi_decode_u8_batch(ctx.handle, g.ctypes.data, w, h, int(levels), self._interp,
                                                       out.ctypes.data, b, h * w))
             return out
         import torch
         ctx = _torch_ctx(grids, self._ctx)
+        if grids.dim() != 3:
+            raise ValueError("expected a (batch, height, width) stack")
         b, h, w = grids.shape
-        if out is None:
-            out = torch.empty_like(grids)
+        out = torch.empty_like(grids) if out is None else _check_out(out, grids, "decode_batch")
         _ffi.check(_ffi.lib().hgi_decode_u8_dev(ctx.handle, grids.data_ptr(), w, h, int(levels),
                                                 self._interp, out.data_ptr(), b, h * w))
         return out

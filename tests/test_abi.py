@@ -112,3 +112,28 @@ def test_mirror_surface():
     assert g.get(1, 2) == 9 and g.height == 3
     g.set((1, 2), 77)
     assert g.get(1, 2) == 77 and g == H.Grid(g.buffer.copy(), 4)
+
+
+def test_caller_supplied_out_buffers_are_validated():
+    """`out=` goes to the C ABI as a raw pointer, so the Python mirror refuses anything the call would not write exactly:
+    wrong dtype, shape, layout, read-only, or memory shared with the input (checked before any device is touched)."""
+    import rustyhgi_amd as H
+    from rustyhgi_amd.interpolator import Crossed
+    from rustyhgi_amd.quantizator import NoOp
+    enc, dec = H.Encoder(Crossed(), NoOp(), 2), H.Decoder(Crossed())
+    stack = np.zeros((2, 8, 16), np.uint8)
+    big = np.zeros((2, 8, 32), np.uint8)
+    ro = np.zeros_like(stack)
+    ro.flags.writeable = False
+    bad = [np.zeros((2, 8, 16), np.uint16), np.zeros((2, 8, 15), np.uint8), np.zeros((1, 8, 16), np.uint8),
+           big[:, :, ::2], ro, stack, [[0]]]
+    for out in bad:
+        with pytest.raises(ValueError):
+            enc.encode_batch(stack, out=out)
+        with pytest.raises(ValueError):
+            dec.decode_batch(stack, 2, out=out)
+    joined = np.zeros(2 * stack.size - 5, np.uint8)        # two views of one buffer, 5 bytes shared
+    a = joined[:stack.size].reshape(stack.shape)
+    b = joined[stack.size - 5:].reshape(stack.shape)
+    with pytest.raises(ValueError, match="overlaps"):
+        enc.encode_batch(a, out=b)
