@@ -89,6 +89,70 @@ __global__ __launch_bounds__(64) void k_tiles(const uint8_t *__restrict__ src, u
     }
 }
 
+// 128 x 64 tile, rows loaded the way the codec loads them: even rows and odd rows in separate instructions, each with its
+// own cache policy; SPLIT: the even rows as left halves (bytes 0..63 of each line, the part a neighbour tile's halo loads
+// also touch) and right halves (64..127) in separate instructions with separate policies.
+template <int AUX_EVEN_L, int AUX_EVEN_R, int AUX_ODD, bool SPLIT>
+__global__ __launch_bounds__(64) void k_tiles_rows(const uint8_t *__restrict__ src, uint8_t *__restrict__ dst, Geo g)
+{
+    const uint32_t b = blockIdx.x;
+    uint32_t t = __builtin_amdgcn_readfirstlane(range_first(g.ntiles, b & 7u) + (b >> 3));
+    const uint32_t tpf = g.tiles_x * g.tiles_y, frame = t / tpf, tt = t - frame * tpf;
+    const uint32_t per = g.band * g.tiles_x, bd = tt / per, r = tt - bd * per;
+    const uint32_t tx = r / g.band, ty = bd * g.band + (r - tx * g.band);
+    const size_t fbytes = (size_t)g.W * g.H;
+    __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(src) + frame * fbytes, 0, (uint32_t)fbytes, 0x00020000);
+    __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc(dst + frame * fbytes, 0, (uint32_t)fbytes, 0x00020000);
+    const uint32_t lane = threadIdx.x, W = __builtin_amdgcn_readfirstlane(g.W);
+    const uint32_t tile = ty * 64u * g.W + tx * 128u;
+    v4u e[4], o[4];
+    uint32_t be[4];
+    if (SPLIT) {
+        // instruction j < 2: left halves of even rows 2 * (16 j + lane / 4); j >= 2: right halves
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            be[j] = tile + 2u * (16u * (j & 1) + (lane >> 2)) * g.W + (j >> 1) * 64u + (lane & 3u) * 16u;
+            e[j] = j < 2 ? __builtin_amdgcn_raw_buffer_load_b128(rs, be[j], 0, AUX_EVEN_L) : __builtin_amdgcn_raw_buffer_load_b128(rs, be[j], 0, AUX_EVEN_R);
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            be[j] = tile + 2u * (8u * j + (lane >> 3)) * g.W + (lane & 7u) * 16u;
+            e[j] = __builtin_amdgcn_raw_buffer_load_b128(rs, be[j], 0, AUX_EVEN_L);
+        }
+    }
+    const uint32_t bo = tile + (2u * (lane >> 3) + 1u) * g.W + (lane & 7u) * 16u;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) o[j] = __builtin_amdgcn_raw_buffer_load_b128(rs, bo, j * 16 * W, AUX_ODD);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) __builtin_amdgcn_raw_buffer_store_b128(e[j], rd, be[j], 0, 2);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) __builtin_amdgcn_raw_buffer_store_b128(o[j], rd, bo, j * 16 * W, 2);
+}
+
+// one 128 x 64 tile per WORKGROUP of WAVES waves: each wave moves 8 / WAVES of the tile's eight 8-row groups (fewer
+// loads in flight per wave, more and shorter-lived waves -- the direction in which a linear copy differs from a tile copy)
+template <int WAVES, int AUX_LD>
+__global__ __launch_bounds__(64 * WAVES) void k_tiles_wg(const uint8_t *__restrict__ src, uint8_t *__restrict__ dst, Geo g)
+{
+    constexpr int PER = 8 / WAVES;
+    const uint32_t b = blockIdx.x;
+    uint32_t t = __builtin_amdgcn_readfirstlane(range_first(g.ntiles, b & 7u) + (b >> 3));
+    const uint32_t tpf = g.tiles_x * g.tiles_y, frame = t / tpf, tt = t - frame * tpf;
+    const uint32_t per = g.band * g.tiles_x, bd = tt / per, r = tt - bd * per;
+    const uint32_t tx = r / g.band, ty = bd * g.band + (r - tx * g.band);
+    const size_t fbytes = (size_t)g.W * g.H;
+    __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(src) + frame * fbytes, 0, (uint32_t)fbytes, 0x00020000);
+    __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc(dst + frame * fbytes, 0, (uint32_t)fbytes, 0x00020000);
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6, W = __builtin_amdgcn_readfirstlane(g.W);
+    const uint32_t base = (ty * 64u + wave * PER * 8u + (lane >> 3)) * g.W + tx * 128u + (lane & 7u) * 16u;
+    v4u v[PER];
+#pragma unroll
+    for (int j = 0; j < PER; ++j) v[j] = __builtin_amdgcn_raw_buffer_load_b128(rs, base, j * 8 * W, AUX_LD);
+#pragma unroll
+    for (int j = 0; j < PER; ++j) __builtin_amdgcn_raw_buffer_store_b128(v[j], rd, base, j * 8 * W, 2);
+}
+
 typedef v4u copy_v4u;
 __global__ void k_linear(const copy_v4u *__restrict__ src, copy_v4u *__restrict__ dst, size_t n16)
 {
@@ -187,6 +251,37 @@ int main()
     RUN(256, 2, false, 0, 2, 8, 0);
     RUN(512, 2, false, 0, 2, 16, 0);
     RUN(1024, 2, false, 2, 2, 0, 0);
+#define RUN_ROWS(EL, ER, OD, SPLIT)                                                                                           \
+    do {                                                                                                                       \
+        Geo g = {W, H, W / 128, H / 64, 0, 8};                                                                                 \
+        g.ntiles = g.tiles_x * g.tiles_y * F;                                                                                  \
+        double t1 = T.ms([&] { hipLaunchKernelGGL((k_tiles_rows<EL, ER, OD, SPLIT>), dim3(g.ntiles), dim3(64), 0, 0, a, b, g); }); \
+        printf("tile 128 x 64 by row class, band 8: even rows %s ld %d / %d, odd rows ld %d : %7.1f GB/s (%.4f ms)\n",       \
+               (SPLIT) ? "as two half-line instructions" : "whole lines", EL, ER, OD, gbs(t1), t1);                            \
+    } while (0)
+    RUN_ROWS(0, 0, 0, false);
+    RUN_ROWS(0, 0, 2, false);      // the codec today
+    RUN_ROWS(2, 2, 2, false);
+    RUN_ROWS(0, 0, 2, true);
+    RUN_ROWS(0, 2, 2, true);       // right halves of the even rows nt as well
+    RUN_ROWS(2, 2, 2, true);
+    RUN_ROWS(0, 0, 2, false);
+    RUN_ROWS(0, 2, 2, true);
+#define RUN_WG(WV, LD)                                                                                                        \
+    do {                                                                                                                       \
+        Geo g = {W, H, W / 128, H / 64, 0, 8};                                                                                 \
+        g.ntiles = g.tiles_x * g.tiles_y * F;                                                                                  \
+        double t1 = T.ms([&] { hipLaunchKernelGGL((k_tiles_wg<WV, LD>), dim3(g.ntiles), dim3(64 * (WV)), 0, 0, a, b, g); });   \
+        printf("tile 128 x 64 per workgroup of %d waves (%d loads per lane), ld %d st 2, band 8 : %7.1f GB/s (%.4f ms)\n", WV, \
+               8 / (WV), LD, gbs(t1), t1);                                                                                     \
+    } while (0)
+    RUN_WG(1, 0);
+    RUN_WG(2, 0);
+    RUN_WG(4, 0);
+    RUN_WG(8, 0);
+    RUN_WG(1, 2);
+    RUN_WG(4, 2);
+    RUN_WG(8, 2);
     hgi_planes_free(ctx, 3, planes);
     hgi_ctx_destroy(ctx);
     return 0;
