@@ -109,6 +109,9 @@ def parse_args(argv=None):
                     help="also time the labelled variant where all frames start and end on GPU 0 (scatter, code, gather)")
     ap.add_argument("--placement", choices=("planes", "torch"), default="planes",
                     help="frame stacks from hgi_planes_alloc (neighbouring planes in different HBM regions) or from torch")
+    ap.add_argument("--share-gpu", action="store_true",
+                    help="every rank uses cuda:0 and the collectives go over gloo (RCCL refuses two ranks on one device): "
+                         "the whole N-rank path with the real codec on a ONE-GPU box; `value` then says nothing about scaling")
     ap.add_argument("--rehearse", action="store_true",
                     help="CPU rehearsal of the multi-rank plumbing (gloo, no codec work, value null)")
     return ap.parse_args(argv)
@@ -164,14 +167,17 @@ def run_rank(args):
         print("bench.py: --gpus %d but WORLD_SIZE=%d" % (args.gpus, world), file=sys.stderr)
         return 2
     rehearse = args.rehearse
+    if args.share_gpu:
+        local = 0
     dev = torch.device("cpu") if rehearse else torch.device("cuda", local)
+    cdev = torch.device("cpu") if (rehearse or args.share_gpu) else dev      # where the collectives' tensors live
     dist = None
     # HGI_BENCH_FORCE_DIST=1: take the RCCL code path (init, broadcast, barrier, all-reduce, all-gather) with one rank too
     if world > 1 or os.environ.get("HGI_BENCH_FORCE_DIST"):
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", str(free_port()))
-        if rehearse:
+        if rehearse or args.share_gpu:
             dist.init_process_group("gloo", rank=rank, world_size=world)
         else:
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
@@ -186,9 +192,9 @@ def run_rank(args):
     level = QuantizationLevel.parse(args.quant)
     if rank == 0:
         q = Linear.from_level(level)
-        lut, err, levels = batch.broadcast_params(dist, dev, q.table(), q.error(), args.levels)
+        lut, err, levels = batch.broadcast_params(dist, cdev, q.table(), q.error(), args.levels)
     else:
-        lut, err, levels = batch.broadcast_params(dist, dev)
+        lut, err, levels = batch.broadcast_params(dist, cdev)
     if dist is not None:
         print("bench.py: rank %d has the broadcast parameters (levels %d, max error %d)" % (rank, levels, err), file=sys.stderr)
 
@@ -229,7 +235,7 @@ def run_rank(args):
         if codec:
             codec.timed_step(k)
     fence()
-    elapsed = batch.max_over_ranks(dist, time.perf_counter() - t0, dev)
+    elapsed = batch.max_over_ranks(dist, time.perf_counter() - t0, cdev)
 
     if rehearse:
         # what the ranks would gather: [squared error, max error, checksum] -- here the shard itself, so that the
@@ -255,10 +261,10 @@ def run_rank(args):
     copy_ms = codec.copy_ms() if rank == 0 else None
     pfine = codec.p_fine() if rank == 0 and not (args.no_pfine or args.no_extras) else None
     placement = codec.placement(compare=not args.no_extras) if rank == 0 else None
-    xgmi = codec.xgmi(dist, world, rank, fence, args.steps) if args.xgmi_scatter else None
+    xgmi = codec.xgmi(dist, world, rank, fence, args.steps) if args.xgmi_scatter and not args.share_gpu else None
 
     # ---- per-rank checks + stats gather (RCCL all-gather) ----
-    allst = batch.gather_stats(dist, codec.stats())
+    allst = batch.gather_stats(dist, codec.stats().to(cdev))
     if dist is not None:
         print("bench.py: rank %d gathered the statistics of %d ranks" % (rank, len(allst)), file=sys.stderr)
     if not os.environ.get("HGI_BENCH_NOCHECK"):   # timing-only experiments produce wrong pixels
@@ -298,6 +304,8 @@ def run_rank(args):
         line["config"]["placement"] = placement
         line["config"]["per_step_ms"] = codec.per_step_ms()
         line["config"]["settle"] = settle
+        if args.share_gpu:
+            line["share_gpu"] = "all %d ranks time-share cuda:0, collectives over gloo: exercises the N-rank path on a one-GPU box; not a scaling number" % world
         if pfine is not None:
             line["p_fine"] = pfine
         if xgmi is not None:

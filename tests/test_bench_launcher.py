@@ -70,3 +70,25 @@ def test_launcher_parent_never_imports_the_gpu_stack():
     head = src[:src.index("def run_rank")]
     assert "import torch" not in head and "import rustyhgi_amd" not in head
     assert "os.exec" not in src
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(600)
+def test_two_ranks_with_the_real_codec_on_one_device():
+    """The whole N-rank path with the HIP codec, on a one-GPU box: `python bench.py --gpus 2 --share-gpu` -- launcher, two
+    ranks (both on cuda:0), broadcast, per-rank shards coded on the device, barrier/timing, all-gather (over gloo: RCCL
+    refuses two ranks on one device; its path is exercised by HGI_BENCH_FORCE_DIST, profiles/r02_bench_forcedist.txt)."""
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--share-gpu", "--steps", "3", "--warmup", "1", "--frames", "4",
+                        "--size", "1024", "--no-cpu", "--no-extras", "--placement", "torch"],
+                       env=_env(), capture_output=True, text=True, timeout=560)
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = _one_line(r.stdout)
+    c = d["config"]
+    assert d["n_gpus"] == 2 and c["global_frames"] == 8 and c["max_abs_err"] <= 20
+    assert len(c["grid_checksums"]) == 2 and c["grid_checksums"][0] != c["grid_checksums"][1]      # two different shards
+    # the same eight frames in one process: the per-rank checksums add up to the whole
+    one = subprocess.run([sys.executable, BENCH, "--gpus", "1", "--steps", "1", "--warmup", "0", "--frames", "8", "--size", "1024",
+                          "--no-cpu", "--no-extras", "--placement", "torch"], env=_env(), capture_output=True, text=True, timeout=560)
+    assert one.returncode == 0, one.stderr[-3000:]
+    whole = _one_line(one.stdout)["config"]
+    assert whole["sq_err_sum"] == c["sq_err_sum"]

@@ -15,7 +15,7 @@ for p in ("/sys/class/drm/card0/device/current_memory_partition", "/sys/class/dr
           "/sys/class/drm/card0/device/current_compute_partition"):
     try: print(p, open(p).read().strip())
     except Exception as e: print(p, e)
-NF = 64; W = Hh = 4096; n = NF * W * Hh
+NF = int(sys.argv[2]) if len(sys.argv) > 2 else 64; W = Hh = 4096; n = NF * W * Hh
 stream = torch.cuda.Stream(); torch.cuda.set_stream(stream)
 ctx = H.Context(0); ctx.set_stream(stream.cuda_stream)
 lut = np.zeros(256, np.uint8); err = np.zeros(1, np.uint8)
