@@ -205,6 +205,32 @@ __device__ __forceinline__ u32 quant1s(u32 a, u32 p, const u8 *slut)
     return out;
 }
 
+// N pixels that share one prediction (the new pixels of one cell; N = 6: of two cells), split-phase: all residuals,
+// then all table look-ups back to back, then the fallback tests -- ONE dependent LDS round trip instead of N.
+template <bool IDENT, int N>
+__device__ __forceinline__ void quant_batch(const u32 (&a)[N], const u32 (&p)[N], u32 (&out)[N])
+{
+    if (IDENT) {
+#pragma unroll
+        for (int i = 0; i < N; ++i) out[i] = (a[i] - p[i]) & 255u;
+        return;
+    }
+    u32 d[N], q[N];
+#pragma unroll
+    for (int i = 0; i < N; ++i) Q_SUB(d[i], a[i], 0, p[i], 0);
+#pragma unroll
+    for (int i = 0; i < N; ++i) q[i] = lut_at(d[i]);
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        const u32 np = ~p[i];
+        lanemask b, c;
+        Q_LT(b, a[i], 0, p[i], 0);
+        Q_GT(c, q[i], np, 0);
+        asm("s_xor_b64 vcc, %1, %2\n\tv_cndmask_b32_e32 %0, %3, %4, vcc"
+            : "=v"(out[i]) : "s"(b), "s"(c), "v"(q[i]), "v"(d[i]) : "vcc", "scc");
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // tile bookkeeping
 // ---------------------------------------------------------------------------------------------
@@ -639,7 +665,10 @@ template <int INTERP, bool IDENT>
 __device__ __forceinline__ void cell_finish(u8 *buf, u8 *rbuf, const u8 *slut, const CellAddr &a, const CellVal &v)
 {
     const u32 p = pred1<INTERP>(v.lt, v.rt, v.lb, v.rb);
-    const u32 qx = quant1s<IDENT>(v.ax, p, slut), qy = quant1s<IDENT>(v.ay, p, slut), qxy = quant1s<IDENT>(v.axy, p, slut);
+    const u32 orig[3] = {v.ax, v.ay, v.axy}, pp[3] = {p, p, p};
+    u32 res[3];
+    quant_batch<IDENT, 3>(orig, pp, res);
+    const u32 qx = res[0], qy = res[1], qxy = res[2];
     if (a.xw) {
         buf[a.nx] = (u8)qx;
         rbuf[a.rx] = (u8)(p + qx);
