@@ -5,6 +5,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <cstring>
 #include <vector>
 
 #include "../../include/hgi.h"
@@ -743,6 +744,104 @@ hgi_status hgi_diff_stats_dev(hgi_ctx *c, const void *d_before, const void *d_af
     Frames f = {w, h, (uint64_t)frame_stride, (uint32_t)batch};
     HIP_TRY(launch_diff_stats(static_cast<const uint8_t *>(d_before), static_cast<const uint8_t *>(d_after), f,
                               static_cast<unsigned long long *>(d_out), c->stream));
+    return HGI_OK;
+}
+
+// ---- entropy stage --------------------------------------------------------------------------------------------
+hgi_status hgi_huffman_plan(const uint64_t hist[257], uint8_t lens[257], uint16_t codes[257], uint8_t *header, size_t header_cap,
+                            size_t *header_bits)
+{
+    if (!hist || !lens || !codes || !header || !header_bits) return fail(HGI_EINVAL, "NULL argument");
+    uint64_t any = 0;
+    for (int i = 0; i < 257; ++i) any |= hist[i];
+    if (!any) return fail(HGI_EINVAL, "empty histogram");
+    *header_bits = huffman_plan(hist, lens, codes, header, header_cap);
+    if (!*header_bits) return fail(HGI_EINVAL, "header buffer too small (%zu bytes)", header_cap);
+    return HGI_OK;
+}
+
+hgi_status hgi_deflate_grid_dev(hgi_ctx *c, const void *d_grid, uint32_t w, uint32_t h, uint8_t *out, size_t cap, size_t *bytes)
+{
+    if (!c || !out || !bytes) return fail(HGI_EINVAL, "NULL argument");
+    const uint64_t n = (uint64_t)w * h;
+    if (n && !d_grid) return fail(HGI_EINVAL, "NULL buffer");
+    HIP_TRY(hipSetDevice(c->device));
+    // the bincode image of Grid { buffer: Vec<u8>, width: usize } (src/grid.rs:2-5): u64 length, the bytes, u64 width
+    uint8_t prefix[8], suffix[8];
+    for (int i = 0; i < 8; ++i) {
+        prefix[i] = (uint8_t)(n >> (8 * i));
+        suffix[i] = (uint8_t)((uint64_t)w >> (8 * i));
+    }
+    const uint32_t nchunks = huffman_chunks(n);
+    const size_t dev_cap = align_up((size_t)(n + n / 4) + 4096, 256);      // an optimal code averages < 9 bits per byte
+    const size_t need = 257 * 8 + 256 * 4 + (size_t)nchunks * 12 + 8 + dev_cap + 8 * 256;
+    HGI_TRY(ws_ensure(c, need));
+    c->ws_used = 0;
+    unsigned long long *d_hist = reinterpret_cast<unsigned long long *>(ws_take(c, 257 * 8));
+    uint32_t *d_table = reinterpret_cast<uint32_t *>(ws_take(c, 256 * 4));
+    uint64_t *d_off = reinterpret_cast<uint64_t *>(ws_take(c, (size_t)nchunks * 8 + 8));
+    uint32_t *d_cbits = reinterpret_cast<uint32_t *>(ws_take(c, (size_t)nchunks * 4 + 8));
+    uint64_t *d_total = reinterpret_cast<uint64_t *>(ws_take(c, 8));
+    uint32_t *d_out = reinterpret_cast<uint32_t *>(ws_take(c, dev_cap));
+    if (!d_hist || !d_table || !d_off || !d_cbits || !d_total || !d_out) return fail(HGI_ENOMEM, "scratch exhausted (entropy stage)");
+    uint64_t hist[257] = {0};
+    if (n) {
+        const Frames f = {w, h, n, 1};
+        HIP_TRY(launch_histogram(static_cast<const uint8_t *>(d_grid), f, d_hist, c->stream));
+        HIP_TRY(hipMemcpyAsync(hist, d_hist, 256 * 8, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+    }
+    for (int i = 0; i < 8; ++i) {
+        ++hist[prefix[i]];
+        ++hist[suffix[i]];
+    }
+    hist[256] = 1;      // end of block
+    uint8_t lens[257], head[512];
+    uint16_t codes[257];
+    size_t bits = huffman_plan(hist, lens, codes, head, sizeof(head) - 64);
+    if (!bits) return fail(HGI_EDEVICE, "block header does not fit");
+    auto put = [&](std::vector<uint8_t> &v, size_t &at, uint32_t value, int nb) {
+        for (int i = 0; i < nb; ++i, ++at) {
+            if ((at >> 3) >= v.size()) v.push_back(0);
+            v[at >> 3] |= (uint8_t)(((value >> i) & 1u) << (at & 7));
+        }
+    };
+    std::vector<uint8_t> front(head, head + (bits + 7) / 8);
+    for (int i = 0; i < 8; ++i) put(front, bits, codes[prefix[i]], lens[prefix[i]]);
+    const uint64_t base_bits = bits;
+    uint64_t grid_bits = 0;
+    if (n) {
+        uint32_t table[256];
+        for (int v = 0; v < 256; ++v) table[v] = (uint32_t)codes[v] | ((uint32_t)lens[v] << 16);
+        HIP_TRY(hipMemsetAsync(d_out, 0, dev_cap, c->stream));
+        HIP_TRY(hipMemcpyAsync(d_out, front.data(), front.size(), hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(hipMemcpyAsync(d_table, table, sizeof(table), hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(launch_huffman_pack(static_cast<const uint8_t *>(d_grid), n, d_table, d_cbits, d_off, d_total, base_bits, d_out,
+                                    c->stream));
+        HIP_TRY(hipMemcpyAsync(&grid_bits, d_total, 8, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));       // (front / table are read by the copies above: they end here)
+    }
+    uint64_t end_bits = base_bits + grid_bits;
+    size_t tail_bits = 0;
+    for (int i = 0; i < 8; ++i) tail_bits += lens[suffix[i]];
+    tail_bits += lens[256];
+    const size_t total_bytes = (size_t)((end_bits + tail_bits + 7) / 8);
+    c->ws_used = 0;
+    if ((end_bits + 7) / 8 + 8 > dev_cap) return fail(HGI_EDEVICE, "entropy stage overran its buffer");
+    if (total_bytes > cap) return fail(HGI_EINVAL, "output buffer too small: %zu bytes needed", total_bytes);
+    std::memset(out, 0, total_bytes);
+    if (n) {
+        HIP_TRY(hipMemcpyAsync(out, d_out, (size_t)((end_bits + 7) / 8), hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+    } else {
+        std::memcpy(out, front.data(), front.size());
+    }
+    auto put_out = [&](uint32_t value, int nb) {
+        for (int i = 0; i < nb; ++i, ++end_bits) out[end_bits >> 3] |= (uint8_t)(((value >> i) & 1u) << (end_bits & 7));
+    };
+    for (int i = 0; i < 8; ++i) put_out(codes[suffix[i]], lens[suffix[i]]);
+    put_out(codes[256], lens[256]);
+    *bytes = total_bytes;
     return HGI_OK;
 }
 

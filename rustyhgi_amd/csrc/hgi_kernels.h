@@ -80,4 +80,13 @@ hipError_t launch_histogram(const uint8_t *src, const Frames &f, unsigned long l
 hipError_t launch_diff_stats(const uint8_t *a, const uint8_t *b, const Frames &f,
                              unsigned long long *out, hipStream_t s);
 
+// ---- entropy stage (hgi_entropy.hip): raw DEFLATE of a grid as one dynamic-Huffman block of literals -----------
+// host: code for the 257 literal / end-of-block symbols + the block header; returns the header's bits (0: no room)
+size_t huffman_plan(const uint64_t hist[257], uint8_t lens[257], uint16_t codes[257], uint8_t *header, size_t header_cap);
+// device: the codes of src[0..n) OR-ed into the zeroed stream d_out from bit `base_bits` on (table[v] = reversed
+// code | length << 16); *d_total = their bits.  Scratch: huffman_chunks(n) u32 + as many u64.
+uint32_t huffman_chunks(uint64_t n);
+hipError_t launch_huffman_pack(const uint8_t *src, uint64_t n, const uint32_t *d_table, uint32_t *d_chunk_bits, uint64_t *d_chunk_off,
+                               uint64_t *d_total, uint64_t base_bits, uint32_t *d_out, hipStream_t s);
+
 }  // namespace hgi

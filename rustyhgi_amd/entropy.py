@@ -41,3 +41,20 @@ def estimated_bytes(hist):
     if h.ndim == 1:
         h = h[None]
     return np.ceil(h.sum(axis=1) * entropy_bits_per_pixel(h) / 8.0).astype(np.int64)
+
+
+def deflate_grid(grid, context=None):
+    """(H, W) uint8 CUDA tensor -> bytes: raw DEFLATE (one dynamic-Huffman block of literals) of the grid's bincode image
+    (u64 H*W, the bytes, u64 W) -- what follows the metadata in a .hgi archive -- entropy-coded on the device
+    (hgi_deflate_grid_dev, include/hgi.h).  Synchronous."""
+    import ctypes
+    import torch
+    if grid.dim() != 2 or grid.dtype != torch.uint8 or not grid.is_cuda or not grid.is_contiguous():
+        raise TypeError("deflate_grid() takes a contiguous uint8 CUDA tensor of shape (H, W)")
+    ctx = _torch_ctx(grid, context)
+    h, w = grid.shape
+    cap = h * w + h * w // 8 + 1024
+    out = np.empty(cap, np.uint8)
+    n = ctypes.c_size_t(0)
+    _ffi.check(_ffi.lib().hgi_deflate_grid_dev(ctx.handle, grid.data_ptr(), w, h, out.ctypes.data, cap, ctypes.byref(n)))
+    return out[:n.value].tobytes()
