@@ -4,6 +4,8 @@
 //   hgi encode -i <input> -o <output> [-l <level>=4] [-q lossless|low|medium|high = medium]
 //   hgi decode -i <input.hgi> -o <output>
 //   hgi test <input> [-s <suffix>=""] [-l <level>=4] [-q <quantizator>=medium]
+//   (encode / test also take --entropy zlib|device, default zlib: `device` has the GPU write the archive's DEFLATE stream
+//    as Huffman-coded literals -- same container, readable by the same readers; no counterpart in the reference)
 //
 // `hgi test` prints the reference's four report lines (src/main.rs:108-111, integer MSE division at
 // :106) and writes "<stem><suffix>.pgm" and "<stem><suffix>.hgi" into the working directory.
@@ -155,7 +157,13 @@ struct Opts {
     std::string cmd, input, output, suffix;
     size_t level = 4;                                            // src/options.rs:54
     QuantizationLevel quant = QuantizationLevel::Medium;         // src/options.rs:62
+    bool device_entropy = false;   // --entropy device: the DEFLATE stream from the GPU's entropy stage (no reference flag)
 };
+
+std::vector<uint8_t> write_archive(const Opts &o, const Metadata &metadata, const Grid &grid)
+{
+    return o.device_entropy ? hgi::serialize_device(metadata, grid, hgi::Context::global().get()) : serialize(metadata, grid);
+}
 
 Opts parse(int argc, char **argv)
 {
@@ -173,6 +181,11 @@ Opts parse(int argc, char **argv)
         else if (a == "-l" || a == "--level") o.level = std::stoul(next());
         else if (a == "-q" || a == "--quantizator") o.quant = parse_level(next());
         else if (a == "-s" || a == "--suffix") o.suffix = next();
+        else if (a == "--entropy") {
+            const std::string v = next();
+            if (v != "device" && v != "zlib") throw Failure("'" + v + "' isn't a valid value for '--entropy' [values: zlib, device]");
+            o.device_entropy = v == "device";
+        }
         else if (o.cmd == "test" && o.input.empty() && a[0] != '-') o.input = a;   // positional <input>
         else throw Failure("unexpected argument '" + a + "'");
     }
@@ -197,7 +210,7 @@ void encode(const Opts &o)   // src/main.rs:41-61
     const uint32_t width = image.width, height = image.height;
     Grid grid = encoder.encode(std::move(image));
     Metadata metadata{o.quant, InterpolationType::Crossed, width, height, o.level};
-    write_file(o.output, serialize(metadata, grid));
+    write_file(o.output, write_archive(o, metadata, grid));
 }
 
 void decode(const Opts &o)   // src/main.rs:63-71 (always Crossed; metadata.interpolation is ignored there too)
@@ -226,7 +239,7 @@ void test(const Opts &o)   // src/main.rs:73-120
         sd += diff * diff;
     }
     Metadata metadata{o.quant, InterpolationType::Crossed, image_before.width, image_before.height, o.level};
-    std::vector<uint8_t> buffer = serialize(metadata, grid);
+    std::vector<uint8_t> buffer = write_archive(o, metadata, grid);
 
     const uint32_t uncompressed = image_before.height * image_before.width;
     sd /= uncompressed;   // :106 integer division

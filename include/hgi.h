@@ -155,6 +155,9 @@ hgi_status hgi_diff_stats_dev(hgi_ctx *ctx, const void *d_before, const void *d_
 /* (w*h + w*h/8 + 600 always suffices).  Synchronous on the ctx stream.                         */
 hgi_status hgi_deflate_grid_dev(hgi_ctx *ctx, const void *d_grid, uint32_t width, uint32_t height,
                                 uint8_t *out, size_t cap, size_t *bytes);
+/* The same with the grid in host memory (what pairs with hgi_encode_u8).                      */
+hgi_status hgi_deflate_grid(hgi_ctx *ctx, const uint8_t *grid, uint32_t width, uint32_t height,
+                            uint8_t *out, size_t cap, size_t *bytes);
 /* The code construction alone (host only): lengths (<= 15) and bit-reversed canonical codes    */
 /* of the 256 literals + end-of-block (hist[256]) for the given counts, and the block header   */
 /* (BFINAL = 1, dynamic, 257 + 2 codes) that announces them; *header_bits = its length.        */

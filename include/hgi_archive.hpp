@@ -15,6 +15,7 @@
 
 #include <cstdint>
 #include <stdexcept>
+#include <string>
 #include <vector>
 
 #include "hgi.hpp"
@@ -84,6 +85,47 @@ inline void serialize_into(std::vector<uint8_t> &out, const Metadata &m, const G
     deflateEnd(&z);
     if (rc != Z_STREAM_END) throw ArchiveError("deflate failed");
     out.resize(head + z.total_out);
+}
+
+// The same container with the entropy stage on the device (hgi_deflate_grid_dev, include/hgi.h): the grid stays where
+// the encoder left it (d_grid, m.width x m.height bytes of device memory), the DEFLATE stream is one dynamic-Huffman block
+// of literals written by the GPU.  Readable by deserialize() below and by the reference's reader alike.
+inline void serialize_device_into(std::vector<uint8_t> &out, const Metadata &m, hgi_ctx *ctx, const void *d_grid)
+{
+    using archive_detail::put_le;
+    put_le(out, kArchiveMagic, 4);
+    put_le(out, (uint32_t)m.quantization_level, 4);
+    put_le(out, (uint32_t)m.interpolation, 4);
+    put_le(out, m.width, 4);
+    put_le(out, m.height, 4);
+    put_le(out, m.scale_level, 8);
+    const size_t n = size_t(m.width) * m.height, head = out.size(), cap = n + n / 8 + 1024;
+    out.resize(head + cap);
+    size_t bytes = 0;
+    if (hgi_deflate_grid_dev(ctx, d_grid, m.width, m.height, out.data() + head, cap, &bytes) != HGI_OK)
+        throw ArchiveError(std::string("device entropy stage: ") + hgi_last_error());
+    out.resize(head + bytes);
+}
+
+// ... and with the grid in host memory (hgi_deflate_grid): what the CLI's `--entropy device` writes
+inline std::vector<uint8_t> serialize_device(const Metadata &m, const Grid &grid, hgi_ctx *ctx)
+{
+    using archive_detail::put_le;
+    std::vector<uint8_t> out;
+    put_le(out, kArchiveMagic, 4);
+    put_le(out, (uint32_t)m.quantization_level, 4);
+    put_le(out, (uint32_t)m.interpolation, 4);
+    put_le(out, m.width, 4);
+    put_le(out, m.height, 4);
+    put_le(out, m.scale_level, 8);
+    const size_t n = grid.buffer.size(), head = out.size(), cap = n + n / 8 + 1024;
+    const uint32_t height = grid.width ? (uint32_t)(n / grid.width) : 0;
+    out.resize(head + cap);
+    size_t bytes = 0;
+    if (hgi_deflate_grid(ctx, grid.buffer.data(), (uint32_t)grid.width, height, out.data() + head, cap, &bytes) != HGI_OK)
+        throw ArchiveError(std::string("device entropy stage: ") + hgi_last_error());
+    out.resize(head + bytes);
+    return out;
 }
 
 inline std::vector<uint8_t> serialize(const Metadata &m, const Grid &grid)

@@ -760,6 +760,25 @@ hgi_status hgi_huffman_plan(const uint64_t hist[257], uint8_t lens[257], uint16_
     return HGI_OK;
 }
 
+static size_t deflate_scratch_bytes(uint64_t n)
+{
+    return 257 * 8 + 256 * 4 + (size_t)huffman_chunks(n) * 12 + 8 + align_up((size_t)(n + n / 4) + 4096, 256) + 8 * 256;
+}
+
+// host-pointer form (what pairs with hgi_encode_u8): the grid goes up into scratch behind the stage's own buffers
+hgi_status hgi_deflate_grid(hgi_ctx *c, const uint8_t *grid, uint32_t w, uint32_t h, uint8_t *out, size_t cap, size_t *bytes)
+{
+    if (!c || !out || !bytes) return fail(HGI_EINVAL, "NULL argument");
+    const size_t n = (size_t)w * h;
+    if (n && !grid) return fail(HGI_EINVAL, "NULL buffer");
+    HIP_TRY(hipSetDevice(c->device));
+    const size_t front = align_up(deflate_scratch_bytes(n), 256);
+    HGI_TRY(ws_ensure(c, front + n + 256));
+    uint8_t *staged = c->ws + front;
+    if (n) HIP_TRY(hipMemcpyAsync(staged, grid, n, hipMemcpyHostToDevice, c->stream));
+    return hgi_deflate_grid_dev(c, staged, w, h, out, cap, bytes);
+}
+
 hgi_status hgi_deflate_grid_dev(hgi_ctx *c, const void *d_grid, uint32_t w, uint32_t h, uint8_t *out, size_t cap, size_t *bytes)
 {
     if (!c || !out || !bytes) return fail(HGI_EINVAL, "NULL argument");
@@ -774,7 +793,7 @@ hgi_status hgi_deflate_grid_dev(hgi_ctx *c, const void *d_grid, uint32_t w, uint
     }
     const uint32_t nchunks = huffman_chunks(n);
     const size_t dev_cap = align_up((size_t)(n + n / 4) + 4096, 256);      // an optimal code averages < 9 bits per byte
-    const size_t need = 257 * 8 + 256 * 4 + (size_t)nchunks * 12 + 8 + dev_cap + 8 * 256;
+    const size_t need = deflate_scratch_bytes(n);
     HGI_TRY(ws_ensure(c, need));
     c->ws_used = 0;
     unsigned long long *d_hist = reinterpret_cast<unsigned long long *>(ws_take(c, 257 * 8));

@@ -384,6 +384,12 @@ def test_cli_hgi_test_report_and_archive_interop(H, oracle, lena, tmp_path):
         arc = Archive.deserialize_from_reader(f)
     dec_m = oracle.decode(want, 4)
     assert arc.metadata == Metadata(1, 0, 256, 256, 3) and (arc.grid.as_image() == oracle.encode(dec_m, 3, oracle.linear_lut(1)[0])).all()
+    # the same report with the archive's DEFLATE stream written by the device's entropy stage: smaller on this image
+    dev = subprocess.run([exe, "test", "LENA.TIF", "-s", "_d", "--entropy", "device"], cwd=str(tmp_path), capture_output=True, text=True, timeout=120)
+    assert dev.returncode == 0, dev.stderr
+    assert "Compressed:   14 kb" in dev.stdout and "SD:           9.17" in dev.stdout, dev.stdout
+    with open(str(tmp_path / "LENA_d.hgi"), "rb") as f:
+        assert H.Archive.deserialize_from_reader(f) == H.Archive.deserialize_from_reader(open(str(tmp_path / "LENA_m.hgi"), "rb"))
     bad = subprocess.run([exe, "encode", "-i", "LENA.TIF", "-o", "x.hgi", "-q", "loseless"], cwd=str(tmp_path),
                          capture_output=True, text=True)
     assert bad.returncode != 0 and "An error occured" in bad.stderr          # not typo tolerant
