@@ -144,24 +144,27 @@ hgi_status hgi_diff_stats_dev(hgi_ctx *ctx, const void *d_before, const void *d_
                               uint32_t width, uint32_t height, size_t batch, size_t frame_stride,
                               void *d_out);
 /* ---- entropy stage on the device (the step behind src/archive.rs:34-40) ------------------- */
-/* Raw DEFLATE (RFC 1951: one dynamic-Huffman block of literals, no matches) of the bincode    */
-/* image of a Grid -- u64 w*h, the w*h residual bytes at d_grid, u64 w -- i.e. exactly the     */
-/* bytes that follow the metadata in a .hgi archive.  Histogram, bit counting, scan and bit    */
-/* packing run on the device; the 257-symbol code and the block header are built on the host.  */
-/* Any inflate reads the result (the reference's flate2 DeflateDecoder included).  Residual    */
-/* grids are noise around zero, which LZ77 cannot shorten: on LENA / Medium this stream is     */
-/* 14.5 kB where DEFLATE at the best level makes 16.0 kB -- and it is written 100x faster.     */
+/* Raw DEFLATE (RFC 1951: one dynamic-Huffman block of literals and run matches -- a byte that */
+/* repeats its predecessor is covered by matches of distance 1) of the bincode image of a Grid */
+/* -- u64 w*h, the w*h residual bytes at d_grid, u64 w -- i.e. exactly the bytes that follow   */
+/* the metadata in a .hgi archive.  Tokens, histogram, bit counting, scan and bit packing run  */
+/* on the device; the 286-symbol code and the block header are built on the host.  Any inflate */
+/* reads the result (the reference's flate2 DeflateDecoder included).  Residual grids are      */
+/* noise around zero, in which LZ77 finds runs and nothing else: the stream is within a few %  */
+/* of DEFLATE at the best level on smooth images and smaller than it on busy ones (LENA /      */
+/* Medium: 14.5 against 16.0 kB) -- and written two to four orders of magnitude sooner.        */
 /* `out` is host memory; *bytes receives the stream length; HGI_EINVAL if cap is too small     */
-/* (w*h + w*h/8 + 600 always suffices).  Synchronous on the ctx stream.                         */
+/* (w*h + w*h/8 + 1024 always suffices).  Synchronous on the ctx stream.                        */
 hgi_status hgi_deflate_grid_dev(hgi_ctx *ctx, const void *d_grid, uint32_t width, uint32_t height,
                                 uint8_t *out, size_t cap, size_t *bytes);
 /* The same with the grid in host memory (what pairs with hgi_encode_u8).                      */
 hgi_status hgi_deflate_grid(hgi_ctx *ctx, const uint8_t *grid, uint32_t width, uint32_t height,
                             uint8_t *out, size_t cap, size_t *bytes);
 /* The code construction alone (host only): lengths (<= 15) and bit-reversed canonical codes    */
-/* of the 256 literals + end-of-block (hist[256]) for the given counts, and the block header   */
-/* (BFINAL = 1, dynamic, 257 + 2 codes) that announces them; *header_bits = its length.        */
-hgi_status hgi_huffman_plan(const uint64_t hist[257], uint8_t lens[257], uint16_t codes[257],
+/* of the 286 symbols -- literals 0..255, end of block 256 (hist[256]), match lengths 257..285 */
+/* -- for the given counts, and the block header (BFINAL = 1, dynamic, 286 + 2 codes; distance */
+/* code 0 = distance 1 is the one-bit code "0") that announces them; *header_bits = its length.*/
+hgi_status hgi_huffman_plan(const uint64_t hist[286], uint8_t lens[286], uint16_t codes[286],
                             uint8_t *header, size_t header_cap, size_t *header_bits);
 
 /* ---- plane placement (no reference counterpart: the reference's buffers are Vec<u8>) ---- */

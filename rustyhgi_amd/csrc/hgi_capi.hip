@@ -748,12 +748,12 @@ hgi_status hgi_diff_stats_dev(hgi_ctx *c, const void *d_before, const void *d_af
 }
 
 // ---- entropy stage --------------------------------------------------------------------------------------------
-hgi_status hgi_huffman_plan(const uint64_t hist[257], uint8_t lens[257], uint16_t codes[257], uint8_t *header, size_t header_cap,
+hgi_status hgi_huffman_plan(const uint64_t hist[286], uint8_t lens[286], uint16_t codes[286], uint8_t *header, size_t header_cap,
                             size_t *header_bits)
 {
     if (!hist || !lens || !codes || !header || !header_bits) return fail(HGI_EINVAL, "NULL argument");
     uint64_t any = 0;
-    for (int i = 0; i < 257; ++i) any |= hist[i];
+    for (int i = 0; i < kDeflateSymbols; ++i) any |= hist[i];
     if (!any) return fail(HGI_EINVAL, "empty histogram");
     *header_bits = huffman_plan(hist, lens, codes, header, header_cap);
     if (!*header_bits) return fail(HGI_EINVAL, "header buffer too small (%zu bytes)", header_cap);
@@ -762,7 +762,7 @@ hgi_status hgi_huffman_plan(const uint64_t hist[257], uint8_t lens[257], uint16_
 
 static size_t deflate_scratch_bytes(uint64_t n)
 {
-    return 257 * 8 + 256 * 4 + (size_t)huffman_chunks(n) * 12 + 8 + align_up((size_t)(n + n / 4) + 4096, 256) + 8 * 256;
+    return kDeflateSymbols * 12 + (size_t)huffman_chunks(n) * 12 + 8 + align_up((size_t)(n + n / 4) + 4096, 256) + 10 * 256;
 }
 
 // host-pointer form (what pairs with hgi_encode_u8): the grid goes up into scratch behind the stage's own buffers
@@ -796,18 +796,17 @@ hgi_status hgi_deflate_grid_dev(hgi_ctx *c, const void *d_grid, uint32_t w, uint
     const size_t need = deflate_scratch_bytes(n);
     HGI_TRY(ws_ensure(c, need));
     c->ws_used = 0;
-    unsigned long long *d_hist = reinterpret_cast<unsigned long long *>(ws_take(c, 257 * 8));
-    uint32_t *d_table = reinterpret_cast<uint32_t *>(ws_take(c, 256 * 4));
+    unsigned long long *d_hist = reinterpret_cast<unsigned long long *>(ws_take(c, kDeflateSymbols * 8));
+    uint32_t *d_table = reinterpret_cast<uint32_t *>(ws_take(c, kDeflateSymbols * 4));
     uint64_t *d_off = reinterpret_cast<uint64_t *>(ws_take(c, (size_t)nchunks * 8 + 8));
     uint32_t *d_cbits = reinterpret_cast<uint32_t *>(ws_take(c, (size_t)nchunks * 4 + 8));
     uint64_t *d_total = reinterpret_cast<uint64_t *>(ws_take(c, 8));
     uint32_t *d_out = reinterpret_cast<uint32_t *>(ws_take(c, dev_cap));
     if (!d_hist || !d_table || !d_off || !d_cbits || !d_total || !d_out) return fail(HGI_ENOMEM, "scratch exhausted (entropy stage)");
-    uint64_t hist[257] = {0};
+    uint64_t hist[kDeflateSymbols] = {0};
     if (n) {
-        const Frames f = {w, h, n, 1};
-        HIP_TRY(launch_histogram(static_cast<const uint8_t *>(d_grid), f, d_hist, c->stream));
-        HIP_TRY(hipMemcpyAsync(hist, d_hist, 256 * 8, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(launch_token_histogram(static_cast<const uint8_t *>(d_grid), n, d_hist, c->stream));
+        HIP_TRY(hipMemcpyAsync(hist, d_hist, kDeflateSymbols * 8, hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(hipStreamSynchronize(c->stream));
     }
     for (int i = 0; i < 8; ++i) {
@@ -815,8 +814,8 @@ hgi_status hgi_deflate_grid_dev(hgi_ctx *c, const void *d_grid, uint32_t w, uint
         ++hist[suffix[i]];
     }
     hist[256] = 1;      // end of block
-    uint8_t lens[257], head[512];
-    uint16_t codes[257];
+    uint8_t lens[kDeflateSymbols], head[640];
+    uint16_t codes[kDeflateSymbols];
     size_t bits = huffman_plan(hist, lens, codes, head, sizeof(head) - 64);
     if (!bits) return fail(HGI_EDEVICE, "block header does not fit");
     auto put = [&](std::vector<uint8_t> &v, size_t &at, uint32_t value, int nb) {
@@ -830,13 +829,14 @@ hgi_status hgi_deflate_grid_dev(hgi_ctx *c, const void *d_grid, uint32_t w, uint
     const uint64_t base_bits = bits;
     uint64_t grid_bits = 0;
     if (n) {
-        uint32_t table[256];
-        for (int v = 0; v < 256; ++v) table[v] = (uint32_t)codes[v] | ((uint32_t)lens[v] << 16);
+        uint32_t table[kDeflateSymbols];
+        for (int v = 0; v < kDeflateSymbols; ++v) table[v] = (uint32_t)codes[v] | ((uint32_t)lens[v] << 16);
+        const uint32_t dist_code = 0u | (1u << 16);      // distance symbol 0 (= distance 1): the one-bit code "0"
         HIP_TRY(hipMemsetAsync(d_out, 0, dev_cap, c->stream));
         HIP_TRY(hipMemcpyAsync(d_out, front.data(), front.size(), hipMemcpyHostToDevice, c->stream));
         HIP_TRY(hipMemcpyAsync(d_table, table, sizeof(table), hipMemcpyHostToDevice, c->stream));
-        HIP_TRY(launch_huffman_pack(static_cast<const uint8_t *>(d_grid), n, d_table, d_cbits, d_off, d_total, base_bits, d_out,
-                                    c->stream));
+        HIP_TRY(launch_huffman_pack(static_cast<const uint8_t *>(d_grid), n, d_table, dist_code, d_cbits, d_off, d_total, base_bits,
+                                    d_out, c->stream));
         HIP_TRY(hipMemcpyAsync(&grid_bits, d_total, 8, hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(hipStreamSynchronize(c->stream));       // (front / table are read by the copies above: they end here)
     }

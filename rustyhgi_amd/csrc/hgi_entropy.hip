@@ -1,15 +1,20 @@
-// Entropy stage on the device: raw DEFLATE (RFC 1951) of a residual grid as ONE dynamic-Huffman block of literals.
+// Entropy stage on the device: raw DEFLATE (RFC 1951) of a residual grid as ONE dynamic-Huffman block of literals and
+// run matches.
 //
 // The reference serialises a grid by handing its bincode image to flate2's DEFLATE at the best level
-// (src/archive.rs:34-40), on the CPU, one thread: 8.5 ms for a 1920 x 1080 grid against 7 us for the encode that made it
-// (profiles/r02_bench_cpp.txt).  Residual grids are noise around zero: LZ77 matches find almost nothing in them (zlib
-// level 9 on LENA / Medium: 16 036 B; Huffman only: 14 496 B -- SMALLER), so the stage that matters is the Huffman code,
-// and that parallelises: histogram (hgi_kernels.hip) -> code lengths and block header on the host (a few
-// hundred symbols) -> code lengths summed per chunk, scanned, and every chunk's codes OR-ed into place by the device.
+// (src/archive.rs:34-40), on the CPU, one thread: 8 ms for a 1920 x 1080 grid against 7 us for the encode that made it
+// (profiles/r02_bench_cpp.txt), seconds for a 4096 x 4096 one.  Residual grids are noise around zero: what LZ77 finds in
+// them is runs (of zeros, in smooth regions) and nothing else -- zlib's run-length-only strategy (Z_RLE) is within 1 % of
+// its level 9 on them, and where there are no runs the plain Huffman code alone is SMALLER than level 9 (LENA / Medium:
+// 14.5 against 16.0 kB).  Both parallelise:
+//   tokens     a byte equal to its predecessor continues a run; a run's bytes after its first are covered by matches of
+//              distance 1 and length 3..258 (leftovers of 1-2 bytes stay literals).  Runs are cut at 1 KiB chunk
+//              boundaries, so every token is decided inside one workgroup (cost: one extra literal per KiB of run).
+//   histogram  of the 286 literal / length symbols the tokens use                              (device, pass 1)
+//   code       length-limited canonical Huffman code + the RFC 1951 block header               (host, a few hundred symbols)
+//   bits       per chunk (pass 2), exclusive scan over the chunks, and every token OR-ed into place (pass 3)
 // The stream is ordinary DEFLATE: flate2 / zlib / miniz inflate it; `Archive::deserialize_from_reader`
 // (src/archive.rs:43-55) reads archives written this way unchanged.
-//
-// This file: the host-side planner (length-limited canonical Huffman code, RFC 1951 block header) and the three kernels.
 #include <algorithm>
 #include <cstring>
 #include <vector>
@@ -118,26 +123,41 @@ struct BitWriter {
 
 }  // namespace
 
-// Code for the 257 literal / end-of-block symbols from their frequencies (hist[256] = end of block, normally 1) and the
-// header of the one block that carries them: BFINAL = 1, BTYPE = dynamic, 257 literal/length codes, two distance codes
-// of one bit each (never used; a complete distance code is what every inflate accepts), the code lengths themselves
-// Huffman-coded with zero runs folded (RFC 1951 3.2.7).  Returns the header's length in bits, 0 if it does not fit.
-size_t huffman_plan(const uint64_t hist[257], uint8_t lens[257], uint16_t codes[257], uint8_t *header, size_t header_cap)
+// RFC 1951 3.2.5: match length 3..258 -> length symbol 257..285, number of extra bits, value of the extra bits
+void deflate_length_symbol(uint32_t length, uint32_t *symbol, uint32_t *extra_bits, uint32_t *extra)
 {
-    code_lengths(hist, 257, 15, lens);
-    canonical_codes(lens, 257, 15, codes);
-    // the 259 code lengths to transmit, zero runs as symbols 17 (3..10) / 18 (11..138)
-    u8 seq[259];
-    std::memcpy(seq, lens, 257);
-    seq[257] = seq[258] = 1;
+    static const uint16_t base[29] = {3, 4, 5, 6, 7, 8, 9, 10, 11, 13, 15, 17, 19, 23, 27, 31, 35, 43, 51, 59, 67, 83, 99, 115, 131, 163, 195, 227, 258};
+    static const u8 bits[29] = {0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4, 4, 5, 5, 5, 5, 0};
+    int s = 28;
+    while (s > 0 && base[s] > length) --s;
+    *symbol = 257u + (u32)s;
+    *extra_bits = bits[s];
+    *extra = length - base[s];
+}
+
+// Code for the 286 literal / end-of-block / length symbols from their frequencies (hist[256] = end of block, normally
+// 1) and the header of the one block that carries them: BFINAL = 1, BTYPE = dynamic, 286 literal/length codes, two
+// distance codes of one bit each (code 0 = distance 1, the only distance a run match uses; the second only completes the
+// code, which is what every inflate accepts), the code lengths themselves Huffman-coded with zero runs folded
+// (RFC 1951 3.2.7).  Returns the header's length in bits, 0 if it does not fit.
+size_t huffman_plan(const uint64_t hist[kDeflateSymbols], uint8_t lens[kDeflateSymbols], uint16_t codes[kDeflateSymbols], uint8_t *header,
+                    size_t header_cap)
+{
+    code_lengths(hist, kDeflateSymbols, 15, lens);
+    canonical_codes(lens, kDeflateSymbols, 15, codes);
+    // the 288 code lengths to transmit, zero runs as symbols 17 (3..10) / 18 (11..138)
+    constexpr int kSeq = kDeflateSymbols + 2;
+    u8 seq[kSeq];
+    std::memcpy(seq, lens, kDeflateSymbols);
+    seq[kSeq - 2] = seq[kSeq - 1] = 1;
     struct Item {
         u8 sym, extra_bits;
         uint16_t extra;
     };
     std::vector<Item> items;
-    for (int i = 0; i < 259;) {
+    for (int i = 0; i < kSeq;) {
         int run = 1;
-        while (i + run < 259 && seq[i + run] == seq[i]) ++run;
+        while (i + run < kSeq && seq[i + run] == seq[i]) ++run;
         if (seq[i] == 0 && run >= 3) {
             const int r = std::min(run, 138);
             if (r <= 10)
@@ -160,11 +180,11 @@ size_t huffman_plan(const uint64_t hist[257], uint8_t lens[257], uint16_t codes[
     int hclen = 19;
     while (hclen > 4 && cllen[order[hclen - 1]] == 0) --hclen;
     BitWriter bw;
-    bw.put(1, 1);                 // BFINAL
-    bw.put(2, 2);                 // BTYPE = 10: dynamic Huffman
-    bw.put(257 - 257, 5);         // HLIT
-    bw.put(2 - 1, 5);             // HDIST
-    bw.put((u32)(hclen - 4), 4);  // HCLEN
+    bw.put(1, 1);                               // BFINAL
+    bw.put(2, 2);                               // BTYPE = 10: dynamic Huffman
+    bw.put(kDeflateSymbols - 257, 5);           // HLIT
+    bw.put(2 - 1, 5);                           // HDIST
+    bw.put((u32)(hclen - 4), 4);                // HCLEN
     for (int i = 0; i < hclen; ++i) bw.put(cllen[order[i]], 3);
     for (const Item &it : items) {
         bw.put(clcode[it.sym], cllen[it.sym]);
@@ -176,47 +196,204 @@ size_t huffman_plan(const uint64_t hist[257], uint8_t lens[257], uint16_t codes[
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// device: sum, scan, pack
+// device: tokens, histogram, sum, scan, pack
 // ---------------------------------------------------------------------------------------------------------------
 namespace {
 
 constexpr int kPackThreads = 256;
-constexpr int kBytesPerThread = 4;                       // <= 60 code bits: one 64-bit accumulator, no arrays
-constexpr int kChunk = kPackThreads * kBytesPerThread;   // bytes per workgroup
+constexpr int kBytesPerThread = 4;
+constexpr int kChunk = kPackThreads * kBytesPerThread;   // bytes per workgroup: runs never cross a chunk boundary
+constexpr u32 kNone = 0xFFFFFFFFu;
 
-// table[v] = reversed code | length << 16
-__device__ __forceinline__ void pack4(const u8 *__restrict__ src, u64 n, u64 at, const u32 *stab, u64 &val, u32 &bits)
+// What the (up to) four bytes of this thread emit.  A byte "continues" when it equals its predecessor inside the chunk.
+// For a continuing byte at offset o (0-based) inside the run's tail of M continuing bytes, piece = o / 258 and the piece's
+// length is min(258, M - 258 * piece): the first byte of a piece of >= 3 emits the match, the others of that piece
+// nothing; bytes of a piece of 1-2 stay literals.  With k = bytes since the run's head (>= 1) and rem = continuing bytes
+// left including this one: o = k - 1, M - 258 * piece = rem + (o % 258).
+struct Tokens {
+    u32 sym[4];      // literal 0..255, or kNone: nothing, or 0x80000000 | match length
+};
+
+__device__ __forceinline__ Tokens tokens_of_thread(const u8 *__restrict__ src, u64 n, u64 chunk0, u32 *lds /* 2 * kPackThreads + 8 */)
+{
+    const u32 t = threadIdx.x;
+    const u64 at = chunk0 + (u64)t * kBytesPerThread;
+    const int cnt = at >= n ? 0 : (at + 4 <= n ? 4 : (int)(n - at));
+    u32 w = 0;
+    if (cnt == 4) {
+        __builtin_memcpy(&w, src + at, 4);
+    } else {
+        for (int i = 0; i < cnt; ++i) w |= (u32)src[at + i] << (8 * i);
+    }
+    const u32 prev = (t > 0 && cnt > 0) ? src[at - 1] : 0x100u;      // the chunk's first byte never continues
+    u32 b[4], cont[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) b[i] = (w >> (8 * i)) & 255u;
+    cont[0] = cnt > 0 && b[0] == prev;
+#pragma unroll
+    for (int i = 1; i < 4; ++i) cont[i] = i < cnt && b[i] == b[i - 1];
+    // positions inside the chunk: p = 4 t + i.  head(p) = last position <= p that does not continue (exists: position 0);
+    // end(p) = first position > p that does not continue, or the number of valid bytes in the chunk
+    u32 last_head = kNone, first_head = kNone;      // of this thread's positions (kNone: all four continue / are invalid)
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+        if (i < cnt && !cont[i]) {
+            last_head = 4 * t + i;
+            if (first_head == kNone) first_head = 4 * t + i;
+        }
+    // invalid positions (beyond n) end every run: treat the first invalid position as a head for the backward scan
+    const u32 valid_end = cnt < 4 ? 4 * t + cnt : kNone;
+    u32 first_stop = first_head < valid_end ? first_head : valid_end;
+    // exclusive forward max-scan of last_head (kNone = -1: use +1 encoding), exclusive backward min-scan of first_stop
+    u32 fwd = last_head + 1u;      // 0 = none
+    u32 bwd = first_stop;          // kNone = none
+    const u32 lane = t & 63u, wave = t >> 6;
+    u32 fi = fwd, bi = bwd;
+    for (int o = 1; o < 64; o <<= 1) {
+        const u32 up = __shfl_up(fi, o, 64), dn = __shfl_down(bi, o, 64);
+        if ((int)lane >= o) fi = fi > up ? fi : up;
+        if ((int)lane + o < 64) bi = bi < dn ? bi : dn;
+    }
+    if (lane == 63) lds[wave] = fi;
+    if (lane == 0) lds[4 + wave] = bi;
+    __syncthreads();
+    u32 head_before = __shfl_up(fi, 1, 64);
+    if (lane == 0) head_before = 0;
+    for (u32 wv = 0; wv < wave; ++wv) head_before = head_before > lds[wv] ? head_before : lds[wv];
+    u32 stop_after = __shfl_down(bi, 1, 64);
+    if (lane == 63) stop_after = kNone;
+    for (u32 wv = wave + 1; wv < kPackThreads / 64; ++wv) stop_after = stop_after < lds[4 + wv] ? stop_after : lds[4 + wv];
+    __syncthreads();                 // lds is reused by the caller
+    // walk my four positions
+    Tokens tk;
+    u32 head = head_before;          // +1 encoded position of the latest head before my first byte (0 only for thread 0)
+    // end position for each of my bytes: the next stop after it
+    u32 stop[4];
+    u32 nxt = stop_after;            // first stop strictly after my last position (kNone: none in the chunk)
+    const u32 chunk_valid = (u32)(n - chunk0 < (u64)kChunk ? n - chunk0 : (u64)kChunk);
+    if (nxt == kNone || nxt > chunk_valid) nxt = chunk_valid;
+#pragma unroll
+    for (int i = 3; i >= 0; --i) {
+        stop[i] = nxt;
+        if (i < cnt && !cont[i]) nxt = 4 * t + i;
+        if (i >= cnt) nxt = nxt < 4 * t + (u32)i ? nxt : 4 * t + (u32)i;
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const u32 p = 4 * t + i;
+        tk.sym[i] = kNone;
+        if (i >= cnt) continue;
+        if (!cont[i]) {
+            head = p + 1;
+            tk.sym[i] = b[i];
+            continue;
+        }
+        const u32 k = p - (head - 1);            // >= 1: bytes since the head
+        const u32 rem = stop[i] - p;             // continuing bytes left including this one
+        const u32 o = (k - 1) % 258u;
+        u32 piece = rem + o;
+        piece = piece < 258u ? piece : 258u;
+        if (piece >= 3)
+            tk.sym[i] = o == 0 ? (0x80000000u | piece) : kNone;
+        else
+            tk.sym[i] = b[i];
+    }
+    return tk;
+}
+
+// length 3..258 -> length symbol, extra bits (RFC 1951 3.2.5), branch-free enough
+__device__ __forceinline__ void length_symbol(u32 length, u32 &symbol, u32 &extra_bits, u32 &extra)
+{
+    if (length == 258) {
+        symbol = 285;
+        extra_bits = 0;
+        extra = 0;
+        return;
+    }
+    const u32 l = length - 3;                         // 0..254
+    if (l < 8) {
+        symbol = 257 + l;
+        extra_bits = 0;
+        extra = 0;
+        return;
+    }
+    const u32 e = 29 - __clz(l);                      // extra bits: l in [8,16) -> 1, [16,32) -> 2, ...
+    symbol = 257 + 4 * e + 4 + ((l >> e) & 3u);
+    extra_bits = e;
+    extra = l & ((1u << e) - 1u);
+}
+
+// pass 1: histogram of the literal / length symbols the tokens use
+__global__ __launch_bounds__(kPackThreads) void k_token_hist(const u8 *__restrict__ src, u64 n, unsigned long long *__restrict__ hist)
+{
+    __shared__ u32 scan[16];
+    __shared__ u32 h[kDeflateSymbols * 8];            // eight copies, value-major (a handful of symbols dominate)
+    for (int i = threadIdx.x; i < kDeflateSymbols * 8; i += kPackThreads) h[i] = 0;
+    __syncthreads();
+    const u32 copy = threadIdx.x & 7u;
+    for (u64 chunk = blockIdx.x; chunk * kChunk < n; chunk += gridDim.x) {
+        const Tokens tk = tokens_of_thread(src, n, chunk * kChunk, scan);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const u32 s = tk.sym[i];
+            if (s == kNone) continue;
+            u32 sym = s;
+            if (s & 0x80000000u) {
+                u32 eb, ex;
+                length_symbol(s & 0xFFFFu, sym, eb, ex);
+            }
+            atomicAdd(&h[sym * 8 + copy], 1u);
+        }
+    }
+    __syncthreads();
+    for (int v = threadIdx.x; v < kDeflateSymbols; v += kPackThreads) {
+        u32 sum = 0;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) sum += h[v * 8 + k];
+        if (sum) atomicAdd(&hist[v], (unsigned long long)sum);
+    }
+}
+
+// the bits of this thread's tokens (table[s] = reversed code | length << 16 for the 286 symbols; dist = the one distance
+// code used, same packing): at most 3 x 15 + (15 + 5 + 1) = 66 bits in 4 bytes -> a 128-bit accumulator
+__device__ __forceinline__ void pack_tokens(const Tokens &tk, const u32 *stab, u32 dist, unsigned __int128 &val, u32 &bits)
 {
     val = 0;
     bits = 0;
-    if (at >= n) return;
-    u32 w = 0;
-    if (at + 4 <= n) {
-        __builtin_memcpy(&w, src + at, 4);
-    } else {
-        for (u64 i = at; i < n; ++i) w |= (u32)src[i] << (8 * (i - at));
-    }
-    const int cnt = at + 4 <= n ? 4 : (int)(n - at);
 #pragma unroll
-    for (int b = 0; b < 4; ++b) {
-        if (b < cnt) {
-            const u32 e = stab[(w >> (8 * b)) & 255u];
-            val |= (u64)(e & 0xFFFFu) << bits;
+    for (int i = 0; i < 4; ++i) {
+        const u32 s = tk.sym[i];
+        if (s == kNone) continue;
+        if (s & 0x80000000u) {
+            u32 sym, eb, ex;
+            length_symbol(s & 0xFFFFu, sym, eb, ex);
+            const u32 e = stab[sym];
+            val |= (unsigned __int128)(e & 0xFFFFu) << bits;
+            bits += e >> 16;
+            val |= (unsigned __int128)ex << bits;
+            bits += eb;
+            val |= (unsigned __int128)(dist & 0xFFFFu) << bits;
+            bits += dist >> 16;
+        } else {
+            const u32 e = stab[s];
+            val |= (unsigned __int128)(e & 0xFFFFu) << bits;
             bits += e >> 16;
         }
     }
 }
 
-__global__ __launch_bounds__(kPackThreads) void k_huff_count(const u8 *__restrict__ src, u64 n, const u32 *__restrict__ table,
-                                                             u32 *__restrict__ chunk_bits)
+// pass 2: bits per chunk
+__global__ __launch_bounds__(kPackThreads) void k_token_count(const u8 *__restrict__ src, u64 n, const u32 *__restrict__ table, u32 dist,
+                                                              u32 *__restrict__ chunk_bits)
 {
-    __shared__ u32 stab[256];
+    __shared__ u32 stab[kDeflateSymbols];
+    __shared__ u32 scan[16];
     __shared__ u32 wsum[kPackThreads / 64];
-    stab[threadIdx.x] = table[threadIdx.x];
-    __syncthreads();
-    u64 val;
+    for (int i = threadIdx.x; i < kDeflateSymbols; i += kPackThreads) stab[i] = table[i];
+    const Tokens tk = tokens_of_thread(src, n, (u64)blockIdx.x * kChunk, scan);      // (its barriers publish stab too)
+    unsigned __int128 val;
     u32 bits;
-    pack4(src, n, (u64)blockIdx.x * kChunk + threadIdx.x * kBytesPerThread, stab, val, bits);
+    pack_tokens(tk, stab, dist, val, bits);
     for (int o = 32; o > 0; o >>= 1) bits += __shfl_down(bits, o, 64);
     if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = bits;
     __syncthreads();
@@ -228,7 +405,8 @@ __global__ __launch_bounds__(1024) void k_huff_scan(const u32 *__restrict__ chun
                                                     u64 *__restrict__ total)
 {
     __shared__ u64 part[1024];
-    const u32 per = (nchunks + 1023u) / 1024u, lo = threadIdx.x * per, hi = lo + per < nchunks ? lo + per : nchunks;
+    const u32 per = (nchunks + 1023u) / 1024u, lo = threadIdx.x * per < nchunks ? threadIdx.x * per : nchunks,
+              hi = lo + per < nchunks ? lo + per : nchunks;
     u64 sum = 0;
     for (u32 i = lo; i < hi; ++i) sum += chunk_bits[i];
     part[threadIdx.x] = sum;
@@ -247,17 +425,18 @@ __global__ __launch_bounds__(1024) void k_huff_scan(const u32 *__restrict__ chun
     if (threadIdx.x == 1023) *total = part[1023];
 }
 
-// every thread ORs the codes of its four bytes into the (zeroed) stream at its bit position
-__global__ __launch_bounds__(kPackThreads) void k_huff_pack(const u8 *__restrict__ src, u64 n, const u32 *__restrict__ table,
-                                                            const u64 *__restrict__ chunk_off, u64 base_bits, u32 *__restrict__ out)
+// pass 3: every thread ORs its tokens into the (zeroed) stream at its bit position
+__global__ __launch_bounds__(kPackThreads) void k_token_pack(const u8 *__restrict__ src, u64 n, const u32 *__restrict__ table, u32 dist,
+                                                             const u64 *__restrict__ chunk_off, u64 base_bits, u32 *__restrict__ out)
 {
-    __shared__ u32 stab[256];
+    __shared__ u32 stab[kDeflateSymbols];
+    __shared__ u32 scan[16];
     __shared__ u32 wsum[kPackThreads / 64];
-    stab[threadIdx.x] = table[threadIdx.x];
-    __syncthreads();
-    u64 val;
+    for (int i = threadIdx.x; i < kDeflateSymbols; i += kPackThreads) stab[i] = table[i];
+    const Tokens tk = tokens_of_thread(src, n, (u64)blockIdx.x * kChunk, scan);
+    unsigned __int128 val;
     u32 bits;
-    pack4(src, n, (u64)blockIdx.x * kChunk + threadIdx.x * kBytesPerThread, stab, val, bits);
+    pack_tokens(tk, stab, dist, val, bits);
     // exclusive scan of `bits` over the workgroup: inside the wave by shuffles, across the four waves through LDS
     u32 incl = bits;
     const u32 lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
@@ -273,27 +452,36 @@ __global__ __launch_bounds__(kPackThreads) void k_huff_pack(const u8 *__restrict
     const u64 pos = base_bits + chunk_off[blockIdx.x] + before;
     const u32 sh = (u32)(pos & 31u);
     u32 *dst = out + (pos >> 5);
-    const u32 v0 = (u32)val, v1 = (u32)(val >> 32);
-    const u32 o0 = v0 << sh;
-    const u32 o1 = (sh ? v0 >> (32 - sh) : 0u) | (v1 << sh);
-    const u32 o2 = sh ? v1 >> (32 - sh) : 0u;
+    const unsigned __int128 shifted = val << sh;          // <= 66 + 31 bits
+    const u32 o0 = (u32)shifted, o1 = (u32)(shifted >> 32), o2 = (u32)(shifted >> 64), o3 = (u32)(shifted >> 96);
     if (o0) atomicOr(dst, o0);
     if (o1) atomicOr(dst + 1, o1);
     if (o2) atomicOr(dst + 2, o2);
+    if (o3) atomicOr(dst + 3, o3);
 }
 
 }  // namespace
 
 u32 huffman_chunks(u64 n) { return (u32)((n + kChunk - 1) / kChunk); }
 
-hipError_t launch_huffman_pack(const uint8_t *src, uint64_t n, const uint32_t *d_table, uint32_t *d_chunk_bits, uint64_t *d_chunk_off,
-                               uint64_t *d_total, uint64_t base_bits, uint32_t *d_out, hipStream_t s)
+hipError_t launch_token_histogram(const uint8_t *src, uint64_t n, unsigned long long *d_hist, hipStream_t s)
+{
+    hipError_t e = hipMemsetAsync(d_hist, 0, kDeflateSymbols * sizeof(unsigned long long), s);
+    if (e != hipSuccess || n == 0) return e;
+    u32 blocks = huffman_chunks(n);
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(k_token_hist, dim3(blocks), dim3(kPackThreads), 0, s, src, n, d_hist);
+    return hipGetLastError();
+}
+
+hipError_t launch_huffman_pack(const uint8_t *src, uint64_t n, const uint32_t *d_table, uint32_t dist_code, uint32_t *d_chunk_bits,
+                               uint64_t *d_chunk_off, uint64_t *d_total, uint64_t base_bits, uint32_t *d_out, hipStream_t s)
 {
     const u32 nchunks = huffman_chunks(n);
     if (nchunks == 0) return hipSuccess;
-    hipLaunchKernelGGL(k_huff_count, dim3(nchunks), dim3(kPackThreads), 0, s, src, n, d_table, d_chunk_bits);
+    hipLaunchKernelGGL(k_token_count, dim3(nchunks), dim3(kPackThreads), 0, s, src, n, d_table, dist_code, d_chunk_bits);
     hipLaunchKernelGGL(k_huff_scan, dim3(1), dim3(1024), 0, s, d_chunk_bits, d_chunk_off, nchunks, d_total);
-    hipLaunchKernelGGL(k_huff_pack, dim3(nchunks), dim3(kPackThreads), 0, s, src, n, d_table, d_chunk_off, base_bits, d_out);
+    hipLaunchKernelGGL(k_token_pack, dim3(nchunks), dim3(kPackThreads), 0, s, src, n, d_table, dist_code, d_chunk_off, base_bits, d_out);
     return hipGetLastError();
 }
 

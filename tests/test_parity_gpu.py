@@ -792,11 +792,11 @@ def test_planes_alloc_places_neighbours_in_different_regions(H, oracle):
 
 
 @pytest.mark.parametrize("w,h,levels,q", [(256, 256, 4, 2), (256, 256, 4, 0), (1920, 1080, 4, 2), (13, 7, 3, 1), (1, 1, 0, 0),
-                                          (4096, 4096, 4, 2), (1001, 999, 5, 3), (3, 1, 1, 0)])
+                                          (4096, 4096, 4, 2), (1001, 999, 5, 3), (3, 1, 1, 0), (1920, 1080, 4, 3), (1025, 3, 1, 3)])
 def test_device_entropy_stage_writes_ordinary_deflate(H, oracle, lena, w, h, levels, q):
     """hgi_deflate_grid_dev (include/hgi.h): the stream the device writes for a grid is raw DEFLATE that zlib inflates to
     the grid's bincode image (u64 N, bytes, u64 width) -- what `Archive::deserialize_from_reader` (src/archive.rs:43-55)
-    expects behind the metadata -- and it is as tight as zlib's own Huffman-only stream."""
+    expects behind the metadata -- and it is as tight as zlib's own Huffman-only / run-length-only streams."""
     import struct
     import zlib
     import torch
@@ -807,9 +807,11 @@ def test_device_entropy_stage_writes_ordinary_deflate(H, oracle, lena, w, h, lev
     stream = entropy.deflate_grid(d)
     body = struct.pack("<Q", w * h) + grid.tobytes() + struct.pack("<Q", w)
     assert zlib.decompressobj(-15).decompress(stream) == body
-    co = zlib.compressobj(9, zlib.DEFLATED, -15, 9, zlib.Z_HUFFMAN_ONLY)
-    ref = len(co.compress(body) + co.flush())
-    assert len(stream) <= ref + 64 + ref // 100, (len(stream), ref)
+    def zsize(strategy):
+        co = zlib.compressobj(9, zlib.DEFLATED, -15, 9, strategy)
+        return len(co.compress(body) + co.flush())
+    ref = min(zsize(zlib.Z_HUFFMAN_ONLY), zsize(zlib.Z_RLE))     # the two things the stage does, as zlib does them
+    assert len(stream) <= ref + 64 + ref // 25, (len(stream), ref)
 
 
 def test_archive_with_device_entropy_interoperates(H, oracle, lena, tmp_path):
