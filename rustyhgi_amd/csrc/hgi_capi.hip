@@ -762,7 +762,8 @@ hgi_status hgi_huffman_plan(const uint64_t hist[286], uint8_t lens[286], uint16_
 
 static size_t deflate_scratch_bytes(uint64_t n)
 {
-    return kDeflateSymbols * 12 + (size_t)huffman_chunks(n) * 12 + 8 + align_up((size_t)(n + n / 4) + 4096, 256) + 10 * 256;
+    return kMatchThresholds * kDeflateSymbols * 8 + kDeflateSymbols * 4 + (size_t)huffman_chunks(n) * 12 + 8 +
+           align_up((size_t)(n + n / 4) + 4096, 256) + 10 * 256;
 }
 
 // host-pointer form (what pairs with hgi_encode_u8): the grid goes up into scratch behind the stage's own buffers
@@ -796,28 +797,54 @@ hgi_status hgi_deflate_grid_dev(hgi_ctx *c, const void *d_grid, uint32_t w, uint
     const size_t need = deflate_scratch_bytes(n);
     HGI_TRY(ws_ensure(c, need));
     c->ws_used = 0;
-    unsigned long long *d_hist = reinterpret_cast<unsigned long long *>(ws_take(c, kDeflateSymbols * 8));
+    unsigned long long *d_hist = reinterpret_cast<unsigned long long *>(ws_take(c, kMatchThresholds * kDeflateSymbols * 8));
     uint32_t *d_table = reinterpret_cast<uint32_t *>(ws_take(c, kDeflateSymbols * 4));
     uint64_t *d_off = reinterpret_cast<uint64_t *>(ws_take(c, (size_t)nchunks * 8 + 8));
     uint32_t *d_cbits = reinterpret_cast<uint32_t *>(ws_take(c, (size_t)nchunks * 4 + 8));
     uint64_t *d_total = reinterpret_cast<uint64_t *>(ws_take(c, 8));
     uint32_t *d_out = reinterpret_cast<uint32_t *>(ws_take(c, dev_cap));
     if (!d_hist || !d_table || !d_off || !d_cbits || !d_total || !d_out) return fail(HGI_ENOMEM, "scratch exhausted (entropy stage)");
-    uint64_t hist[kDeflateSymbols] = {0};
+    uint64_t hists[kMatchThresholds][kDeflateSymbols] = {{0}};
     if (n) {
         HIP_TRY(launch_token_histogram(static_cast<const uint8_t *>(d_grid), n, d_hist, c->stream));
-        HIP_TRY(hipMemcpyAsync(hist, d_hist, kDeflateSymbols * 8, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipMemcpyAsync(hists, d_hist, sizeof(hists), hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(hipStreamSynchronize(c->stream));
     }
-    for (int i = 0; i < 8; ++i) {
-        ++hist[prefix[i]];
-        ++hist[suffix[i]];
-    }
-    hist[256] = 1;      // end of block
+    // for each candidate threshold: the code its histogram asks for and the exact size of the stream it gives; keep the
+    // smallest (the 16 bytes around the grid are literals under every threshold)
     uint8_t lens[kDeflateSymbols], head[640];
     uint16_t codes[kDeflateSymbols];
-    size_t bits = huffman_plan(hist, lens, codes, head, sizeof(head) - 64);
-    if (!bits) return fail(HGI_EDEVICE, "block header does not fit");
+    size_t bits = 0;
+    uint32_t min_match = kMatchThresholdHost[0];
+    {
+        uint64_t best = ~0ull;
+        int pick = 0;
+        for (int v = 0; v < kMatchThresholds; ++v) {
+            uint64_t *hv = hists[v];
+            for (int i = 0; i < 8; ++i) {
+                ++hv[prefix[i]];
+                ++hv[suffix[i]];
+            }
+            hv[256] = 1;      // end of block
+            uint8_t l[kDeflateSymbols], hd[640];
+            uint16_t cd[kDeflateSymbols];
+            uint64_t total = huffman_plan(hv, l, cd, hd, sizeof(hd) - 64);
+            if (!total) return fail(HGI_EDEVICE, "block header does not fit");
+            for (int sym = 0; sym < kDeflateSymbols; ++sym) total += hv[sym] * l[sym];
+            for (uint32_t len = 3; len <= 258; ++len) {      // extra bits of the length symbols, one distance bit per match
+                uint32_t sym, eb, ex;
+                deflate_length_symbol(len, &sym, &eb, &ex);
+                if (ex == 0) total += hv[sym] * (eb + 1);
+            }
+            if (total < best) {
+                best = total;
+                pick = v;
+            }
+            if (n == 0) break;
+        }
+        min_match = kMatchThresholdHost[pick];
+        bits = huffman_plan(hists[pick], lens, codes, head, sizeof(head) - 64);
+    }
     auto put = [&](std::vector<uint8_t> &v, size_t &at, uint32_t value, int nb) {
         for (int i = 0; i < nb; ++i, ++at) {
             if ((at >> 3) >= v.size()) v.push_back(0);
@@ -835,8 +862,8 @@ hgi_status hgi_deflate_grid_dev(hgi_ctx *c, const void *d_grid, uint32_t w, uint
         HIP_TRY(hipMemsetAsync(d_out, 0, dev_cap, c->stream));
         HIP_TRY(hipMemcpyAsync(d_out, front.data(), front.size(), hipMemcpyHostToDevice, c->stream));
         HIP_TRY(hipMemcpyAsync(d_table, table, sizeof(table), hipMemcpyHostToDevice, c->stream));
-        HIP_TRY(launch_huffman_pack(static_cast<const uint8_t *>(d_grid), n, d_table, dist_code, d_cbits, d_off, d_total, base_bits,
-                                    d_out, c->stream));
+        HIP_TRY(launch_huffman_pack(static_cast<const uint8_t *>(d_grid), n, d_table, dist_code, min_match, d_cbits, d_off, d_total,
+                                    base_bits, d_out, c->stream));
         HIP_TRY(hipMemcpyAsync(&grid_bits, d_total, 8, hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(hipStreamSynchronize(c->stream));       // (front / table are read by the copies above: they end here)
     }

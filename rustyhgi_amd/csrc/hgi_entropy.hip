@@ -10,8 +10,9 @@
 //   tokens     a byte equal to its predecessor continues a run; a run's bytes after its first are covered by matches of
 //              distance 1 and length 3..258 (leftovers of 1-2 bytes stay literals).  Runs are cut at 1 KiB chunk
 //              boundaries, so every token is decided inside one workgroup (cost: one extra literal per KiB of run).
-//   histogram  of the 286 literal / length symbols the tokens use                              (device, pass 1)
-//   code       length-limited canonical Huffman code + the RFC 1951 block header               (host, a few hundred symbols)
+//   histogram  of the 286 literal / length symbols the tokens use, for four match thresholds   (device, pass 1)
+//   code       for each threshold: length-limited canonical Huffman code, exact stream size;    (host, a few hundred symbols)
+//              the smallest wins (short runs of a byte whose literal costs 1 bit are cheaper as literals) + block header
 //   bits       per chunk (pass 2), exclusive scan over the chunks, and every token OR-ed into place (pass 3)
 // The stream is ordinary DEFLATE: flate2 / zlib / miniz inflate it; `Archive::deserialize_from_reader`
 // (src/archive.rs:43-55) reads archives written this way unchanged.
@@ -204,15 +205,27 @@ constexpr int kPackThreads = 256;
 constexpr int kBytesPerThread = 4;
 constexpr int kChunk = kPackThreads * kBytesPerThread;   // bytes per workgroup: runs never cross a chunk boundary
 constexpr u32 kNone = 0xFFFFFFFFu;
+__device__ constexpr u32 kMatchThreshold[kMatchThresholds] = {3, 4, 6, 10};      // = kMatchThresholdHost (hgi_kernels.h)
 
 // What the (up to) four bytes of this thread emit.  A byte "continues" when it equals its predecessor inside the chunk.
 // For a continuing byte at offset o (0-based) inside the run's tail of M continuing bytes, piece = o / 258 and the piece's
-// length is min(258, M - 258 * piece): the first byte of a piece of >= 3 emits the match, the others of that piece
-// nothing; bytes of a piece of 1-2 stay literals.  With k = bytes since the run's head (>= 1) and rem = continuing bytes
+// length is min(258, M - 258 * piece): the first byte of a piece of >= min_match (>= 3) emits the match, the others of that
+// piece nothing; bytes of shorter pieces stay literals.  With k = bytes since the run's head (>= 1) and rem = continuing bytes
 // left including this one: o = k - 1, M - 258 * piece = rem + (o % 258).
 struct Tokens {
-    u32 sym[4];      // literal 0..255, or kNone: nothing, or 0x80000000 | match length
+    u32 lit[4];      // the byte, or kNone beyond the end of the data
+    u32 piece[4];    // 0: the byte heads a run (or stands alone); else the length (1..258) of the run piece it lies in
+    u32 first[4];    // ... and whether it is that piece's first byte
 };
+
+// what byte i emits when pieces of at least `min_match` become matches: literal 0..255, kNone (nothing: covered by a
+// match), or 0x80000000 | match length
+__device__ __forceinline__ u32 token_symbol(const Tokens &tk, int i, u32 min_match)
+{
+    if (tk.lit[i] == kNone) return kNone;
+    if (tk.piece[i] >= min_match) return tk.first[i] ? (0x80000000u | tk.piece[i]) : kNone;
+    return tk.lit[i];
+}
 
 __device__ __forceinline__ Tokens tokens_of_thread(const u8 *__restrict__ src, u64 n, u64 chunk0, u32 *lds /* 2 * kPackThreads + 8 */)
 {
@@ -281,22 +294,21 @@ __device__ __forceinline__ Tokens tokens_of_thread(const u8 *__restrict__ src, u
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const u32 p = 4 * t + i;
-        tk.sym[i] = kNone;
+        tk.lit[i] = kNone;
+        tk.piece[i] = 0;
+        tk.first[i] = 0;
         if (i >= cnt) continue;
+        tk.lit[i] = b[i];
         if (!cont[i]) {
             head = p + 1;
-            tk.sym[i] = b[i];
             continue;
         }
         const u32 k = p - (head - 1);            // >= 1: bytes since the head
         const u32 rem = stop[i] - p;             // continuing bytes left including this one
         const u32 o = (k - 1) % 258u;
-        u32 piece = rem + o;
-        piece = piece < 258u ? piece : 258u;
-        if (piece >= 3)
-            tk.sym[i] = o == 0 ? (0x80000000u | piece) : kNone;
-        else
-            tk.sym[i] = b[i];
+        const u32 piece = rem + o;
+        tk.piece[i] = piece < 258u ? piece : 258u;
+        tk.first[i] = o == 0;
     }
     return tk;
 }
@@ -323,46 +335,53 @@ __device__ __forceinline__ void length_symbol(u32 length, u32 &symbol, u32 &extr
     extra = l & ((1u << e) - 1u);
 }
 
-// pass 1: histogram of the literal / length symbols the tokens use
+// pass 1: histograms of the literal / length symbols the tokens use, for each candidate match threshold at once (a short
+// run of a byte whose literal costs one bit is cheaper as literals than as a match; which threshold pays is decided on
+// the host from the exact stream sizes the histograms imply)
 __global__ __launch_bounds__(kPackThreads) void k_token_hist(const u8 *__restrict__ src, u64 n, unsigned long long *__restrict__ hist)
 {
+    constexpr int kCopies = 4;
     __shared__ u32 scan[16];
-    __shared__ u32 h[kDeflateSymbols * 8];            // eight copies, value-major (a handful of symbols dominate)
-    for (int i = threadIdx.x; i < kDeflateSymbols * 8; i += kPackThreads) h[i] = 0;
+    __shared__ u32 h[kMatchThresholds][kDeflateSymbols * kCopies];      // copies value-major (a handful of symbols dominate)
+    for (int i = threadIdx.x; i < kMatchThresholds * kDeflateSymbols * kCopies; i += kPackThreads) (&h[0][0])[i] = 0;
     __syncthreads();
-    const u32 copy = threadIdx.x & 7u;
+    const u32 copy = threadIdx.x & (kCopies - 1);
     for (u64 chunk = blockIdx.x; chunk * kChunk < n; chunk += gridDim.x) {
         const Tokens tk = tokens_of_thread(src, n, chunk * kChunk, scan);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const u32 s = tk.sym[i];
-            if (s == kNone) continue;
-            u32 sym = s;
-            if (s & 0x80000000u) {
-                u32 eb, ex;
-                length_symbol(s & 0xFFFFu, sym, eb, ex);
+        for (int v = 0; v < kMatchThresholds; ++v) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const u32 s = token_symbol(tk, i, kMatchThreshold[v]);
+                if (s == kNone) continue;
+                u32 sym = s;
+                if (s & 0x80000000u) {
+                    u32 eb, ex;
+                    length_symbol(s & 0xFFFFu, sym, eb, ex);
+                }
+                atomicAdd(&h[v][sym * kCopies + copy], 1u);
             }
-            atomicAdd(&h[sym * 8 + copy], 1u);
         }
     }
     __syncthreads();
-    for (int v = threadIdx.x; v < kDeflateSymbols; v += kPackThreads) {
+    for (int i = threadIdx.x; i < kMatchThresholds * kDeflateSymbols; i += kPackThreads) {
+        const int v = i / kDeflateSymbols, sym = i - v * kDeflateSymbols;
         u32 sum = 0;
 #pragma unroll
-        for (int k = 0; k < 8; ++k) sum += h[v * 8 + k];
-        if (sum) atomicAdd(&hist[v], (unsigned long long)sum);
+        for (int k = 0; k < kCopies; ++k) sum += h[v][sym * kCopies + k];
+        if (sum) atomicAdd(&hist[i], (unsigned long long)sum);
     }
 }
 
 // the bits of this thread's tokens (table[s] = reversed code | length << 16 for the 286 symbols; dist = the one distance
 // code used, same packing): at most 3 x 15 + (15 + 5 + 1) = 66 bits in 4 bytes -> a 128-bit accumulator
-__device__ __forceinline__ void pack_tokens(const Tokens &tk, const u32 *stab, u32 dist, unsigned __int128 &val, u32 &bits)
+__device__ __forceinline__ void pack_tokens(const Tokens &tk, u32 min_match, const u32 *stab, u32 dist, unsigned __int128 &val, u32 &bits)
 {
     val = 0;
     bits = 0;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        const u32 s = tk.sym[i];
+        const u32 s = token_symbol(tk, i, min_match);
         if (s == kNone) continue;
         if (s & 0x80000000u) {
             u32 sym, eb, ex;
@@ -384,7 +403,7 @@ __device__ __forceinline__ void pack_tokens(const Tokens &tk, const u32 *stab, u
 
 // pass 2: bits per chunk
 __global__ __launch_bounds__(kPackThreads) void k_token_count(const u8 *__restrict__ src, u64 n, const u32 *__restrict__ table, u32 dist,
-                                                              u32 *__restrict__ chunk_bits)
+                                                              u32 min_match, u32 *__restrict__ chunk_bits)
 {
     __shared__ u32 stab[kDeflateSymbols];
     __shared__ u32 scan[16];
@@ -393,7 +412,7 @@ __global__ __launch_bounds__(kPackThreads) void k_token_count(const u8 *__restri
     const Tokens tk = tokens_of_thread(src, n, (u64)blockIdx.x * kChunk, scan);      // (its barriers publish stab too)
     unsigned __int128 val;
     u32 bits;
-    pack_tokens(tk, stab, dist, val, bits);
+    pack_tokens(tk, min_match, stab, dist, val, bits);
     for (int o = 32; o > 0; o >>= 1) bits += __shfl_down(bits, o, 64);
     if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = bits;
     __syncthreads();
@@ -427,7 +446,8 @@ __global__ __launch_bounds__(1024) void k_huff_scan(const u32 *__restrict__ chun
 
 // pass 3: every thread ORs its tokens into the (zeroed) stream at its bit position
 __global__ __launch_bounds__(kPackThreads) void k_token_pack(const u8 *__restrict__ src, u64 n, const u32 *__restrict__ table, u32 dist,
-                                                             const u64 *__restrict__ chunk_off, u64 base_bits, u32 *__restrict__ out)
+                                                             u32 min_match, const u64 *__restrict__ chunk_off, u64 base_bits,
+                                                             u32 *__restrict__ out)
 {
     __shared__ u32 stab[kDeflateSymbols];
     __shared__ u32 scan[16];
@@ -436,7 +456,7 @@ __global__ __launch_bounds__(kPackThreads) void k_token_pack(const u8 *__restric
     const Tokens tk = tokens_of_thread(src, n, (u64)blockIdx.x * kChunk, scan);
     unsigned __int128 val;
     u32 bits;
-    pack_tokens(tk, stab, dist, val, bits);
+    pack_tokens(tk, min_match, stab, dist, val, bits);
     // exclusive scan of `bits` over the workgroup: inside the wave by shuffles, across the four waves through LDS
     u32 incl = bits;
     const u32 lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
@@ -466,7 +486,7 @@ u32 huffman_chunks(u64 n) { return (u32)((n + kChunk - 1) / kChunk); }
 
 hipError_t launch_token_histogram(const uint8_t *src, uint64_t n, unsigned long long *d_hist, hipStream_t s)
 {
-    hipError_t e = hipMemsetAsync(d_hist, 0, kDeflateSymbols * sizeof(unsigned long long), s);
+    hipError_t e = hipMemsetAsync(d_hist, 0, kMatchThresholds * kDeflateSymbols * sizeof(unsigned long long), s);
     if (e != hipSuccess || n == 0) return e;
     u32 blocks = huffman_chunks(n);
     if (blocks > 4096) blocks = 4096;
@@ -474,14 +494,15 @@ hipError_t launch_token_histogram(const uint8_t *src, uint64_t n, unsigned long 
     return hipGetLastError();
 }
 
-hipError_t launch_huffman_pack(const uint8_t *src, uint64_t n, const uint32_t *d_table, uint32_t dist_code, uint32_t *d_chunk_bits,
-                               uint64_t *d_chunk_off, uint64_t *d_total, uint64_t base_bits, uint32_t *d_out, hipStream_t s)
+hipError_t launch_huffman_pack(const uint8_t *src, uint64_t n, const uint32_t *d_table, uint32_t dist_code, uint32_t min_match,
+                               uint32_t *d_chunk_bits, uint64_t *d_chunk_off, uint64_t *d_total, uint64_t base_bits, uint32_t *d_out,
+                               hipStream_t s)
 {
     const u32 nchunks = huffman_chunks(n);
     if (nchunks == 0) return hipSuccess;
-    hipLaunchKernelGGL(k_token_count, dim3(nchunks), dim3(kPackThreads), 0, s, src, n, d_table, dist_code, d_chunk_bits);
+    hipLaunchKernelGGL(k_token_count, dim3(nchunks), dim3(kPackThreads), 0, s, src, n, d_table, dist_code, min_match, d_chunk_bits);
     hipLaunchKernelGGL(k_huff_scan, dim3(1), dim3(1024), 0, s, d_chunk_bits, d_chunk_off, nchunks, d_total);
-    hipLaunchKernelGGL(k_token_pack, dim3(nchunks), dim3(kPackThreads), 0, s, src, n, d_table, dist_code, d_chunk_off, base_bits, d_out);
+    hipLaunchKernelGGL(k_token_pack, dim3(nchunks), dim3(kPackThreads), 0, s, src, n, d_table, dist_code, min_match, d_chunk_off, base_bits, d_out);
     return hipGetLastError();
 }
 

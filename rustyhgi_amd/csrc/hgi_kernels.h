@@ -82,19 +82,22 @@ hipError_t launch_diff_stats(const uint8_t *a, const uint8_t *b, const Frames &f
 
 // ---- entropy stage (hgi_entropy.hip): raw DEFLATE of a grid as one dynamic-Huffman block of literals + run matches ----
 constexpr int kDeflateSymbols = 286;      // literals 0..255, end of block 256, match lengths 257..285 (RFC 1951 3.2.5)
+constexpr int kMatchThresholds = 4;       // run pieces become matches from this length on: candidates, the host picks
+constexpr uint32_t kMatchThresholdHost[kMatchThresholds] = {3, 4, 6, 10};
 // host: code for those symbols + the block header (two distance codes of one bit; code 0 = distance 1); returns the
 // header's bits (0: no room)
 size_t huffman_plan(const uint64_t hist[kDeflateSymbols], uint8_t lens[kDeflateSymbols], uint16_t codes[kDeflateSymbols],
                     uint8_t *header, size_t header_cap);
 void deflate_length_symbol(uint32_t length, uint32_t *symbol, uint32_t *extra_bits, uint32_t *extra);
-// device, pass 1: d_hist[kDeflateSymbols] = how often the tokens of src[0..n) use each symbol (runs -> distance-1 matches,
-// cut at 1 KiB chunk boundaries)
+// device, pass 1: d_hist[kMatchThresholds][kDeflateSymbols] = how often the tokens of src[0..n) use each symbol (runs ->
+// distance-1 matches, cut at 1 KiB chunk boundaries), for each candidate match threshold
 hipError_t launch_token_histogram(const uint8_t *src, uint64_t n, unsigned long long *d_hist, hipStream_t s);
 // device, passes 2 + 3: the tokens' codes OR-ed into the zeroed stream d_out from bit `base_bits` on (table[s] = reversed
 // code | length << 16; dist_code likewise for the one distance code); *d_total = their bits.  Scratch:
 // huffman_chunks(n) u32 + as many u64.
 uint32_t huffman_chunks(uint64_t n);
-hipError_t launch_huffman_pack(const uint8_t *src, uint64_t n, const uint32_t *d_table, uint32_t dist_code, uint32_t *d_chunk_bits,
-                               uint64_t *d_chunk_off, uint64_t *d_total, uint64_t base_bits, uint32_t *d_out, hipStream_t s);
+hipError_t launch_huffman_pack(const uint8_t *src, uint64_t n, const uint32_t *d_table, uint32_t dist_code, uint32_t min_match,
+                               uint32_t *d_chunk_bits, uint64_t *d_chunk_off, uint64_t *d_total, uint64_t base_bits, uint32_t *d_out,
+                               hipStream_t s);
 
 }  // namespace hgi
