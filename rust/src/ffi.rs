@@ -29,6 +29,9 @@ extern "C" {
     pub fn hgi_decode_u8_dev(ctx: *mut HgiCtx, d_grid: *const c_void, width: u32, height: u32, levels: u32,
                              interp: c_int, d_img: *mut c_void, batch: usize, frame_stride: usize) -> c_int;
     pub fn hgi_sync(ctx: *mut HgiCtx) -> c_int;
+    /// include/hgi.h: raw DEFLATE of a grid's bincode image, entropy-coded on the device (grid in host memory)
+    pub fn hgi_deflate_grid(ctx: *mut HgiCtx, grid: *const u8, width: u32, height: u32, out: *mut u8, cap: usize,
+                            bytes: *mut usize) -> c_int;
     /// include/hgi.h: `batch` frames in host memory, pipelined through the device (uploads overlap downloads)
     pub fn hgi_encode_u8_batch(ctx: *mut HgiCtx, imgs: *const u8, width: u32, height: u32, levels: u32, interp: c_int,
                                lut: *const u8, grids_out: *mut u8, batch: usize, frame_stride: usize) -> c_int;

@@ -413,6 +413,29 @@ mod archive {
 
 pub use archive::{Archive, Metadata};
 
+impl Archive<Grid> {
+    /// `serialize_to_writer` with the DEFLATE stage on the device (`hgi_deflate_grid`, include/hgi.h): the same
+    /// container -- magic, bincode metadata, raw DEFLATE of the grid's bincode image -- whose stream is one
+    /// dynamic-Huffman block of literals and run matches written by the GPU instead of flate2 at `Compression::best()`
+    /// (src/archive.rs:34-40).  `deserialize_from_reader` reads it like any other archive.  No reference counterpart.
+    pub fn serialize_to_writer_device<W: Write>(&self, w: &mut W) -> Result<(), Box<Error>> {
+        use byteorder::{WriteBytesExt, LE};
+        w.write_u32::<LE>(0xBAAD_A555)?;
+        bincode::serialize_into(&mut *w, &self.metadata)?;
+        let (width, n) = (self.grid.width, self.grid.buffer.len());
+        let height = if width == 0 { 0 } else { n / width };
+        let mut out = vec![0u8; n + n / 8 + 1024];
+        let mut bytes = 0usize;
+        let ctx = thread_ctx()?;
+        status(unsafe {
+            ffi::hgi_deflate_grid(ctx.0, self.grid.buffer.as_ptr(), width as u32, height as u32, out.as_mut_ptr(), out.len(),
+                                  &mut bytes)
+        })?;
+        w.write_all(&out[..bytes])?;
+        Ok(())
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // Encoder / Decoder -- src/encoder.rs, src/decoder.rs
 // ---------------------------------------------------------------------------------------------------------------
