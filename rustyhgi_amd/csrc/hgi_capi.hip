@@ -844,6 +844,9 @@ hgi_status hgi_deflate_grid_dev(hgi_ctx *c, const void *d_grid, uint32_t w, uint
         }
         min_match = kMatchThresholdHost[pick];
         bits = huffman_plan(hists[pick], lens, codes, head, sizeof(head) - 64);
+        // the histograms say exactly how long the stream will be: never start packing into a buffer it would overrun
+        if (best / 8 + 64 > dev_cap) return fail(HGI_EDEVICE, "entropy stage: stream of %llu bytes exceeds its scratch", (unsigned long long)(best / 8));
+        if (best / 8 + 1 > cap) return fail(HGI_EINVAL, "output buffer too small: %llu bytes needed", (unsigned long long)(best / 8 + 1));
     }
     auto put = [&](std::vector<uint8_t> &v, size_t &at, uint32_t value, int nb) {
         for (int i = 0; i < nb; ++i, ++at) {

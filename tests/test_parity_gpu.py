@@ -845,3 +845,25 @@ def test_archive_with_device_entropy_interoperates(H, oracle, lena, tmp_path):
     pgm = (tmp_path / "dev.pgm").read_bytes()
     want = oracle.decode(grid.buffer.cpu().numpy().reshape(256, 256), 4)
     assert pgm[-65536:] == want.tobytes()
+
+
+def test_device_entropy_stage_refuses_a_short_output_buffer(H, oracle):
+    """The stream's exact length is known from the histograms before anything is packed: a caller buffer that cannot hold
+    it is refused with HGI_EINVAL and nothing is written beyond it (incompressible input: 8+ bits per byte)."""
+    import ctypes
+    import torch
+    from rustyhgi_amd import _ffi
+    L = _ffi.lib()
+    ctx = H.Context(0)
+    noise = oracle.synth(oracle.SYNTH_NOISE, SEED0 + 5, 0, 512, 512)
+    d = torch.from_numpy(noise).cuda()
+    out = np.full(512 * 512 // 2 + 64, 0xEE, np.uint8)
+    n = ctypes.c_size_t(0)
+    assert L.hgi_deflate_grid_dev(ctx.handle, d.data_ptr(), 512, 512, out.ctypes.data, 512 * 512 // 2, ctypes.byref(n)) == _ffi.EINVAL
+    assert b"too small" in L.hgi_last_error() and (out == 0xEE).all()
+    big = np.zeros(512 * 512 * 2, np.uint8)
+    assert L.hgi_deflate_grid_dev(ctx.handle, d.data_ptr(), 512, 512, big.ctypes.data, big.size, ctypes.byref(n)) == _ffi.OK
+    import struct
+    import zlib
+    assert zlib.decompressobj(-15).decompress(big[:n.value].tobytes()) == struct.pack("<Q", 512 * 512) + noise.tobytes() + struct.pack("<Q", 512)
+    ctx.close()
