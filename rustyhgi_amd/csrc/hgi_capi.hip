@@ -826,16 +826,7 @@ hgi_status hgi_deflate_grid_dev(hgi_ctx *c, const void *d_grid, uint32_t w, uint
                 ++hv[suffix[i]];
             }
             hv[256] = 1;      // end of block
-            uint8_t l[kDeflateSymbols], hd[640];
-            uint16_t cd[kDeflateSymbols];
-            uint64_t total = huffman_plan(hv, l, cd, hd, sizeof(hd) - 64);
-            if (!total) return fail(HGI_EDEVICE, "block header does not fit");
-            for (int sym = 0; sym < kDeflateSymbols; ++sym) total += hv[sym] * l[sym];
-            for (uint32_t len = 3; len <= 258; ++len) {      // extra bits of the length symbols, one distance bit per match
-                uint32_t sym, eb, ex;
-                deflate_length_symbol(len, &sym, &eb, &ex);
-                if (ex == 0) total += hv[sym] * (eb + 1);
-            }
+            const uint64_t total = huffman_payload_bits(hv);
             if (total < best) {
                 best = total;
                 pick = v;
@@ -844,6 +835,8 @@ hgi_status hgi_deflate_grid_dev(hgi_ctx *c, const void *d_grid, uint32_t w, uint
         }
         min_match = kMatchThresholdHost[pick];
         bits = huffman_plan(hists[pick], lens, codes, head, sizeof(head) - 64);
+        if (!bits) return fail(HGI_EDEVICE, "block header does not fit");
+        best += bits;
         // the histograms say exactly how long the stream will be: never start packing into a buffer it would overrun
         if (best / 8 + 64 > dev_cap) return fail(HGI_EDEVICE, "entropy stage: stream of %llu bytes exceeds its scratch", (unsigned long long)(best / 8));
         if (best / 8 + 1 > cap) return fail(HGI_EINVAL, "output buffer too small: %llu bytes needed", (unsigned long long)(best / 8 + 1));

@@ -38,47 +38,47 @@ typedef uint64_t u64;
 // order of frequency.  Symbols of frequency 0 get length 0; a single used symbol gets length 1.
 void code_lengths(const u64 *freq, int n, int maxlen, u8 *len)
 {
-    std::vector<int> used;
+    constexpr int kMax = kDeflateSymbols;      // n <= kMax: everything on the stack (this runs per frame, per candidate)
+    int used[kMax], m = 0;
     for (int i = 0; i < n; ++i) {
         len[i] = 0;
-        if (freq[i]) used.push_back(i);
+        if (freq[i]) used[m++] = i;
     }
-    const int m = (int)used.size();
     if (m == 0) return;
     if (m == 1) {
         len[used[0]] = 1;
         return;
     }
-    std::sort(used.begin(), used.end(), [&](int a, int b) { return freq[a] != freq[b] ? freq[a] < freq[b] : a < b; });
+    std::sort(used, used + m, [&](int a, int b) { return freq[a] != freq[b] ? freq[a] < freq[b] : a < b; });
     // nodes 0..m-1: leaves in ascending frequency; m..2m-2: internal nodes in order of creation (also ascending)
-    std::vector<u64> w(2 * (size_t)m - 1);
-    std::vector<int> parent(2 * (size_t)m - 1, -1);
-    for (int i = 0; i < m; ++i) w[(size_t)i] = freq[used[(size_t)i]];
+    u64 w[2 * kMax];
+    int parent[2 * kMax], depth[2 * kMax];
+    for (int i = 0; i < m; ++i) w[i] = freq[used[i]];
     int leaf = 0, inner = m, next = m;
     auto take = [&]() {
-        if (leaf < m && (inner >= next || w[(size_t)leaf] <= w[(size_t)inner])) return leaf++;
+        if (leaf < m && (inner >= next || w[leaf] <= w[inner])) return leaf++;
         return inner++;
     };
     for (; next < 2 * m - 1; ++next) {
         const int a = take(), b = take();
-        w[(size_t)next] = w[(size_t)a] + w[(size_t)b];
-        parent[(size_t)a] = parent[(size_t)b] = next;
+        w[next] = w[a] + w[b];
+        parent[a] = parent[b] = next;
     }
-    std::vector<int> depth(2 * (size_t)m - 1, 0);
-    for (int i = 2 * m - 3; i >= 0; --i) depth[(size_t)i] = depth[(size_t)parent[(size_t)i]] + 1;
+    depth[2 * m - 2] = 0;
+    for (int i = 2 * m - 3; i >= 0; --i) depth[i] = depth[parent[i]] + 1;
     // how many codes of each length; fold what is too long into maxlen and repair the Kraft sum
-    std::vector<int> count((size_t)std::max(maxlen, m) + 2, 0);
-    for (int i = 0; i < m; ++i) ++count[(size_t)std::min(depth[(size_t)i], maxlen)];
+    int count[17] = {0};
+    for (int i = 0; i < m; ++i) ++count[std::min(depth[i], maxlen)];
     u64 kraft = 0;                                       // in units of 2^-maxlen
-    for (int l = 1; l <= maxlen; ++l) kraft += (u64)count[(size_t)l] << (maxlen - l);
+    for (int l = 1; l <= maxlen; ++l) kraft += (u64)count[l] << (maxlen - l);
     while (kraft > ((u64)1 << maxlen)) {
         // take one code of the longest length away with one of the next shorter length that exists: the shorter one
         // becomes two codes one bit longer, and one code of length maxlen disappears into that pair
-        --count[(size_t)maxlen];
+        --count[maxlen];
         for (int l = maxlen - 1; l > 0; --l)
-            if (count[(size_t)l]) {
-                --count[(size_t)l];
-                count[(size_t)l + 1] += 2;
+            if (count[l]) {
+                --count[l];
+                count[l + 1] += 2;
                 break;
             }
         --kraft;
@@ -86,20 +86,20 @@ void code_lengths(const u64 *freq, int n, int maxlen, u8 *len)
     // longest codes to the rarest symbols
     int at = 0;
     for (int l = maxlen; l >= 1; --l)
-        for (int k = 0; k < count[(size_t)l]; ++k) len[used[(size_t)at++]] = (u8)l;
+        for (int k = 0; k < count[l]; ++k) len[used[at++]] = (u8)l;
 }
 
 // canonical codes (RFC 1951 3.2.2), returned bit-reversed: DEFLATE packs codes starting from their most significant
 // bit into a stream that fills bytes from the least significant bit, so a reversed code can simply be OR-ed in
 void canonical_codes(const u8 *len, int n, int maxlen, uint16_t *code)
 {
-    std::vector<u32> count((size_t)maxlen + 1, 0), next((size_t)maxlen + 2, 0);
+    u32 count[17] = {0}, next[18] = {0};
     for (int i = 0; i < n; ++i) ++count[len[i]];
     count[0] = 0;
     u32 c = 0;
     for (int l = 1; l <= maxlen; ++l) {
-        c = (c + count[(size_t)l - 1]) << 1;
-        next[(size_t)l] = c;
+        c = (c + count[l - 1]) << 1;
+        next[l] = c;
     }
     for (int i = 0; i < n; ++i) {
         code[i] = 0;
@@ -111,14 +111,15 @@ void canonical_codes(const u8 *len, int n, int maxlen, uint16_t *code)
 }
 
 struct BitWriter {
-    std::vector<u8> bytes;
+    u8 bytes[640];
     size_t bits = 0;
-    void put(u32 value, int n)      // n <= 24 bits, least significant first
+    BitWriter() { std::memset(bytes, 0, sizeof(bytes)); }
+    void put(u32 value, int n)      // n <= 16 bits, least significant first
     {
-        for (int i = 0; i < n; ++i, ++bits) {
-            if ((bits & 7) == 0) bytes.push_back(0);
-            bytes.back() |= (u8)(((value >> i) & 1u) << (bits & 7));
-        }
+        if (bits + (size_t)n > 8 * sizeof(bytes) - 32) return;      // (a header is < 300 bytes)
+        u32 v = (value & ((1u << n) - 1u)) << (bits & 7);
+        for (size_t at = bits >> 3; v; ++at, v >>= 8) bytes[at] |= (u8)v;
+        bits += (size_t)n;
     }
 };
 
@@ -134,6 +135,20 @@ void deflate_length_symbol(uint32_t length, uint32_t *symbol, uint32_t *extra_bi
     *symbol = 257u + (u32)s;
     *extra_bits = bits[s];
     *extra = length - base[s];
+}
+
+// The bits the tokens themselves take under the best code for `hist` (codes + length extra bits + one distance bit per
+// match; without the block header, which varies by a few dozen bits between candidates): what the choice of the match
+// threshold is made on.
+uint64_t huffman_payload_bits(const uint64_t hist[kDeflateSymbols])
+{
+    u8 lens[kDeflateSymbols];
+    code_lengths(hist, kDeflateSymbols, 15, lens);
+    static const u8 extra[29] = {0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4, 4, 5, 5, 5, 5, 0};
+    u64 total = 0;
+    for (int s = 0; s < kDeflateSymbols; ++s) total += hist[s] * lens[s];
+    for (int s = 257; s < kDeflateSymbols; ++s) total += hist[s] * (extra[s - 257] + 1u);
+    return total;
 }
 
 // Code for the 286 literal / end-of-block / length symbols from their frequencies (hist[256] = end of block, normally
@@ -155,24 +170,25 @@ size_t huffman_plan(const uint64_t hist[kDeflateSymbols], uint8_t lens[kDeflateS
         u8 sym, extra_bits;
         uint16_t extra;
     };
-    std::vector<Item> items;
+    Item items[kSeq];
+    int nitems = 0;
     for (int i = 0; i < kSeq;) {
         int run = 1;
         while (i + run < kSeq && seq[i + run] == seq[i]) ++run;
         if (seq[i] == 0 && run >= 3) {
             const int r = std::min(run, 138);
             if (r <= 10)
-                items.push_back({17, 3, (uint16_t)(r - 3)});
+                items[nitems++] = {17, 3, (uint16_t)(r - 3)};
             else
-                items.push_back({18, 7, (uint16_t)(r - 11)});
+                items[nitems++] = {18, 7, (uint16_t)(r - 11)};
             i += r;
         } else {
-            items.push_back({seq[i], 0, 0});
+            items[nitems++] = {seq[i], 0, 0};
             ++i;
         }
     }
     u64 clfreq[19] = {0};
-    for (const Item &it : items) ++clfreq[it.sym];
+    for (int k = 0; k < nitems; ++k) ++clfreq[items[k].sym];
     u8 cllen[19];
     uint16_t clcode[19];
     code_lengths(clfreq, 19, 7, cllen);
@@ -187,12 +203,14 @@ size_t huffman_plan(const uint64_t hist[kDeflateSymbols], uint8_t lens[kDeflateS
     bw.put(2 - 1, 5);                           // HDIST
     bw.put((u32)(hclen - 4), 4);                // HCLEN
     for (int i = 0; i < hclen; ++i) bw.put(cllen[order[i]], 3);
-    for (const Item &it : items) {
+    for (int k = 0; k < nitems; ++k) {
+        const Item &it = items[k];
         bw.put(clcode[it.sym], cllen[it.sym]);
         if (it.extra_bits) bw.put(it.extra, it.extra_bits);
     }
-    if (bw.bytes.size() > header_cap) return 0;
-    std::memcpy(header, bw.bytes.data(), bw.bytes.size());
+    const size_t nbytes = (bw.bits + 7) / 8;
+    if (nbytes > header_cap) return 0;
+    std::memcpy(header, bw.bytes, nbytes);
     return bw.bits;
 }
 

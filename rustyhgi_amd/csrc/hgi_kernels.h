@@ -89,6 +89,7 @@ constexpr uint32_t kMatchThresholdHost[kMatchThresholds] = {3, 4, 6, 10};
 size_t huffman_plan(const uint64_t hist[kDeflateSymbols], uint8_t lens[kDeflateSymbols], uint16_t codes[kDeflateSymbols],
                     uint8_t *header, size_t header_cap);
 void deflate_length_symbol(uint32_t length, uint32_t *symbol, uint32_t *extra_bits, uint32_t *extra);
+uint64_t huffman_payload_bits(const uint64_t hist[kDeflateSymbols]);      // token bits under the best code, header excluded
 // device, pass 1: d_hist[kMatchThresholds][kDeflateSymbols] = how often the tokens of src[0..n) use each symbol (runs ->
 // distance-1 matches, cut at 1 KiB chunk boundaries), for each candidate match threshold
 hipError_t launch_token_histogram(const uint8_t *src, uint64_t n, unsigned long long *d_hist, hipStream_t s);
