@@ -95,8 +95,11 @@ def traffic_json(out, frames, size, levels):
         acc = defaultdict(list)
         for path in glob.glob(os.path.join(out, name, "**", "*counter_collection.csv"), recursive=True):
             for row in csv.DictReader(open(path)):
+                name = short(row["Kernel_Name"])
+                if name.startswith("k_dec_tiles<0,"):      # the placement probe (LeftTop decode on scratch), not the workload
+                    continue
                 if row["Counter_Name"] == ctr:
-                    acc[short(row["Kernel_Name"]).split("<")[0]].append(float(row["Counter_Value"]))
+                    acc[name.split("<")[0]].append(float(row["Counter_Value"]))
         for k, v in acc.items():
             per[k][ctr] = sum(v) / len(v)
     kernels = {}
