@@ -107,8 +107,9 @@ def parse_args(argv=None):
                          "(profiling passes: every k_*_tiles launch in the trace is then a launch of the headline workload)")
     ap.add_argument("--xgmi-scatter", action="store_true",
                     help="also time the labelled variant where all frames start and end on GPU 0 (scatter, code, gather)")
-    ap.add_argument("--placement", choices=("planes", "torch"), default="planes",
-                    help="frame stacks from hgi_planes_alloc (neighbouring planes in different HBM regions) or from torch")
+    ap.add_argument("--placement", choices=("planes", "torch", "same-region"), default="planes",
+                    help="frame stacks from hgi_planes_alloc (neighbouring planes in different HBM regions), from torch, or -- "
+                         "for the counter comparison of DESIGN.md 5.1 -- deliberately all three in ONE region (planes 0, 2, 4 of five)")
     ap.add_argument("--share-gpu", action="store_true",
                     help="every rank uses cuda:0 and the collectives go over gloo (RCCL refuses two ranks on one device): "
                          "the whole N-rank path with the real codec on a ONE-GPU box; `value` then says nothing about scaling")
@@ -356,6 +357,18 @@ class Codec:
             for p in held:
                 p.close()
             self.imgs, self.grids, self.outs = (self.planes.torch(i, (F, S, S)) for i in range(3))
+        elif args.placement == "same-region":
+            # three planes of seven whose two pairings (image -> grid, grid -> image) both probe SLOW: one region
+            self.planes = H.Planes(ctx, F * S * S, 7)
+            for _ in range(12):
+                self.planes.probe_ms(0, 1)                  # clocks
+            t = {(a, b): self.planes.probe_ms(a, b) for a in range(7) for b in range(7) if a != b}
+            mid = (min(t.values()) + max(t.values())) / 2
+            pick = next(((a, b, c) for a in range(7) for b in range(7) for c in range(7)
+                         if len({a, b, c}) == 3 and t[(a, b)] > mid and t[(b, c)] > mid), (0, 2, 4))
+            print("bench.py: same-region planes %s: probes %.4f / %.4f ms (fastest pairing %.4f)"
+                  % (pick, t[(pick[0], pick[1])], t[(pick[1], pick[2])], min(t.values())), file=sys.stderr)
+            self.imgs, self.grids, self.outs = (self.planes.torch(i, (F, S, S)) for i in pick)
         else:
             self.imgs = torch.empty((F, S, S), dtype=torch.uint8, device=dev)
             self.grids = torch.empty_like(self.imgs)
@@ -513,7 +526,7 @@ class Codec:
         torch, F, S = self.torch, self.F, self.S
         info = {"mode": self.args.placement}
         if self.planes is not None:
-            info.update({"api": "hgi_planes_alloc(bytes, 3): neighbouring planes in different HBM regions (DESIGN.md 5.1)",
+            info.update({"api": "hgi_planes_alloc(bytes, %d): neighbouring planes in different HBM regions (DESIGN.md 5.1)" % self.planes.count,
                          "separated": self.planes.separated})
         if not compare:
             return info
