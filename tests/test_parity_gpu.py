@@ -867,3 +867,25 @@ def test_device_entropy_stage_refuses_a_short_output_buffer(H, oracle):
     import zlib
     assert zlib.decompressobj(-15).decompress(big[:n.value].tobytes()) == struct.pack("<Q", 512 * 512) + noise.tobytes() + struct.pack("<Q", 512)
     ctx.close()
+
+
+def test_criterion_harness_port_prints_all_eight_cases(tmp_path):
+    """benches/bench.cpp -- the C++ port of the reference's criterion harness (benches/bench.rs:38-151) -- builds against
+    the library and runs its eight cases (memory, four encode variants, decode, serialization, compression), the device
+    forms beside the host ones, with the lossless round trip and the device-entropy archive read back exactly."""
+    import os
+    import shutil
+    import subprocess
+    from conftest import ROOT
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    exe = str(tmp_path / "bench_cpp")
+    subprocess.check_call([hipcc, "--offload-arch=gfx950", "-O2", "-std=c++17", "-w", "-I", os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "benches", "bench.cpp"), "-L", os.path.join(ROOT, "rustyhgi_amd"), "-lhgi_hip", "-lz",
+                           "-Wl,-rpath," + os.path.join(ROOT, "rustyhgi_amd"), "-o", exe])
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    for case in ("memory", "left_top_nop_encode", "left_top_quanted_encode", "crossed_nop_encode", "crossed_quanted_encode",
+                 "decode", "serialization", "compression"):
+        assert any(line.startswith(case + " ") for line in out.stdout.splitlines()), (case, out.stdout)
+    assert "lossless round trip exact: yes" in out.stdout
+    assert "device-entropy archive reads back exactly: yes" in out.stdout
