@@ -224,6 +224,11 @@ def run_rank(args):
     # care).  W = 5 warm-up steps are 4 ms.  So the device is first kept busy with untimed steps of the same workload
     # until the step time has stopped falling (bounded; reported as config.settle): the timed steps then measure the
     # steady state a batch job runs in, not the power manager's ramp.
+    # Ranks finish their setup (placement probing, allocations) at different times: absorb that skew at a barrier HERE, so
+    # that the barrier in front of the timed region finds every rank busy and is short -- a rank left idling there would
+    # start the timed steps with its clocks down again.
+    if dist is not None:
+        fence()
     settle = codec.settle() if codec else None
     for _ in range(args.warmup):
         if codec:
