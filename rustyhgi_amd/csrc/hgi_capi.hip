@@ -762,7 +762,7 @@ hgi_status hgi_huffman_plan(const uint64_t hist[286], uint8_t lens[286], uint16_
 
 static size_t deflate_scratch_bytes(uint64_t n)
 {
-    return kMatchThresholds * kDeflateSymbols * 8 + kDeflateSymbols * 4 + (size_t)huffman_chunks(n) * 12 + 8 +
+    return (kMatchThresholds + 1) * kDeflateSymbols * 8 + kDeflateSymbols * 4 + (size_t)huffman_chunks(n) * 12 + 8 +
            align_up((size_t)(n + n / 4) + 4096, 256) + 10 * 256;
 }
 
@@ -797,18 +797,20 @@ hgi_status hgi_deflate_grid_dev(hgi_ctx *c, const void *d_grid, uint32_t w, uint
     const size_t need = deflate_scratch_bytes(n);
     HGI_TRY(ws_ensure(c, need));
     c->ws_used = 0;
-    unsigned long long *d_hist = reinterpret_cast<unsigned long long *>(ws_take(c, kMatchThresholds * kDeflateSymbols * 8));
+    unsigned long long *d_hist = reinterpret_cast<unsigned long long *>(ws_take(c, (kMatchThresholds + 1) * kDeflateSymbols * 8));
     uint32_t *d_table = reinterpret_cast<uint32_t *>(ws_take(c, kDeflateSymbols * 4));
     uint64_t *d_off = reinterpret_cast<uint64_t *>(ws_take(c, (size_t)nchunks * 8 + 8));
     uint32_t *d_cbits = reinterpret_cast<uint32_t *>(ws_take(c, (size_t)nchunks * 4 + 8));
     uint64_t *d_total = reinterpret_cast<uint64_t *>(ws_take(c, 8));
     uint32_t *d_out = reinterpret_cast<uint32_t *>(ws_take(c, dev_cap));
     if (!d_hist || !d_table || !d_off || !d_cbits || !d_total || !d_out) return fail(HGI_ENOMEM, "scratch exhausted (entropy stage)");
-    uint64_t hists[kMatchThresholds][kDeflateSymbols] = {{0}};
+    uint64_t hists[kMatchThresholds + 1][kDeflateSymbols] = {{0}};      // [kMatchThresholds]: the part common to all candidates
     if (n) {
         HIP_TRY(launch_token_histogram(static_cast<const uint8_t *>(d_grid), n, d_hist, c->stream));
         HIP_TRY(hipMemcpyAsync(hists, d_hist, sizeof(hists), hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(hipStreamSynchronize(c->stream));
+        for (int v = 0; v < kMatchThresholds; ++v)
+            for (int sym = 0; sym < kDeflateSymbols; ++sym) hists[v][sym] += hists[kMatchThresholds][sym];
     }
     // for each candidate threshold: the code its histogram asks for and the exact size of the stream it gives; keep the
     // smallest (the 16 bytes around the grid are literals under every threshold)

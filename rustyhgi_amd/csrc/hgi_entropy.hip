@@ -355,34 +355,50 @@ __device__ __forceinline__ void length_symbol(u32 length, u32 &symbol, u32 &extr
 
 // pass 1: histograms of the literal / length symbols the tokens use, for each candidate match threshold at once (a short
 // run of a byte whose literal costs one bit is cheaper as literals than as a match; which threshold pays is decided on
-// the host from the exact stream sizes the histograms imply)
+// the host from the exact stream sizes the histograms imply).  A byte's token is the same under every candidate unless
+// it lies in a run piece of kMatchThreshold[0] .. kMatchThreshold[last] - 1 bytes: those go to a per-candidate histogram,
+// everything else to ONE common histogram (slot kMatchThresholds) that the host adds to each.
 __global__ __launch_bounds__(kPackThreads) void k_token_hist(const u8 *__restrict__ src, u64 n, unsigned long long *__restrict__ hist)
 {
-    constexpr int kCopies = 4;
+    constexpr int kCopies = 4, kHists = kMatchThresholds + 1;
     __shared__ u32 scan[16];
-    __shared__ u32 h[kMatchThresholds][kDeflateSymbols * kCopies];      // copies value-major (a handful of symbols dominate)
-    for (int i = threadIdx.x; i < kMatchThresholds * kDeflateSymbols * kCopies; i += kPackThreads) (&h[0][0])[i] = 0;
+    __shared__ u32 h[kHists][kDeflateSymbols * kCopies];      // copies value-major (a handful of symbols dominate)
+    for (int i = threadIdx.x; i < kHists * kDeflateSymbols * kCopies; i += kPackThreads) (&h[0][0])[i] = 0;
     __syncthreads();
     const u32 copy = threadIdx.x & (kCopies - 1);
+    auto add = [&](int which, u32 s) {
+        u32 sym = s;
+        if (s & 0x80000000u) {
+            u32 eb, ex;
+            length_symbol(s & 0xFFFFu, sym, eb, ex);
+        }
+        atomicAdd(&h[which][sym * kCopies + copy], 1u);
+    };
     for (u64 chunk = blockIdx.x; chunk * kChunk < n; chunk += gridDim.x) {
         const Tokens tk = tokens_of_thread(src, n, chunk * kChunk, scan);
 #pragma unroll
-        for (int v = 0; v < kMatchThresholds; ++v) {
+        for (int i = 0; i < 4; ++i) {
+            const bool valid = tk.lit[i] != kNone;
+            const bool common = tk.piece[i] < kMatchThreshold[0] || tk.piece[i] >= kMatchThreshold[kMatchThresholds - 1];
+            const u32 s = token_symbol(tk, i, kMatchThreshold[0]);       // what every candidate emits when `common`
+            // literal zeros are most of a residual grid: count them per wave with a ballot, one add per wave
+            const unsigned long long zeros = __ballot(valid && common && s == 0u);
+            if (zeros && (threadIdx.x & 63u) == (u32)__ffsll((long long)zeros) - 1u)
+                atomicAdd(&h[kMatchThresholds][0 * kCopies + copy], (u32)__popcll(zeros));
+            if (!valid) continue;
+            if (common) {
+                if (s != kNone && s != 0u) add(kMatchThresholds, s);
+                continue;
+            }
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const u32 s = token_symbol(tk, i, kMatchThreshold[v]);
-                if (s == kNone) continue;
-                u32 sym = s;
-                if (s & 0x80000000u) {
-                    u32 eb, ex;
-                    length_symbol(s & 0xFFFFu, sym, eb, ex);
-                }
-                atomicAdd(&h[v][sym * kCopies + copy], 1u);
+            for (int v = 0; v < kMatchThresholds; ++v) {
+                const u32 sv = token_symbol(tk, i, kMatchThreshold[v]);
+                if (sv != kNone) add(v, sv);
             }
         }
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < kMatchThresholds * kDeflateSymbols; i += kPackThreads) {
+    for (int i = threadIdx.x; i < kHists * kDeflateSymbols; i += kPackThreads) {
         const int v = i / kDeflateSymbols, sym = i - v * kDeflateSymbols;
         u32 sum = 0;
 #pragma unroll
@@ -437,41 +453,61 @@ __global__ __launch_bounds__(kPackThreads) void k_token_count(const u8 *__restri
     if (threadIdx.x == 0) chunk_bits[blockIdx.x] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
 }
 
-// exclusive scan of the chunk sizes into bit offsets; one workgroup
+// exclusive scan of the chunk sizes into bit offsets; one workgroup walks the chunks 1024 at a time (coalesced reads and
+// writes; shuffle scan inside each wave, the sixteen wave totals through LDS, a running total carried between blocks)
 __global__ __launch_bounds__(1024) void k_huff_scan(const u32 *__restrict__ chunk_bits, u64 *__restrict__ chunk_off, u32 nchunks,
                                                     u64 *__restrict__ total)
 {
-    __shared__ u64 part[1024];
-    const u32 per = (nchunks + 1023u) / 1024u, lo = threadIdx.x * per < nchunks ? threadIdx.x * per : nchunks,
-              hi = lo + per < nchunks ? lo + per : nchunks;
-    u64 sum = 0;
-    for (u32 i = lo; i < hi; ++i) sum += chunk_bits[i];
-    part[threadIdx.x] = sum;
-    __syncthreads();
-    for (u32 o = 1; o < 1024; o <<= 1) {      // Hillis-Steele inclusive scan
-        const u64 add = threadIdx.x >= o ? part[threadIdx.x - o] : 0;
-        __syncthreads();
-        part[threadIdx.x] += add;
-        __syncthreads();
+    __shared__ u64 wtot[16];
+    const u32 lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    u64 carry = 0;                      // every thread keeps its own copy of the running total
+    constexpr u32 kAhead = 8;           // blocks of 1024 whose loads are issued together (the loop is a latency chain otherwise)
+    for (u32 super = 0; super < nchunks; super += kAhead * 1024) {
+        u32 mine[kAhead];
+#pragma unroll
+        for (u32 k = 0; k < kAhead; ++k) {
+            const u32 i = super + k * 1024 + threadIdx.x;
+            mine[k] = i < nchunks ? chunk_bits[i] : 0;
+        }
+#pragma unroll
+        for (u32 k = 0; k < kAhead; ++k) {
+            const u32 i = super + k * 1024 + threadIdx.x;
+            u64 incl = mine[k];
+            for (int o = 1; o < 64; o <<= 1) {
+                const u64 up = __shfl_up(incl, o, 64);
+                if ((int)lane >= o) incl += up;
+            }
+            if (lane == 63) wtot[wave] = incl;
+            __syncthreads();
+            u64 before = 0, all = 0;
+            for (u32 wv = 0; wv < 16; ++wv) {
+                const u64 t = wtot[wv];
+                before += wv < wave ? t : 0;
+                all += t;
+            }
+            if (i < nchunks) chunk_off[i] = carry + before + incl - mine[k];
+            carry += all;
+            __syncthreads();            // wtot is rewritten by the next block
+        }
     }
-    u64 run = threadIdx.x ? part[threadIdx.x - 1] : 0;
-    for (u32 i = lo; i < hi; ++i) {
-        chunk_off[i] = run;
-        run += chunk_bits[i];
-    }
-    if (threadIdx.x == 1023) *total = part[1023];
+    if (threadIdx.x == 0) *total = carry;
 }
 
-// pass 3: every thread ORs its tokens into the (zeroed) stream at its bit position
+// pass 3: the chunk's tokens are OR-ed into an LDS image of the chunk's part of the stream (<= 1024 x 21 bits), which then
+// goes out as whole words -- plain coalesced stores for the words the chunk owns alone, atomicOr only for its first and
+// last word, which it shares with its neighbours (the stream was zeroed)
 __global__ __launch_bounds__(kPackThreads) void k_token_pack(const u8 *__restrict__ src, u64 n, const u32 *__restrict__ table, u32 dist,
                                                              u32 min_match, const u64 *__restrict__ chunk_off, u64 base_bits,
                                                              u32 *__restrict__ out)
 {
+    constexpr int kWords = (kChunk * 21 + 31) / 32 + 3;      // worst case: every byte a 15-bit literal; matches are rarer
     __shared__ u32 stab[kDeflateSymbols];
     __shared__ u32 scan[16];
     __shared__ u32 wsum[kPackThreads / 64];
+    __shared__ u32 img[kWords];
     for (int i = threadIdx.x; i < kDeflateSymbols; i += kPackThreads) stab[i] = table[i];
-    const Tokens tk = tokens_of_thread(src, n, (u64)blockIdx.x * kChunk, scan);
+    for (int i = threadIdx.x; i < kWords; i += kPackThreads) img[i] = 0;
+    const Tokens tk = tokens_of_thread(src, n, (u64)blockIdx.x * kChunk, scan);      // (its barriers publish stab and img)
     unsigned __int128 val;
     u32 bits;
     pack_tokens(tk, min_match, stab, dist, val, bits);
@@ -486,16 +522,31 @@ __global__ __launch_bounds__(kPackThreads) void k_token_pack(const u8 *__restric
     __syncthreads();
     u32 before = incl - bits;
     for (u32 wv = 0; wv < wave; ++wv) before += wsum[wv];
-    if (!bits) return;
-    const u64 pos = base_bits + chunk_off[blockIdx.x] + before;
-    const u32 sh = (u32)(pos & 31u);
-    u32 *dst = out + (pos >> 5);
-    const unsigned __int128 shifted = val << sh;          // <= 66 + 31 bits
-    const u32 o0 = (u32)shifted, o1 = (u32)(shifted >> 32), o2 = (u32)(shifted >> 64), o3 = (u32)(shifted >> 96);
-    if (o0) atomicOr(dst, o0);
-    if (o1) atomicOr(dst + 1, o1);
-    if (o2) atomicOr(dst + 2, o2);
-    if (o3) atomicOr(dst + 3, o3);
+    const u32 chunk_total = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+    const u64 pos0 = base_bits + chunk_off[blockIdx.x];      // the chunk's first bit in the stream
+    const u32 sh0 = (u32)(pos0 & 31u);                       // ... and where that is inside its first word
+    if (bits) {
+        const u32 at = sh0 + before, sh = at & 31u;
+        const unsigned __int128 shifted = val << sh;          // <= 66 + 31 bits
+        const u32 o0 = (u32)shifted, o1 = (u32)(shifted >> 32), o2 = (u32)(shifted >> 64), o3 = (u32)(shifted >> 96);
+        u32 *dst = img + (at >> 5);
+        if (o0) atomicOr(dst, o0);
+        if (o1) atomicOr(dst + 1, o1);
+        if (o2) atomicOr(dst + 2, o2);
+        if (o3) atomicOr(dst + 3, o3);
+    }
+    __syncthreads();
+    if (!chunk_total) return;
+    const u32 nwords = (sh0 + chunk_total + 31u) >> 5;
+    u32 *dst = out + (pos0 >> 5);
+    for (u32 w = threadIdx.x; w < nwords; w += kPackThreads) {
+        const u32 v = img[w];
+        if (w == 0 || w == nwords - 1) {
+            if (v) atomicOr(dst + w, v);
+        } else {
+            dst[w] = v;
+        }
+    }
 }
 
 }  // namespace
@@ -504,7 +555,7 @@ u32 huffman_chunks(u64 n) { return (u32)((n + kChunk - 1) / kChunk); }
 
 hipError_t launch_token_histogram(const uint8_t *src, uint64_t n, unsigned long long *d_hist, hipStream_t s)
 {
-    hipError_t e = hipMemsetAsync(d_hist, 0, kMatchThresholds * kDeflateSymbols * sizeof(unsigned long long), s);
+    hipError_t e = hipMemsetAsync(d_hist, 0, (kMatchThresholds + 1) * kDeflateSymbols * sizeof(unsigned long long), s);
     if (e != hipSuccess || n == 0) return e;
     u32 blocks = huffman_chunks(n);
     if (blocks > 4096) blocks = 4096;

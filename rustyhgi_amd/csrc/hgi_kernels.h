@@ -90,8 +90,9 @@ size_t huffman_plan(const uint64_t hist[kDeflateSymbols], uint8_t lens[kDeflateS
                     uint8_t *header, size_t header_cap);
 void deflate_length_symbol(uint32_t length, uint32_t *symbol, uint32_t *extra_bits, uint32_t *extra);
 uint64_t huffman_payload_bits(const uint64_t hist[kDeflateSymbols]);      // token bits under the best code, header excluded
-// device, pass 1: d_hist[kMatchThresholds][kDeflateSymbols] = how often the tokens of src[0..n) use each symbol (runs ->
-// distance-1 matches, cut at 1 KiB chunk boundaries), for each candidate match threshold
+// device, pass 1: d_hist[kMatchThresholds + 1][kDeflateSymbols] = how often the tokens of src[0..n) use each symbol (runs ->
+// distance-1 matches, cut at 1 KiB chunk boundaries): slot v < kMatchThresholds counts the tokens that depend on the
+// candidate threshold v, slot kMatchThresholds those that do not -- the histogram of candidate v is the sum of the two
 hipError_t launch_token_histogram(const uint8_t *src, uint64_t n, unsigned long long *d_hist, hipStream_t s);
 // device, passes 2 + 3: the tokens' codes OR-ed into the zeroed stream d_out from bit `base_bits` on (table[s] = reversed
 // code | length << 16; dist_code likewise for the one distance code); *d_total = their bits.  Scratch:

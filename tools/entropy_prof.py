@@ -1,0 +1,11 @@
+import os, sys, numpy as np, torch
+sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
+import rustyhgi_amd as H
+from rustyhgi_amd import entropy
+from oracle import hgi_oracle as O
+img = O.synth(O.SYNTH_RAMP, 0x48474933, 0, 4096, 4096)
+grid = O.encode(img, 4, O.linear_lut(2)[0])
+d = torch.from_numpy(grid).cuda()
+for _ in range(6):
+    s = entropy.deflate_grid(d)
+torch.cuda.synchronize()
