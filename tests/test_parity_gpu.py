@@ -757,8 +757,7 @@ def test_banded_bands_never_read_rows_of_the_next_upload():
 
 def test_planes_alloc_places_neighbours_in_different_regions(H, oracle):
     """hgi_planes_alloc (include/hgi.h): planes are ordinary device buffers -- the codec is bit-exact on them through
-    torch views -- and, when the probe could tell, a launch between neighbouring planes is faster than one between
-    planes two apart (which share a region in a chain of three)."""
+    torch views -- and, when the probe could tell, launches between neighbouring planes run at the fast rate."""
     import torch
     ctx = H.Context(0)
     ctx.set_stream(torch.cuda.current_stream().cuda_stream)
@@ -783,9 +782,12 @@ def test_planes_alloc_places_neighbours_in_different_regions(H, oracle):
         assert_same(grid[f].cpu().numpy(), want, "encode on placed planes, frame %d" % f)
         assert_same(out[f].cpu().numpy(), oracle.decode(want, 4), "decode on placed planes, frame %d" % f)
     if planes.separated:
-        near = min(planes.probe_ms(0, 1), planes.probe_ms(1, 2))
-        far = planes.probe_ms(0, 2)
-        assert near < far, (near, far)
+        # both neighbouring pairings stream at the fast rate (planes 0 and 2 may share a region -- then 0 -> 2 is the slow
+        # one, 4-5 % behind -- or lie in three different regions, then all three are fast)
+        for _ in range(10):
+            planes.probe_ms(0, 1)                  # clocks
+        p01, p12, p02 = planes.probe_ms(0, 1), planes.probe_ms(1, 2), planes.probe_ms(0, 2)
+        assert max(p01, p12) <= 1.03 * min(p01, p12, p02), (p01, p12, p02)
     del img, grid, out
     planes.close()
     ctx.close()
