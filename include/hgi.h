@@ -173,10 +173,13 @@ hgi_status hgi_huffman_plan(const uint64_t hist[286], uint8_t lens[286], uint16_
 /* hgi_planes_alloc returns `count` device buffers of `bytes` each (hipMalloc; release with   */
 /* hgi_planes_free or hipFree) such that planes[i] and planes[i+1] lie in different regions:  */
 /* image -> grid -> image chains alternate through the array.  Best effort, found by timing   */
-/* the decode kernel between candidates (a few ms per plane, transient extra allocations):    */
+/* a decode launch between candidate buffers against a same-region yardstick (typically       */
+/* 30-50 ms in all; when the device's free memory is one huge block, transient allocations of */
+/* up to ~60x `bytes` and several seconds -- set HGI_NO_PLACEMENT=1 to skip the search):      */
 /* *separated (optional) is 1 when every neighbouring pair was seen to be in different        */
 /* regions, 0 when that could not be established (planes below 512 MiB are not probed: such   */
-/* streams live in the Infinity Cache) -- the planes are valid either way.                    */
+/* streams live in the Infinity Cache) -- the planes are valid either way.  Call it while the */
+/* device is otherwise idle: it measures.                                                      */
 hgi_status hgi_planes_alloc(hgi_ctx *ctx, size_t bytes, uint32_t count, void **planes, int *separated);
 hgi_status hgi_planes_free(hgi_ctx *ctx, uint32_t count, void **planes);
 /* The probe itself: mean milliseconds of one decode launch streaming d_src -> d_dst over      */
