@@ -157,6 +157,12 @@ hgi_status hgi_diff_stats_dev(hgi_ctx *ctx, const void *d_before, const void *d_
 /* (w*h + w*h/8 + 1024 always suffices).  Synchronous on the ctx stream.                        */
 hgi_status hgi_deflate_grid_dev(hgi_ctx *ctx, const void *d_grid, uint32_t width, uint32_t height,
                                 uint8_t *out, size_t cap, size_t *bytes);
+/* `batch` grids `frame_stride` bytes apart in device memory: stream f is written to            */
+/* out + f * out_stride (host memory; out_stride is also each stream's capacity), sizes[f] = its */
+/* length.  The phases run group-wise, so the host waits three times per group of frames (up  */
+/* to 1 GiB of stream buffers at once), not three times per frame.                             */
+hgi_status hgi_deflate_grids_dev(hgi_ctx *ctx, const void *d_grids, uint32_t width, uint32_t height, size_t batch,
+                                 size_t frame_stride, uint8_t *out, size_t out_stride, size_t *sizes);
 /* The same with the grid in host memory (what pairs with hgi_encode_u8).                      */
 hgi_status hgi_deflate_grid(hgi_ctx *ctx, const uint8_t *grid, uint32_t width, uint32_t height,
                             uint8_t *out, size_t cap, size_t *bytes);

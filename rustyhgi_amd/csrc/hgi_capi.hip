@@ -760,11 +760,189 @@ hgi_status hgi_huffman_plan(const uint64_t hist[286], uint8_t lens[286], uint16_
     return HGI_OK;
 }
 
-static size_t deflate_scratch_bytes(uint64_t n)
+// ---- the stage itself: `batch` grids, phase by phase, so that the host waits three times per GROUP of frames, not per frame
+namespace {
+
+constexpr size_t kHistBytes = (kMatchThresholds + 1) * kDeflateSymbols * 8;      // per frame, contiguous (one download)
+constexpr size_t kTableBytes = 1280;                                             // 286 x 4, rounded up
+
+struct DeflateGeom {
+    uint64_t n;
+    uint32_t nchunks;
+    size_t dev_cap;       // bytes of stream buffer per frame on the device
+    size_t group;         // frames whose stream buffers live in scratch at once
+    size_t need;          // scratch bytes
+};
+
+DeflateGeom deflate_geom(uint64_t n, size_t batch)
 {
-    return (kMatchThresholds + 1) * kDeflateSymbols * 8 + kDeflateSymbols * 4 + (size_t)huffman_chunks(n) * 12 + 8 +
-           align_up((size_t)(n + n / 4) + 4096, 256) + 10 * 256;
+    DeflateGeom g;
+    g.n = n;
+    g.nchunks = huffman_chunks(n);
+    g.dev_cap = align_up((size_t)(n + n / 4) + 4096, 256);      // an optimal code averages < 9 bits per byte
+    size_t group = ((size_t)1 << 30) / g.dev_cap;               // at most 1 GiB of stream buffers in flight
+    if (group < 1) group = 1;
+    if (group > batch) group = batch ? batch : 1;
+    if (group > 256) group = 256;
+    g.group = group;
+    g.need = group * (kHistBytes + kTableBytes + 8 + g.dev_cap) + (size_t)g.nchunks * 12 + 16 + 12 * 256;
+    return g;
 }
+
+struct FramePlan {
+    uint8_t lens[kDeflateSymbols];
+    uint16_t codes[kDeflateSymbols];
+    uint32_t table[kDeflateSymbols];
+    std::vector<uint8_t> front;      // block header + the eight literals of the u64 length, whole bytes
+    uint64_t base_bits = 0;          // where the grid's tokens start
+    uint64_t exact_bits = 0;         // length of the whole stream, known from the histograms
+    uint32_t min_match = 3;
+};
+
+void put_bits(std::vector<uint8_t> &v, uint64_t &at, uint32_t value, int nb)
+{
+    for (int i = 0; i < nb; ++i, ++at) {
+        if ((at >> 3) >= v.size()) v.push_back(0);
+        v[at >> 3] |= (uint8_t)(((value >> i) & 1u) << (at & 7));
+    }
+}
+
+// hists: [kMatchThresholds + 1][kDeflateSymbols] as downloaded (modified in place)
+hgi_status plan_frame(uint64_t (*hists)[kDeflateSymbols], bool have_grid, const uint8_t prefix[8], const uint8_t suffix[8], FramePlan &p)
+{
+    if (have_grid)
+        for (int v = 0; v < kMatchThresholds; ++v)
+            for (int sym = 0; sym < kDeflateSymbols; ++sym) hists[v][sym] += hists[kMatchThresholds][sym];
+    // for each candidate threshold: the code its histogram asks for and the exact size of the tokens under it; keep the
+    // smallest (the 16 bytes around the grid are literals under every threshold)
+    uint64_t best = ~0ull;
+    int pick = 0;
+    for (int v = 0; v < kMatchThresholds; ++v) {
+        uint64_t *hv = hists[v];
+        for (int i = 0; i < 8; ++i) {
+            ++hv[prefix[i]];
+            ++hv[suffix[i]];
+        }
+        hv[256] = 1;      // end of block
+        const uint64_t total = huffman_payload_bits(hv);
+        if (total < best) {
+            best = total;
+            pick = v;
+        }
+        if (!have_grid) break;
+    }
+    uint8_t head[640];
+    const size_t bits = huffman_plan(hists[pick], p.lens, p.codes, head, sizeof(head) - 64);
+    if (!bits) return fail(HGI_EDEVICE, "block header does not fit");
+    p.min_match = kMatchThresholdHost[pick];
+    p.exact_bits = best + bits;
+    p.front.assign(head, head + (bits + 7) / 8);
+    p.base_bits = bits;
+    for (int i = 0; i < 8; ++i) put_bits(p.front, p.base_bits, p.codes[prefix[i]], p.lens[prefix[i]]);
+    for (int v = 0; v < kDeflateSymbols; ++v) p.table[v] = (uint32_t)p.codes[v] | ((uint32_t)p.lens[v] << 16);
+    return HGI_OK;
+}
+
+hgi_status deflate_frames(hgi_ctx *c, const uint8_t *d_grids, uint32_t w, uint32_t h, size_t batch, size_t stride, uint8_t *out,
+                          size_t out_stride, size_t cap, size_t *sizes)
+{
+    const DeflateGeom g = deflate_geom((uint64_t)w * h, batch);
+    const uint64_t n = g.n;
+    // the bincode image of Grid { buffer: Vec<u8>, width: usize } (src/grid.rs:2-5): u64 length, the bytes, u64 width
+    uint8_t prefix[8], suffix[8];
+    for (int i = 0; i < 8; ++i) {
+        prefix[i] = (uint8_t)(n >> (8 * i));
+        suffix[i] = (uint8_t)((uint64_t)w >> (8 * i));
+    }
+    HGI_TRY(ws_ensure(c, g.need));
+    c->ws_used = 0;
+    uint8_t *d_hist = ws_take(c, g.group * kHistBytes);
+    uint8_t *d_tables = ws_take(c, g.group * kTableBytes);
+    uint64_t *d_totals = reinterpret_cast<uint64_t *>(ws_take(c, g.group * 8));
+    uint64_t *d_off = reinterpret_cast<uint64_t *>(ws_take(c, (size_t)g.nchunks * 8 + 8));
+    uint32_t *d_cbits = reinterpret_cast<uint32_t *>(ws_take(c, (size_t)g.nchunks * 4 + 8));
+    uint8_t *d_outs = ws_take(c, g.group * g.dev_cap);
+    c->ws_used = 0;
+    if (!d_hist || !d_tables || !d_totals || !d_off || !d_cbits || !d_outs) return fail(HGI_ENOMEM, "scratch exhausted (entropy stage)");
+    const uint32_t dist_code = 0u | (1u << 16);      // distance symbol 0 (= distance 1): the one-bit code "0"
+    std::vector<uint64_t> hists(g.group * (kHistBytes / 8));
+    std::vector<FramePlan> plans(g.group);
+    std::vector<uint64_t> totals(g.group);
+    for (size_t g0 = 0; g0 < batch; g0 += g.group) {
+        const size_t cnt = batch - g0 < g.group ? batch - g0 : g.group;
+        // phase 1: token histograms of the group, one download
+        std::fill(hists.begin(), hists.end(), 0);
+        if (n) {
+            for (size_t f = 0; f < cnt; ++f)
+                HIP_TRY(launch_token_histogram(d_grids + (g0 + f) * stride, n, reinterpret_cast<unsigned long long *>(d_hist + f * kHistBytes),
+                                               c->stream));
+            HIP_TRY(hipMemcpyAsync(hists.data(), d_hist, cnt * kHistBytes, hipMemcpyDeviceToHost, c->stream));
+            HIP_TRY(hipStreamSynchronize(c->stream));
+        }
+        // phase 2: codes on the host; phase 3: count / scan / pack queued frame after frame (the chunk arrays are reused:
+        // the stream orders the frames)
+        for (size_t f = 0; f < cnt; ++f) {
+            FramePlan &p = plans[f];
+            hgi_status st = plan_frame(reinterpret_cast<uint64_t (*)[kDeflateSymbols]>(hists.data() + f * (kHistBytes / 8)), n != 0, prefix, suffix, p);
+            // the histograms say exactly how long the stream will be: never start packing into a buffer it would overrun
+            if (st == HGI_OK && p.exact_bits / 8 + 64 > g.dev_cap)
+                st = fail(HGI_EDEVICE, "entropy stage: stream of %llu bytes exceeds its scratch", (unsigned long long)(p.exact_bits / 8));
+            if (st == HGI_OK && p.exact_bits / 8 + 1 > cap)
+                st = fail(HGI_EINVAL, "output buffer too small: %llu bytes needed", (unsigned long long)(p.exact_bits / 8 + 1));
+            if (st != HGI_OK) {
+                (void)hipStreamSynchronize(c->stream);      // what was queued reads host memory that is about to go away
+                return st;
+            }
+            if (!n) continue;
+            uint8_t *d_out = d_outs + f * g.dev_cap;
+            uint32_t *d_table = reinterpret_cast<uint32_t *>(d_tables + f * kTableBytes);
+            HIP_TRY(hipMemsetAsync(d_out, 0, align_up((size_t)(p.exact_bits / 8) + 64, 256), c->stream));
+            HIP_TRY(hipMemcpyAsync(d_out, p.front.data(), p.front.size(), hipMemcpyHostToDevice, c->stream));
+            HIP_TRY(hipMemcpyAsync(d_table, p.table, sizeof(p.table), hipMemcpyHostToDevice, c->stream));
+            HIP_TRY(launch_huffman_pack(d_grids + (g0 + f) * stride, n, d_table, dist_code, p.min_match, d_cbits, d_off, d_totals + f,
+                                        p.base_bits, reinterpret_cast<uint32_t *>(d_out), c->stream));
+        }
+        if (n) {
+            HIP_TRY(hipMemcpyAsync(totals.data(), d_totals, cnt * 8, hipMemcpyDeviceToHost, c->stream));
+            HIP_TRY(hipStreamSynchronize(c->stream));
+        }
+        // phase 4: downloads, then the eight literals of the u64 width and the end-of-block code on the host
+        std::vector<uint64_t> end_bits(cnt);
+        for (size_t f = 0; f < cnt; ++f) {
+            const FramePlan &p = plans[f];
+            end_bits[f] = p.base_bits + (n ? totals[f] : 0);
+            uint64_t tail = p.lens[256];
+            for (int i = 0; i < 8; ++i) tail += p.lens[suffix[i]];
+            if (end_bits[f] + tail != p.exact_bits) {
+                (void)hipStreamSynchronize(c->stream);
+                return fail(HGI_EDEVICE, "entropy stage: packed %llu bits where the histograms promised %llu",
+                            (unsigned long long)(end_bits[f] + tail), (unsigned long long)p.exact_bits);
+            }
+            uint8_t *dst = out + (g0 + f) * out_stride;
+            const size_t total_bytes = (size_t)((p.exact_bits + 7) / 8);
+            std::memset(dst, 0, total_bytes);
+            if (n)
+                HIP_TRY(hipMemcpyAsync(dst, d_outs + f * g.dev_cap, (size_t)((end_bits[f] + 7) / 8), hipMemcpyDeviceToHost, c->stream));
+            else
+                std::memcpy(dst, p.front.data(), p.front.size());
+        }
+        if (n) HIP_TRY(hipStreamSynchronize(c->stream));
+        for (size_t f = 0; f < cnt; ++f) {
+            const FramePlan &p = plans[f];
+            uint8_t *dst = out + (g0 + f) * out_stride;
+            uint64_t at = end_bits[f];
+            auto put_out = [&](uint32_t value, int nb) {
+                for (int i = 0; i < nb; ++i, ++at) dst[at >> 3] |= (uint8_t)(((value >> i) & 1u) << (at & 7));
+            };
+            for (int i = 0; i < 8; ++i) put_out(p.codes[suffix[i]], p.lens[suffix[i]]);
+            put_out(p.codes[256], p.lens[256]);
+            sizes[g0 + f] = (size_t)((p.exact_bits + 7) / 8);
+        }
+    }
+    return HGI_OK;
+}
+
+}  // namespace
 
 // host-pointer form (what pairs with hgi_encode_u8): the grid goes up into scratch behind the stage's own buffers
 hgi_status hgi_deflate_grid(hgi_ctx *c, const uint8_t *grid, uint32_t w, uint32_t h, uint8_t *out, size_t cap, size_t *bytes)
@@ -773,120 +951,31 @@ hgi_status hgi_deflate_grid(hgi_ctx *c, const uint8_t *grid, uint32_t w, uint32_
     const size_t n = (size_t)w * h;
     if (n && !grid) return fail(HGI_EINVAL, "NULL buffer");
     HIP_TRY(hipSetDevice(c->device));
-    const size_t front = align_up(deflate_scratch_bytes(n), 256);
+    const size_t front = align_up(deflate_geom(n, 1).need, 256);
     HGI_TRY(ws_ensure(c, front + n + 256));
     uint8_t *staged = c->ws + front;
     if (n) HIP_TRY(hipMemcpyAsync(staged, grid, n, hipMemcpyHostToDevice, c->stream));
-    return hgi_deflate_grid_dev(c, staged, w, h, out, cap, bytes);
+    return deflate_frames(c, staged, w, h, 1, n, out, cap, cap, bytes);
 }
 
 hgi_status hgi_deflate_grid_dev(hgi_ctx *c, const void *d_grid, uint32_t w, uint32_t h, uint8_t *out, size_t cap, size_t *bytes)
 {
     if (!c || !out || !bytes) return fail(HGI_EINVAL, "NULL argument");
-    const uint64_t n = (uint64_t)w * h;
-    if (n && !d_grid) return fail(HGI_EINVAL, "NULL buffer");
+    if ((uint64_t)w * h && !d_grid) return fail(HGI_EINVAL, "NULL buffer");
     HIP_TRY(hipSetDevice(c->device));
-    // the bincode image of Grid { buffer: Vec<u8>, width: usize } (src/grid.rs:2-5): u64 length, the bytes, u64 width
-    uint8_t prefix[8], suffix[8];
-    for (int i = 0; i < 8; ++i) {
-        prefix[i] = (uint8_t)(n >> (8 * i));
-        suffix[i] = (uint8_t)((uint64_t)w >> (8 * i));
-    }
-    const uint32_t nchunks = huffman_chunks(n);
-    const size_t dev_cap = align_up((size_t)(n + n / 4) + 4096, 256);      // an optimal code averages < 9 bits per byte
-    const size_t need = deflate_scratch_bytes(n);
-    HGI_TRY(ws_ensure(c, need));
-    c->ws_used = 0;
-    unsigned long long *d_hist = reinterpret_cast<unsigned long long *>(ws_take(c, (kMatchThresholds + 1) * kDeflateSymbols * 8));
-    uint32_t *d_table = reinterpret_cast<uint32_t *>(ws_take(c, kDeflateSymbols * 4));
-    uint64_t *d_off = reinterpret_cast<uint64_t *>(ws_take(c, (size_t)nchunks * 8 + 8));
-    uint32_t *d_cbits = reinterpret_cast<uint32_t *>(ws_take(c, (size_t)nchunks * 4 + 8));
-    uint64_t *d_total = reinterpret_cast<uint64_t *>(ws_take(c, 8));
-    uint32_t *d_out = reinterpret_cast<uint32_t *>(ws_take(c, dev_cap));
-    if (!d_hist || !d_table || !d_off || !d_cbits || !d_total || !d_out) return fail(HGI_ENOMEM, "scratch exhausted (entropy stage)");
-    uint64_t hists[kMatchThresholds + 1][kDeflateSymbols] = {{0}};      // [kMatchThresholds]: the part common to all candidates
-    if (n) {
-        HIP_TRY(launch_token_histogram(static_cast<const uint8_t *>(d_grid), n, d_hist, c->stream));
-        HIP_TRY(hipMemcpyAsync(hists, d_hist, sizeof(hists), hipMemcpyDeviceToHost, c->stream));
-        HIP_TRY(hipStreamSynchronize(c->stream));
-        for (int v = 0; v < kMatchThresholds; ++v)
-            for (int sym = 0; sym < kDeflateSymbols; ++sym) hists[v][sym] += hists[kMatchThresholds][sym];
-    }
-    // for each candidate threshold: the code its histogram asks for and the exact size of the stream it gives; keep the
-    // smallest (the 16 bytes around the grid are literals under every threshold)
-    uint8_t lens[kDeflateSymbols], head[640];
-    uint16_t codes[kDeflateSymbols];
-    size_t bits = 0;
-    uint32_t min_match = kMatchThresholdHost[0];
-    {
-        uint64_t best = ~0ull;
-        int pick = 0;
-        for (int v = 0; v < kMatchThresholds; ++v) {
-            uint64_t *hv = hists[v];
-            for (int i = 0; i < 8; ++i) {
-                ++hv[prefix[i]];
-                ++hv[suffix[i]];
-            }
-            hv[256] = 1;      // end of block
-            const uint64_t total = huffman_payload_bits(hv);
-            if (total < best) {
-                best = total;
-                pick = v;
-            }
-            if (n == 0) break;
-        }
-        min_match = kMatchThresholdHost[pick];
-        bits = huffman_plan(hists[pick], lens, codes, head, sizeof(head) - 64);
-        if (!bits) return fail(HGI_EDEVICE, "block header does not fit");
-        best += bits;
-        // the histograms say exactly how long the stream will be: never start packing into a buffer it would overrun
-        if (best / 8 + 64 > dev_cap) return fail(HGI_EDEVICE, "entropy stage: stream of %llu bytes exceeds its scratch", (unsigned long long)(best / 8));
-        if (best / 8 + 1 > cap) return fail(HGI_EINVAL, "output buffer too small: %llu bytes needed", (unsigned long long)(best / 8 + 1));
-    }
-    auto put = [&](std::vector<uint8_t> &v, size_t &at, uint32_t value, int nb) {
-        for (int i = 0; i < nb; ++i, ++at) {
-            if ((at >> 3) >= v.size()) v.push_back(0);
-            v[at >> 3] |= (uint8_t)(((value >> i) & 1u) << (at & 7));
-        }
-    };
-    std::vector<uint8_t> front(head, head + (bits + 7) / 8);
-    for (int i = 0; i < 8; ++i) put(front, bits, codes[prefix[i]], lens[prefix[i]]);
-    const uint64_t base_bits = bits;
-    uint64_t grid_bits = 0;
-    if (n) {
-        uint32_t table[kDeflateSymbols];
-        for (int v = 0; v < kDeflateSymbols; ++v) table[v] = (uint32_t)codes[v] | ((uint32_t)lens[v] << 16);
-        const uint32_t dist_code = 0u | (1u << 16);      // distance symbol 0 (= distance 1): the one-bit code "0"
-        HIP_TRY(hipMemsetAsync(d_out, 0, dev_cap, c->stream));
-        HIP_TRY(hipMemcpyAsync(d_out, front.data(), front.size(), hipMemcpyHostToDevice, c->stream));
-        HIP_TRY(hipMemcpyAsync(d_table, table, sizeof(table), hipMemcpyHostToDevice, c->stream));
-        HIP_TRY(launch_huffman_pack(static_cast<const uint8_t *>(d_grid), n, d_table, dist_code, min_match, d_cbits, d_off, d_total,
-                                    base_bits, d_out, c->stream));
-        HIP_TRY(hipMemcpyAsync(&grid_bits, d_total, 8, hipMemcpyDeviceToHost, c->stream));
-        HIP_TRY(hipStreamSynchronize(c->stream));       // (front / table are read by the copies above: they end here)
-    }
-    uint64_t end_bits = base_bits + grid_bits;
-    size_t tail_bits = 0;
-    for (int i = 0; i < 8; ++i) tail_bits += lens[suffix[i]];
-    tail_bits += lens[256];
-    const size_t total_bytes = (size_t)((end_bits + tail_bits + 7) / 8);
-    c->ws_used = 0;
-    if ((end_bits + 7) / 8 + 8 > dev_cap) return fail(HGI_EDEVICE, "entropy stage overran its buffer");
-    if (total_bytes > cap) return fail(HGI_EINVAL, "output buffer too small: %zu bytes needed", total_bytes);
-    std::memset(out, 0, total_bytes);
-    if (n) {
-        HIP_TRY(hipMemcpyAsync(out, d_out, (size_t)((end_bits + 7) / 8), hipMemcpyDeviceToHost, c->stream));
-        HIP_TRY(hipStreamSynchronize(c->stream));
-    } else {
-        std::memcpy(out, front.data(), front.size());
-    }
-    auto put_out = [&](uint32_t value, int nb) {
-        for (int i = 0; i < nb; ++i, ++end_bits) out[end_bits >> 3] |= (uint8_t)(((value >> i) & 1u) << (end_bits & 7));
-    };
-    for (int i = 0; i < 8; ++i) put_out(codes[suffix[i]], lens[suffix[i]]);
-    put_out(codes[256], lens[256]);
-    *bytes = total_bytes;
-    return HGI_OK;
+    return deflate_frames(c, static_cast<const uint8_t *>(d_grid), w, h, 1, (size_t)w * h, out, cap, cap, bytes);
+}
+
+hgi_status hgi_deflate_grids_dev(hgi_ctx *c, const void *d_grids, uint32_t w, uint32_t h, size_t batch, size_t frame_stride, uint8_t *out,
+                                 size_t out_stride, size_t *sizes)
+{
+    if (!c || (batch && (!out || !sizes))) return fail(HGI_EINVAL, "NULL argument");
+    if (batch == 0) return HGI_OK;
+    const size_t n = (size_t)w * h;
+    if (n && !d_grids) return fail(HGI_EINVAL, "NULL buffer");
+    if (batch > 1 && frame_stride < n) return fail(HGI_EINVAL, "frame_stride %zu < width*height", frame_stride);
+    HIP_TRY(hipSetDevice(c->device));
+    return deflate_frames(c, static_cast<const uint8_t *>(d_grids), w, h, batch, frame_stride, out, out_stride, out_stride, sizes);
 }
 
 // ---- plane placement ------------------------------------------------------------------------------------------

@@ -58,3 +58,19 @@ def deflate_grid(grid, context=None):
     n = ctypes.c_size_t(0)
     _ffi.check(_ffi.lib().hgi_deflate_grid_dev(ctx.handle, grid.data_ptr(), w, h, out.ctypes.data, cap, ctypes.byref(n)))
     return out[:n.value].tobytes()
+
+
+def deflate_grids(grids, context=None):
+    """(B, H, W) uint8 CUDA tensor -> list of B bytes objects, each the raw DEFLATE stream of that grid's bincode image
+    (hgi_deflate_grids_dev: the stage's phases run over the whole batch, three host waits per group of frames)."""
+    import ctypes
+    import torch
+    if grids.dim() != 3 or grids.dtype != torch.uint8 or not grids.is_cuda or not grids.is_contiguous():
+        raise TypeError("deflate_grids() takes a contiguous uint8 CUDA tensor of shape (B, H, W)")
+    ctx = _torch_ctx(grids, context)
+    b, h, w = grids.shape
+    cap = h * w + h * w // 8 + 1024
+    out = np.empty((b, cap), np.uint8)
+    sizes = (ctypes.c_size_t * b)()
+    _ffi.check(_ffi.lib().hgi_deflate_grids_dev(ctx.handle, grids.data_ptr(), w, h, b, h * w, out.ctypes.data, cap, sizes))
+    return [out[f, :sizes[f]].tobytes() for f in range(b)]

@@ -891,3 +891,24 @@ def test_criterion_harness_port_prints_all_eight_cases(tmp_path):
         assert any(line.startswith(case + " ") for line in out.stdout.splitlines()), (case, out.stdout)
     assert "lossless round trip exact: yes" in out.stdout
     assert "device-entropy archive reads back exactly: yes" in out.stdout
+
+
+def test_device_entropy_stage_batch(H, oracle, lena):
+    """hgi_deflate_grids_dev: a batch of grids in one call -- every stream inflates to its own grid's bincode image and
+    equals what the single-frame call writes for that grid (the code is chosen per frame)."""
+    import struct
+    import zlib
+    import torch
+    from rustyhgi_amd import entropy
+    w = h = 256
+    frames = [lena, oracle.synth(oracle.SYNTH_RAMP, SEED0 + 31, 1, w, h), oracle.synth(oracle.SYNTH_NOISE, SEED0 + 32, 2, w, h),
+              np.zeros((h, w), np.uint8), oracle.synth(oracle.SYNTH_XY, 0, 0, w, h)]
+    grids = np.stack([oracle.encode(f, 4, oracle.linear_lut(q)[0]) for q, f in enumerate(frames[:4])] + [frames[4]])
+    d = torch.from_numpy(grids).cuda()
+    streams = entropy.deflate_grids(d)
+    assert len(streams) == 5
+    for f in range(5):
+        body = struct.pack("<Q", w * h) + grids[f].tobytes() + struct.pack("<Q", w)
+        assert zlib.decompressobj(-15).decompress(streams[f]) == body, f
+        assert streams[f] == entropy.deflate_grid(d[f]), f
+    assert len(streams[3]) < 200          # an all-zero grid: a few run matches per KiB chunk
