@@ -34,3 +34,34 @@ for name, img in cases:
         td = (time.perf_counter() - t0) / reps
         assert zlib.decompressobj(-15).decompress(s) == body
         print("| %s | %s | %d | %d | %d | %.3f | %.2f | %.3f | %.0fx |" % (name, qn, w * h, len(z), len(s), len(s) / len(z), tz * 1e3, td * 1e3, tz / td))
+
+# a batch: the C3 shard's 64 grids of 4096 x 4096 at Medium, one call against 64 single-frame calls
+import ctypes
+from rustyhgi_amd import _ffi
+F, S = 64, 4096
+ctx = H.Context(0); ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+imgs = torch.empty((F, S, S), dtype=torch.uint8, device="cuda"); grids = torch.empty_like(imgs)
+lut = np.ascontiguousarray(O.linear_lut(2)[0])
+_ffi.check(_ffi.lib().hgi_synth_u8_dev(ctx.handle, _ffi.SYNTH_RAMP, 0x48474930 + 3, 0, S, S, imgs.data_ptr(), F, S * S))
+_ffi.check(_ffi.lib().hgi_encode_u8_dev(ctx.handle, imgs.data_ptr(), S, S, 4, 1, lut.ctypes.data, grids.data_ptr(), F, S * S))
+torch.cuda.synchronize()
+# through the C ABI with caller-owned, already touched host buffers (a fresh 1.2 GB numpy array would be timed page faults)
+cap = S * S // 2
+out = np.zeros((F, cap), np.uint8)
+sizes = (ctypes.c_size_t * F)()
+L = _ffi.lib()
+def batch_call():
+    _ffi.check(L.hgi_deflate_grids_dev(ctx.handle, grids.data_ptr(), S, S, F, S * S, out.ctypes.data, cap, sizes))
+def single_calls():
+    one = ctypes.c_size_t(0)
+    for f in range(F):
+        _ffi.check(L.hgi_deflate_grid_dev(ctx.handle, grids[f].data_ptr(), S, S, out[f].ctypes.data, cap, ctypes.byref(one)))
+batch_call(); single_calls()
+t0 = time.perf_counter(); batch_call(); tb = time.perf_counter() - t0
+streams = [out[f, :sizes[f]].tobytes() for f in range(F)]
+t0 = time.perf_counter(); single_calls(); ts = time.perf_counter() - t0
+assert streams[5] == entropy.deflate_grid(grids[5], context=ctx)
+total = sum(len(s) for s in streams)
+print()
+print("batch of %d grids %dx%d Medium (the C3 shard): %d -> %d bytes (%.2fx); hgi_deflate_grids_dev %.1f ms = %.2f ms per frame, %.1f GB/s of grid;"
+      " %d single-frame calls %.1f ms" % (F, S, S, F * S * S, total, F * S * S / total, tb * 1e3, tb * 1e3 / F, F * S * S / tb / 1e9, F, ts * 1e3))
