@@ -353,15 +353,28 @@ class Codec:
             # best effort inside the library; if it could not establish the separation, ask again while the first set
             # is still held (the new candidates then come from elsewhere), up to twice
             held = []
-            for attempt in range(3):
-                self.planes = H.Planes(ctx, F * S * S, 3)
-                if self.planes.separated:
-                    break
-                if attempt < 2:
-                    held.append(self.planes)
-            for p in held:
-                p.close()
-            self.imgs, self.grids, self.outs = (self.planes.torch(i, (F, S, S)) for i in range(3))
+            try:
+                for attempt in range(3):
+                    self.planes = H.Planes(ctx, F * S * S, 3)
+                    if self.planes.separated:
+                        break
+                    if attempt < 2:
+                        held.append(self.planes)
+                for p in held:
+                    p.close()
+                self.imgs, self.grids, self.outs = (self.planes.torch(i, (F, S, S)) for i in range(3))
+            except Exception as e:      # placement is an optimisation: never let it cost the run
+                print("bench.py: plane placement failed (%s); falling back to plain allocations" % e, file=sys.stderr)
+                for p in held + ([self.planes] if self.planes is not None else []):
+                    try:
+                        p.close()
+                    except Exception:
+                        pass
+                self.planes = None
+                args.placement = "torch (planes failed)"
+                self.imgs = torch.empty((F, S, S), dtype=torch.uint8, device=dev)
+                self.grids = torch.empty_like(self.imgs)
+                self.outs = torch.empty_like(self.imgs)
         elif args.placement == "same-region":
             # three planes of seven whose two pairings (image -> grid, grid -> image) both probe SLOW: one region
             self.planes = H.Planes(ctx, F * S * S, 7)
