@@ -49,7 +49,7 @@ class Archive:
 
     def serialize_to_writer(self, w, device_entropy=False):
         """src/archive.rs:31-41.  device_entropy=True (grid buffer = a CUDA tensor): the DEFLATE stream is written by the
-        device's entropy stage (rustyhgi_amd.entropy.deflate_grid: Huffman-coded literals, no matches) instead of zlib at
+        device's entropy stage (rustyhgi_amd.entropy.deflate_grid: Huffman-coded literals and run matches) instead of zlib at
         level 9 -- the same container, readable by the same readers, two orders of magnitude sooner."""
         m = self.metadata
         w.write(struct.pack("<I", MAGIC))

@@ -44,7 +44,7 @@ def estimated_bytes(hist):
 
 
 def deflate_grid(grid, context=None):
-    """(H, W) uint8 CUDA tensor -> bytes: raw DEFLATE (one dynamic-Huffman block of literals) of the grid's bincode image
+    """(H, W) uint8 CUDA tensor -> bytes: raw DEFLATE (one dynamic-Huffman block of literals and distance-1 run matches) of the grid's bincode image
     (u64 H*W, the bytes, u64 W) -- what follows the metadata in a .hgi archive -- entropy-coded on the device
     (hgi_deflate_grid_dev, include/hgi.h).  Synchronous."""
     import ctypes
