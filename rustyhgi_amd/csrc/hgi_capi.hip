@@ -764,7 +764,6 @@ hgi_status hgi_huffman_plan(const uint64_t hist[286], uint8_t lens[286], uint16_
 namespace {
 
 constexpr size_t kHistBytes = (kMatchThresholds + 1) * kDeflateSymbols * 8;      // per frame, contiguous (one download)
-constexpr size_t kTableBytes = 1280;                                             // 286 x 4, rounded up
 
 struct DeflateGeom {
     uint64_t n;
@@ -784,27 +783,22 @@ DeflateGeom deflate_geom(uint64_t n, size_t batch)
     if (group < 1) group = 1;
     if (group > batch) group = batch ? batch : 1;
     if (group > 256) group = 256;
+    // equal groups: the last one is not a straggler
+    const size_t ngroups = batch ? (batch + group - 1) / group : 1;
+    if (batch) group = (batch + ngroups - 1) / ngroups;
     g.group = group;
-    g.need = group * (kHistBytes + kTableBytes + 8 + g.dev_cap) + (size_t)g.nchunks * 12 + 16 + 12 * 256;
+    g.need = group * (kHistBytes + kPlanBytes + 8 + g.dev_cap + (size_t)g.nchunks * 12 + 64) + 4096;
     return g;
 }
 
 struct FramePlan {
-    uint8_t lens[kDeflateSymbols];
-    uint16_t codes[kDeflateSymbols];
-    uint32_t table[kDeflateSymbols];
-    std::vector<uint8_t> front;      // block header + the eight literals of the u64 length, whole bytes
-    uint64_t base_bits = 0;          // where the grid's tokens start
+    DeflatePlan block;               // what the device gets
     uint64_t exact_bits = 0;         // length of the whole stream, known from the histograms
-    uint32_t min_match = 3;
 };
 
-void put_bits(std::vector<uint8_t> &v, uint64_t &at, uint32_t value, int nb)
+void put_bits(uint8_t *v, uint64_t &at, uint32_t value, int nb)
 {
-    for (int i = 0; i < nb; ++i, ++at) {
-        if ((at >> 3) >= v.size()) v.push_back(0);
-        v[at >> 3] |= (uint8_t)(((value >> i) & 1u) << (at & 7));
-    }
+    for (int i = 0; i < nb; ++i, ++at) v[at >> 3] |= (uint8_t)(((value >> i) & 1u) << (at & 7));
 }
 
 // hists: [kMatchThresholds + 1][kDeflateSymbols] as downloaded (modified in place)
@@ -831,15 +825,24 @@ hgi_status plan_frame(uint64_t (*hists)[kDeflateSymbols], bool have_grid, const 
         }
         if (!have_grid) break;
     }
-    uint8_t head[640];
-    const size_t bits = huffman_plan(hists[pick], p.lens, p.codes, head, sizeof(head) - 64);
+    uint8_t lens[kDeflateSymbols];
+    uint16_t codes[kDeflateSymbols];
+    DeflatePlan &d = p.block;
+    std::memset(&d, 0, sizeof(d));
+    const size_t bits = huffman_plan(hists[pick], lens, codes, d.front, sizeof(d.front) - 32);
     if (!bits) return fail(HGI_EDEVICE, "block header does not fit");
-    p.min_match = kMatchThresholdHost[pick];
+    d.min_match = kMatchThresholdHost[pick];
     p.exact_bits = best + bits;
-    p.front.assign(head, head + (bits + 7) / 8);
-    p.base_bits = bits;
-    for (int i = 0; i < 8; ++i) put_bits(p.front, p.base_bits, p.codes[prefix[i]], p.lens[prefix[i]]);
-    for (int v = 0; v < kDeflateSymbols; ++v) p.table[v] = (uint32_t)p.codes[v] | ((uint32_t)p.lens[v] << 16);
+    d.base_bits = bits;
+    for (int i = 0; i < 8; ++i) put_bits(d.front, d.base_bits, codes[prefix[i]], lens[prefix[i]]);
+    d.front_bytes = (uint32_t)((d.base_bits + 7) / 8);
+    uint64_t tb = 0;
+    uint8_t tail[sizeof(d.tail)] = {};
+    for (int i = 0; i < 8; ++i) put_bits(tail, tb, codes[suffix[i]], lens[suffix[i]]);
+    put_bits(tail, tb, codes[256], lens[256]);
+    d.tail_bits = (uint32_t)tb;
+    std::memcpy(d.tail, tail, sizeof(tail));
+    for (int v = 0; v < kDeflateSymbols; ++v) d.table[v] = (uint32_t)codes[v] | ((uint32_t)lens[v] << 16);
     return HGI_OK;
 }
 
@@ -857,85 +860,68 @@ hgi_status deflate_frames(hgi_ctx *c, const uint8_t *d_grids, uint32_t w, uint32
     HGI_TRY(ws_ensure(c, g.need));
     c->ws_used = 0;
     uint8_t *d_hist = ws_take(c, g.group * kHistBytes);
-    uint8_t *d_tables = ws_take(c, g.group * kTableBytes);
+    uint8_t *d_plans = ws_take(c, g.group * kPlanBytes);
     uint64_t *d_totals = reinterpret_cast<uint64_t *>(ws_take(c, g.group * 8));
-    uint64_t *d_off = reinterpret_cast<uint64_t *>(ws_take(c, (size_t)g.nchunks * 8 + 8));
-    uint32_t *d_cbits = reinterpret_cast<uint32_t *>(ws_take(c, (size_t)g.nchunks * 4 + 8));
+    uint64_t *d_off = reinterpret_cast<uint64_t *>(ws_take(c, g.group * (size_t)g.nchunks * 8 + 8));
+    uint32_t *d_cbits = reinterpret_cast<uint32_t *>(ws_take(c, g.group * (size_t)g.nchunks * 4 + 8));
     uint8_t *d_outs = ws_take(c, g.group * g.dev_cap);
     c->ws_used = 0;
-    if (!d_hist || !d_tables || !d_totals || !d_off || !d_cbits || !d_outs) return fail(HGI_ENOMEM, "scratch exhausted (entropy stage)");
+    if (!d_hist || !d_plans || !d_totals || !d_off || !d_cbits || !d_outs) return fail(HGI_ENOMEM, "scratch exhausted (entropy stage)");
     const uint32_t dist_code = 0u | (1u << 16);      // distance symbol 0 (= distance 1): the one-bit code "0"
     std::vector<uint64_t> hists(g.group * (kHistBytes / 8));
     std::vector<FramePlan> plans(g.group);
+    std::vector<DeflatePlan> blocks(g.group);
     std::vector<uint64_t> totals(g.group);
     for (size_t g0 = 0; g0 < batch; g0 += g.group) {
         const size_t cnt = batch - g0 < g.group ? batch - g0 : g.group;
-        // phase 1: token histograms of the group, one download
+        // phase 1: token histograms of the group, one launch, one download
         std::fill(hists.begin(), hists.end(), 0);
         if (n) {
-            for (size_t f = 0; f < cnt; ++f)
-                HIP_TRY(launch_token_histogram(d_grids + (g0 + f) * stride, n, reinterpret_cast<unsigned long long *>(d_hist + f * kHistBytes),
-                                               c->stream));
+            HIP_TRY(launch_token_histogram(d_grids + g0 * stride, n, stride, (uint32_t)cnt, reinterpret_cast<unsigned long long *>(d_hist), c->stream));
             HIP_TRY(hipMemcpyAsync(hists.data(), d_hist, cnt * kHistBytes, hipMemcpyDeviceToHost, c->stream));
             HIP_TRY(hipStreamSynchronize(c->stream));
         }
-        // phase 2: codes on the host; phase 3: count / scan / pack queued frame after frame (the chunk arrays are reused:
-        // the stream orders the frames)
+        // phase 2: codes on the host.  The histograms say exactly how long each stream will be: never start packing into
+        // a buffer it would overrun
         for (size_t f = 0; f < cnt; ++f) {
             FramePlan &p = plans[f];
-            hgi_status st = plan_frame(reinterpret_cast<uint64_t (*)[kDeflateSymbols]>(hists.data() + f * (kHistBytes / 8)), n != 0, prefix, suffix, p);
-            // the histograms say exactly how long the stream will be: never start packing into a buffer it would overrun
-            if (st == HGI_OK && p.exact_bits / 8 + 64 > g.dev_cap)
-                st = fail(HGI_EDEVICE, "entropy stage: stream of %llu bytes exceeds its scratch", (unsigned long long)(p.exact_bits / 8));
-            if (st == HGI_OK && p.exact_bits / 8 + 1 > cap)
-                st = fail(HGI_EINVAL, "output buffer too small: %llu bytes needed", (unsigned long long)(p.exact_bits / 8 + 1));
-            if (st != HGI_OK) {
-                (void)hipStreamSynchronize(c->stream);      // what was queued reads host memory that is about to go away
-                return st;
+            HGI_TRY(plan_frame(reinterpret_cast<uint64_t (*)[kDeflateSymbols]>(hists.data() + f * (kHistBytes / 8)), n != 0, prefix, suffix, p));
+            if (p.exact_bits / 8 + 64 > g.dev_cap)
+                return fail(HGI_EDEVICE, "entropy stage: stream of %llu bytes exceeds its scratch", (unsigned long long)(p.exact_bits / 8));
+            if (p.exact_bits / 8 + 1 > cap) return fail(HGI_EINVAL, "output buffer too small: %llu bytes needed", (unsigned long long)(p.exact_bits / 8 + 1));
+            blocks[f] = p.block;
+        }
+        if (!n) {
+            // nothing for the device to code: the front, then the tail, here
+            for (size_t f = 0; f < cnt; ++f) {
+                const DeflatePlan &d = plans[f].block;
+                uint8_t *dst = out + (g0 + f) * out_stride;
+                const size_t total_bytes = (size_t)((plans[f].exact_bits + 7) / 8);
+                std::memset(dst, 0, total_bytes);
+                std::memcpy(dst, d.front, d.front_bytes);
+                uint64_t at = d.base_bits;
+                const uint8_t *tail = reinterpret_cast<const uint8_t *>(d.tail);
+                for (uint32_t i = 0; i < d.tail_bits; ++i, ++at) dst[at >> 3] |= (uint8_t)(((tail[i >> 3] >> (i & 7)) & 1u) << (at & 7));
+                sizes[g0 + f] = total_bytes;
             }
-            if (!n) continue;
-            uint8_t *d_out = d_outs + f * g.dev_cap;
-            uint32_t *d_table = reinterpret_cast<uint32_t *>(d_tables + f * kTableBytes);
-            HIP_TRY(hipMemsetAsync(d_out, 0, align_up((size_t)(p.exact_bits / 8) + 64, 256), c->stream));
-            HIP_TRY(hipMemcpyAsync(d_out, p.front.data(), p.front.size(), hipMemcpyHostToDevice, c->stream));
-            HIP_TRY(hipMemcpyAsync(d_table, p.table, sizeof(p.table), hipMemcpyHostToDevice, c->stream));
-            HIP_TRY(launch_huffman_pack(d_grids + (g0 + f) * stride, n, d_table, dist_code, p.min_match, d_cbits, d_off, d_totals + f,
-                                        p.base_bits, reinterpret_cast<uint32_t *>(d_out), c->stream));
+            continue;
         }
-        if (n) {
-            HIP_TRY(hipMemcpyAsync(totals.data(), d_totals, cnt * 8, hipMemcpyDeviceToHost, c->stream));
-            HIP_TRY(hipStreamSynchronize(c->stream));
-        }
-        // phase 4: downloads, then the eight literals of the u64 width and the end-of-block code on the host
-        std::vector<uint64_t> end_bits(cnt);
+        // phase 3: one upload of the plans, count / scan / pack over the whole group, and the downloads queued behind them
+        // (their sizes are known already); one wait
+        HIP_TRY(hipMemcpyAsync(d_plans, blocks.data(), cnt * kPlanBytes, hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(launch_huffman_pack(d_grids + g0 * stride, n, stride, (uint32_t)cnt, d_plans, dist_code, d_cbits, d_off, d_totals, d_outs,
+                                    g.dev_cap, c->stream));
+        HIP_TRY(hipMemcpyAsync(totals.data(), d_totals, cnt * 8, hipMemcpyDeviceToHost, c->stream));
+        for (size_t f = 0; f < cnt; ++f)
+            HIP_TRY(hipMemcpyAsync(out + (g0 + f) * out_stride, d_outs + f * g.dev_cap, (size_t)((plans[f].exact_bits + 7) / 8), hipMemcpyDeviceToHost,
+                                   c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
         for (size_t f = 0; f < cnt; ++f) {
             const FramePlan &p = plans[f];
-            end_bits[f] = p.base_bits + (n ? totals[f] : 0);
-            uint64_t tail = p.lens[256];
-            for (int i = 0; i < 8; ++i) tail += p.lens[suffix[i]];
-            if (end_bits[f] + tail != p.exact_bits) {
-                (void)hipStreamSynchronize(c->stream);
-                return fail(HGI_EDEVICE, "entropy stage: packed %llu bits where the histograms promised %llu",
-                            (unsigned long long)(end_bits[f] + tail), (unsigned long long)p.exact_bits);
-            }
-            uint8_t *dst = out + (g0 + f) * out_stride;
-            const size_t total_bytes = (size_t)((p.exact_bits + 7) / 8);
-            std::memset(dst, 0, total_bytes);
-            if (n)
-                HIP_TRY(hipMemcpyAsync(dst, d_outs + f * g.dev_cap, (size_t)((end_bits[f] + 7) / 8), hipMemcpyDeviceToHost, c->stream));
-            else
-                std::memcpy(dst, p.front.data(), p.front.size());
-        }
-        if (n) HIP_TRY(hipStreamSynchronize(c->stream));
-        for (size_t f = 0; f < cnt; ++f) {
-            const FramePlan &p = plans[f];
-            uint8_t *dst = out + (g0 + f) * out_stride;
-            uint64_t at = end_bits[f];
-            auto put_out = [&](uint32_t value, int nb) {
-                for (int i = 0; i < nb; ++i, ++at) dst[at >> 3] |= (uint8_t)(((value >> i) & 1u) << (at & 7));
-            };
-            for (int i = 0; i < 8; ++i) put_out(p.codes[suffix[i]], p.lens[suffix[i]]);
-            put_out(p.codes[256], p.lens[256]);
+            const uint64_t got = p.block.base_bits + totals[f] + p.block.tail_bits;
+            if (got != p.exact_bits)
+                return fail(HGI_EDEVICE, "entropy stage: packed %llu bits where the histograms promised %llu", (unsigned long long)got,
+                            (unsigned long long)p.exact_bits);
             sizes[g0 + f] = (size_t)((p.exact_bits + 7) / 8);
         }
     }

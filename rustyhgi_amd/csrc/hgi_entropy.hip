@@ -9,7 +9,7 @@
 // 14.5 against 16.0 kB).  Both parallelise:
 //   tokens     a byte equal to its predecessor continues a run; a run's bytes after its first are covered by matches of
 //              distance 1 and length 3..258 (leftovers of 1-2 bytes stay literals).  Runs are cut at 1 KiB chunk
-//              boundaries, so every token is decided inside one workgroup (cost: one extra literal per KiB of run).
+//              boundaries, so every token is decided inside one wave (cost: one extra literal per KiB of run).
 //   histogram  of the 286 literal / length symbols the tokens use, for four match thresholds   (device, pass 1)
 //   code       for each threshold: length-limited canonical Huffman code, exact stream size;    (host, a few hundred symbols)
 //              the smallest wins (short runs of a byte whose literal costs 1 bit are cheaper as literals) + block header
@@ -214,143 +214,124 @@ size_t huffman_plan(const uint64_t hist[kDeflateSymbols], uint8_t lens[kDeflateS
     return bw.bits;
 }
 
+
 // ---------------------------------------------------------------------------------------------------------------
 // device: tokens, histogram, sum, scan, pack
 // ---------------------------------------------------------------------------------------------------------------
+// One WAVE per 1 KiB chunk, sixteen bytes a lane: everything a chunk needs -- who heads a run, how long the run still
+// goes -- is two shuffle scans inside the wave plus bit tricks on the lane's own 16-bit masks; no workgroup barrier
+// exists in any of the loops.  A workgroup is four such waves that share the read-only tables (and, in pass 1, the
+// histogram) in LDS and walk their own chunks, the next chunk's bytes already loading while this one is coded.
+// grid.y = the frame, so one launch covers a whole batch.
 namespace {
 
-constexpr int kPackThreads = 256;
-constexpr int kBytesPerThread = 4;
-constexpr int kChunk = kPackThreads * kBytesPerThread;   // bytes per workgroup: runs never cross a chunk boundary
+constexpr int kWaves = 4;
+constexpr int kPackThreads = 64 * kWaves;
+constexpr int kLaneBytes = 16;
+constexpr int kChunk = 64 * kLaneBytes;         // bytes per wave pass: runs never cross a chunk boundary
 constexpr u32 kNone = 0xFFFFFFFFu;
 __device__ constexpr u32 kMatchThreshold[kMatchThresholds] = {3, 4, 6, 10};      // = kMatchThresholdHost (hgi_kernels.h)
 
-// What the (up to) four bytes of this thread emit.  A byte "continues" when it equals its predecessor inside the chunk.
-// For a continuing byte at offset o (0-based) inside the run's tail of M continuing bytes, piece = o / 258 and the piece's
-// length is min(258, M - 258 * piece): the first byte of a piece of >= min_match (>= 3) emits the match, the others of that
-// piece nothing; bytes of shorter pieces stay literals.  With k = bytes since the run's head (>= 1) and rem = continuing bytes
-// left including this one: o = k - 1, M - 258 * piece = rem + (o % 258).
-struct Tokens {
-    u32 lit[4];      // the byte, or kNone beyond the end of the data
-    u32 piece[4];    // 0: the byte heads a run (or stands alone); else the length (1..258) of the run piece it lies in
-    u32 first[4];    // ... and whether it is that piece's first byte
+// a wave's LDS instructions execute in order: lanes exchange data through LDS without a barrier, the compiler only has
+// to keep the accesses where they are
+#define WAVE_LDS_ORDER() asm volatile("" ::: "memory")
+
+struct Lane {
+    u32 w[4];      // the lane's sixteen bytes, little endian
+    u32 cnt;       // how many of them exist (16 except at the end of the data)
 };
 
-// what byte i emits when pieces of at least `min_match` become matches: literal 0..255, kNone (nothing: covered by a
-// match), or 0x80000000 | match length
-__device__ __forceinline__ u32 token_symbol(const Tokens &tk, int i, u32 min_match)
+__device__ __forceinline__ Lane load_lane(const u8 *__restrict__ src, u64 n, u64 chunk0, u32 lane)
 {
-    if (tk.lit[i] == kNone) return kNone;
-    if (tk.piece[i] >= min_match) return tk.first[i] ? (0x80000000u | tk.piece[i]) : kNone;
-    return tk.lit[i];
+    Lane L;
+    const u64 at = chunk0 + (u64)lane * kLaneBytes;
+    L.w[0] = L.w[1] = L.w[2] = L.w[3] = 0;
+    if (at + kLaneBytes <= n) {
+        __builtin_memcpy(L.w, src + at, kLaneBytes);
+        L.cnt = kLaneBytes;
+    } else {
+        L.cnt = at >= n ? 0u : (u32)(n - at);
+#pragma unroll
+        for (int i = 0; i < kLaneBytes; ++i)
+            if ((u32)i < L.cnt) L.w[i >> 2] |= (u32)src[at + i] << (8 * (i & 3));
+    }
+    return L;
 }
 
-__device__ __forceinline__ Tokens tokens_of_thread(const u8 *__restrict__ src, u64 n, u64 chunk0, u32 *lds /* 2 * kPackThreads + 8 */)
+__device__ __forceinline__ u32 byte_of(const Lane &L, int i) { return (L.w[i >> 2] >> (8 * (i & 3))) & 255u; }
+
+// Positions inside the chunk: p = 16 lane + i.  A byte CONTINUES when it equals its predecessor inside the chunk; the
+// others HEAD a run (or stand alone).  For a continuing byte: head(p) = last head before it (exists: position 0),
+// stop(p) = first position after it that does not continue (a head, or the end of the data).
+struct Runs {
+    u32 valid, cont, head, stop;      // 16-bit masks over the lane's bytes (stop = head | ~valid)
+    u32 head_before;                  // 1 + position of the last head in earlier lanes (0: none, only for lane 0)
+    u32 stop_after;                   // first stop in later lanes, or the number of valid bytes in the chunk
+};
+
+__device__ __forceinline__ Runs find_runs(const Lane &L, u32 lane, u32 chunk_valid)
 {
-    const u32 t = threadIdx.x;
-    const u64 at = chunk0 + (u64)t * kBytesPerThread;
-    const int cnt = at >= n ? 0 : (at + 4 <= n ? 4 : (int)(n - at));
-    u32 w = 0;
-    if (cnt == 4) {
-        __builtin_memcpy(&w, src + at, 4);
-    } else {
-        for (int i = 0; i < cnt; ++i) w |= (u32)src[at + i] << (8 * i);
+    Runs R;
+    R.valid = (1u << L.cnt) - 1u;
+    u32 prev = __shfl_up(L.w[3], 1, 64) >> 24;
+    if (lane == 0) prev = 0x100u;                 // the chunk's first byte never continues
+    u32 cont = 0;
+#pragma unroll
+    for (int i = 0; i < kLaneBytes; ++i) {
+        const u32 b = byte_of(L, i);
+        cont |= (u32)(b == prev) << i;
+        prev = b;
     }
-    const u32 prev = (t > 0 && cnt > 0) ? src[at - 1] : 0x100u;      // the chunk's first byte never continues
-    u32 b[4], cont[4];
+    R.cont = cont & R.valid;
+    R.head = R.valid & ~R.cont;
+    R.stop = (R.head | ~R.valid) & 0xFFFFu;
+    u32 fi = R.head ? kLaneBytes * lane + (31u - (u32)__clz(R.head)) + 1u : 0u;            // inclusive max-scan, forward
+    u32 bi = R.stop ? kLaneBytes * lane + (u32)__builtin_ctz(R.stop) : kNone;                // inclusive min-scan, backward
 #pragma unroll
-    for (int i = 0; i < 4; ++i) b[i] = (w >> (8 * i)) & 255u;
-    cont[0] = cnt > 0 && b[0] == prev;
-#pragma unroll
-    for (int i = 1; i < 4; ++i) cont[i] = i < cnt && b[i] == b[i - 1];
-    // positions inside the chunk: p = 4 t + i.  head(p) = last position <= p that does not continue (exists: position 0);
-    // end(p) = first position > p that does not continue, or the number of valid bytes in the chunk
-    u32 last_head = kNone, first_head = kNone;      // of this thread's positions (kNone: all four continue / are invalid)
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-        if (i < cnt && !cont[i]) {
-            last_head = 4 * t + i;
-            if (first_head == kNone) first_head = 4 * t + i;
-        }
-    // invalid positions (beyond n) end every run: treat the first invalid position as a head for the backward scan
-    const u32 valid_end = cnt < 4 ? 4 * t + cnt : kNone;
-    u32 first_stop = first_head < valid_end ? first_head : valid_end;
-    // exclusive forward max-scan of last_head (kNone = -1: use +1 encoding), exclusive backward min-scan of first_stop
-    u32 fwd = last_head + 1u;      // 0 = none
-    u32 bwd = first_stop;          // kNone = none
-    const u32 lane = t & 63u, wave = t >> 6;
-    u32 fi = fwd, bi = bwd;
     for (int o = 1; o < 64; o <<= 1) {
         const u32 up = __shfl_up(fi, o, 64), dn = __shfl_down(bi, o, 64);
         if ((int)lane >= o) fi = fi > up ? fi : up;
         if ((int)lane + o < 64) bi = bi < dn ? bi : dn;
     }
-    if (lane == 63) lds[wave] = fi;
-    if (lane == 0) lds[4 + wave] = bi;
-    __syncthreads();
-    u32 head_before = __shfl_up(fi, 1, 64);
-    if (lane == 0) head_before = 0;
-    for (u32 wv = 0; wv < wave; ++wv) head_before = head_before > lds[wv] ? head_before : lds[wv];
-    u32 stop_after = __shfl_down(bi, 1, 64);
-    if (lane == 63) stop_after = kNone;
-    for (u32 wv = wave + 1; wv < kPackThreads / 64; ++wv) stop_after = stop_after < lds[4 + wv] ? stop_after : lds[4 + wv];
-    __syncthreads();                 // lds is reused by the caller
-    // walk my four positions
-    Tokens tk;
-    u32 head = head_before;          // +1 encoded position of the latest head before my first byte (0 only for thread 0)
-    // end position for each of my bytes: the next stop after it
-    u32 stop[4];
-    u32 nxt = stop_after;            // first stop strictly after my last position (kNone: none in the chunk)
-    const u32 chunk_valid = (u32)(n - chunk0 < (u64)kChunk ? n - chunk0 : (u64)kChunk);
-    if (nxt == kNone || nxt > chunk_valid) nxt = chunk_valid;
-#pragma unroll
-    for (int i = 3; i >= 0; --i) {
-        stop[i] = nxt;
-        if (i < cnt && !cont[i]) nxt = 4 * t + i;
-        if (i >= cnt) nxt = nxt < 4 * t + (u32)i ? nxt : 4 * t + (u32)i;
-    }
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const u32 p = 4 * t + i;
-        tk.lit[i] = kNone;
-        tk.piece[i] = 0;
-        tk.first[i] = 0;
-        if (i >= cnt) continue;
-        tk.lit[i] = b[i];
-        if (!cont[i]) {
-            head = p + 1;
-            continue;
-        }
-        const u32 k = p - (head - 1);            // >= 1: bytes since the head
-        const u32 rem = stop[i] - p;             // continuing bytes left including this one
-        const u32 o = (k - 1) % 258u;
-        const u32 piece = rem + o;
-        tk.piece[i] = piece < 258u ? piece : 258u;
-        tk.first[i] = o == 0;
-    }
-    return tk;
+    R.head_before = __shfl_up(fi, 1, 64);
+    if (lane == 0) R.head_before = 0;
+    u32 sa = __shfl_down(bi, 1, 64);
+    if (lane == 63 || sa > chunk_valid) sa = chunk_valid;
+    R.stop_after = sa;
+    return R;
 }
 
-// length 3..258 -> length symbol, extra bits (RFC 1951 3.2.5), branch-free enough
+// For the continuing byte i of this lane: with k = bytes since the run's head (>= 1) and rem = continuing bytes left
+// including this one, the run's tail of continuing bytes is cut into pieces of 258; o = (k - 1) % 258 is the byte's
+// offset inside its piece and the piece's length is min(258, rem + o).  The first byte of a piece of >= min_match (>= 3)
+// bytes emits the match, the piece's other bytes nothing; bytes of shorter pieces stay literals.
+__device__ __forceinline__ void run_piece(const Runs &R, u32 lane, int i, u32 &piece, bool &first)
+{
+    const u32 p = kLaneBytes * lane + (u32)i;
+    const u32 below = R.head & ((1u << i) - 1u);
+    const u32 hp = below ? kLaneBytes * lane + (31u - (u32)__clz(below)) : R.head_before - 1u;
+    const u32 above = R.stop >> (i + 1);
+    const u32 sp = above ? p + 1u + (u32)__builtin_ctz(above) : R.stop_after;
+    u32 o = p - hp - 1u;                          // <= 1022
+    o -= 258u * ((u32)(o >= 258u) + (u32)(o >= 516u) + (u32)(o >= 774u));
+    const u32 len = sp - p + o;
+    piece = len < 258u ? len : 258u;
+    first = o == 0u;
+}
+
+// length 3..258 -> length symbol, extra bits (RFC 1951 3.2.5)
 __device__ __forceinline__ void length_symbol(u32 length, u32 &symbol, u32 &extra_bits, u32 &extra)
 {
-    if (length == 258) {
-        symbol = 285;
-        extra_bits = 0;
-        extra = 0;
-        return;
-    }
-    const u32 l = length - 3;                         // 0..254
-    if (l < 8) {
-        symbol = 257 + l;
-        extra_bits = 0;
-        extra = 0;
-        return;
-    }
-    const u32 e = 29 - __clz(l);                      // extra bits: l in [8,16) -> 1, [16,32) -> 2, ...
-    symbol = 257 + 4 * e + 4 + ((l >> e) & 3u);
+    const u32 l = length - 3u;                        // 0..255
+    const u32 e = l < 8u ? 0u : 29u - (u32)__clz(l);  // extra bits: l in [8,16) -> 1, [16,32) -> 2, ...
+    symbol = l < 8u ? 257u + l : 257u + 4u * e + 4u + ((l >> e) & 3u);
     extra_bits = e;
     extra = l & ((1u << e) - 1u);
+    if (length == 258u) {
+        symbol = 285u;
+        extra_bits = 0;
+        extra = 0;
+    }
 }
 
 // pass 1: histograms of the literal / length symbols the tokens use, for each candidate match threshold at once (a short
@@ -358,45 +339,63 @@ __device__ __forceinline__ void length_symbol(u32 length, u32 &symbol, u32 &extr
 // the host from the exact stream sizes the histograms imply).  A byte's token is the same under every candidate unless
 // it lies in a run piece of kMatchThreshold[0] .. kMatchThreshold[last] - 1 bytes: those go to a per-candidate histogram,
 // everything else to ONE common histogram (slot kMatchThresholds) that the host adds to each.
-__global__ __launch_bounds__(kPackThreads) void k_token_hist(const u8 *__restrict__ src, u64 n, unsigned long long *__restrict__ hist)
+__global__ __launch_bounds__(kPackThreads) void k_token_hist(const u8 *__restrict__ src, u64 n, u64 stride, u32 nchunks,
+                                                         unsigned long long *__restrict__ hist)
 {
     constexpr int kCopies = 4, kHists = kMatchThresholds + 1;
-    __shared__ u32 scan[16];
     __shared__ u32 h[kHists][kDeflateSymbols * kCopies];      // copies value-major (a handful of symbols dominate)
     for (int i = threadIdx.x; i < kHists * kDeflateSymbols * kCopies; i += kPackThreads) (&h[0][0])[i] = 0;
     __syncthreads();
-    const u32 copy = threadIdx.x & (kCopies - 1);
-    auto add = [&](int which, u32 s) {
-        u32 sym = s;
-        if (s & 0x80000000u) {
-            u32 eb, ex;
-            length_symbol(s & 0xFFFFu, sym, eb, ex);
-        }
-        atomicAdd(&h[which][sym * kCopies + copy], 1u);
+    src += (u64)blockIdx.y * stride;
+    hist += (u64)blockIdx.y * (kHists * kDeflateSymbols);
+    const u32 lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const u32 copy = lane & (kCopies - 1);
+    u32 zeros = 0;                                            // literal zeros are most of a residual grid: counted privately
+    auto add = [&](int which, u32 sym) { atomicAdd(&h[which][sym * kCopies + copy], 1u); };
+    auto add_match = [&](int which, u32 length) {
+        u32 sym, eb, ex;
+        length_symbol(length, sym, eb, ex);
+        add(which, sym);
     };
-    for (u64 chunk = blockIdx.x; chunk * kChunk < n; chunk += gridDim.x) {
-        const Tokens tk = tokens_of_thread(src, n, chunk * kChunk, scan);
+    const u32 step = gridDim.x * kWaves;
+    u32 chunk = blockIdx.x * kWaves + wave;
+    Lane cur = {};
+    if (chunk < nchunks) cur = load_lane(src, n, (u64)chunk * kChunk, lane);
+    while (chunk < nchunks) {
+        const u32 next = chunk + step;
+        Lane nxt = {};
+        if (next < nchunks) nxt = load_lane(src, n, (u64)next * kChunk, lane);
+        const u64 left = n - (u64)chunk * kChunk;
+        const Runs R = find_runs(cur, lane, left < (u64)kChunk ? (u32)left : (u32)kChunk);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const bool valid = tk.lit[i] != kNone;
-            const bool common = tk.piece[i] < kMatchThreshold[0] || tk.piece[i] >= kMatchThreshold[kMatchThresholds - 1];
-            const u32 s = token_symbol(tk, i, kMatchThreshold[0]);       // what every candidate emits when `common`
-            // literal zeros are most of a residual grid: count them per wave with a ballot, one add per wave
-            const unsigned long long zeros = __ballot(valid && common && s == 0u);
-            if (zeros && (threadIdx.x & 63u) == (u32)__ffsll((long long)zeros) - 1u)
-                atomicAdd(&h[kMatchThresholds][0 * kCopies + copy], (u32)__popcll(zeros));
-            if (!valid) continue;
-            if (common) {
-                if (s != kNone && s != 0u) add(kMatchThresholds, s);
-                continue;
-            }
+        for (int i = 0; i < kLaneBytes; ++i) {
+            if (!((R.valid >> i) & 1u)) continue;
+            const u32 b = byte_of(cur, i);
+            u32 piece = 0;
+            bool first = false;
+            if ((R.cont >> i) & 1u) run_piece(R, lane, i, piece, first);
+            if (piece < kMatchThreshold[0]) {                       // a literal under every candidate
+                if (b == 0u)
+                    ++zeros;
+                else
+                    add(kMatchThresholds, b);
+            } else if (piece >= kMatchThreshold[kMatchThresholds - 1]) {      // a match under every candidate
+                if (first) add_match(kMatchThresholds, piece);
+            } else {
 #pragma unroll
-            for (int v = 0; v < kMatchThresholds; ++v) {
-                const u32 sv = token_symbol(tk, i, kMatchThreshold[v]);
-                if (sv != kNone) add(v, sv);
+                for (int v = 0; v < kMatchThresholds; ++v) {
+                    if (piece >= kMatchThreshold[v]) {
+                        if (first) add_match(v, piece);
+                    } else {
+                        add(v, b);
+                    }
+                }
             }
         }
+        cur = nxt;
+        chunk = next;
     }
+    if (zeros) atomicAdd(&h[kMatchThresholds][copy], zeros);
     __syncthreads();
     for (int i = threadIdx.x; i < kHists * kDeflateSymbols; i += kPackThreads) {
         const int v = i / kDeflateSymbols, sym = i - v * kDeflateSymbols;
@@ -407,58 +406,87 @@ __global__ __launch_bounds__(kPackThreads) void k_token_hist(const u8 *__restric
     }
 }
 
-// the bits of this thread's tokens (table[s] = reversed code | length << 16 for the 286 symbols; dist = the one distance
-// code used, same packing): at most 3 x 15 + (15 + 5 + 1) = 66 bits in 4 bytes -> a 128-bit accumulator
-__device__ __forceinline__ void pack_tokens(const Tokens &tk, u32 min_match, const u32 *stab, u32 dist, unsigned __int128 &val, u32 &bits)
+// tok[i] = bits << 24 | code of what byte i emits under the frame's code (0: nothing).  A match is its length code, the
+// length's extra bits and the one distance code: <= 15 + 5 + 1 bits.
+__device__ __forceinline__ u32 lane_tokens(const Lane &L, const Runs &R, u32 lane, u32 min_match, const u32 *stab, u32 dist, u32 tok[kLaneBytes])
 {
-    val = 0;
-    bits = 0;
+    u32 bits = 0;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const u32 s = token_symbol(tk, i, min_match);
-        if (s == kNone) continue;
-        if (s & 0x80000000u) {
+    for (int i = 0; i < kLaneBytes; ++i) {
+        tok[i] = 0;
+        if (!((R.valid >> i) & 1u)) continue;
+        u32 piece = 0;
+        bool first = false;
+        if ((R.cont >> i) & 1u) run_piece(R, lane, i, piece, first);
+        u32 code, nb;
+        if (piece >= min_match) {
+            if (!first) continue;
             u32 sym, eb, ex;
-            length_symbol(s & 0xFFFFu, sym, eb, ex);
+            length_symbol(piece, sym, eb, ex);
             const u32 e = stab[sym];
-            val |= (unsigned __int128)(e & 0xFFFFu) << bits;
-            bits += e >> 16;
-            val |= (unsigned __int128)ex << bits;
-            bits += eb;
-            val |= (unsigned __int128)(dist & 0xFFFFu) << bits;
-            bits += dist >> 16;
+            code = e & 0xFFFFu;
+            nb = e >> 16;
+            code |= ex << nb;
+            nb += eb;
+            code |= (dist & 0xFFFFu) << nb;
+            nb += dist >> 16;
         } else {
-            const u32 e = stab[s];
-            val |= (unsigned __int128)(e & 0xFFFFu) << bits;
-            bits += e >> 16;
+            const u32 e = stab[byte_of(L, i)];
+            code = e & 0xFFFFu;
+            nb = e >> 16;
         }
+        tok[i] = code | (nb << 24);
+        bits += nb;
     }
+    return bits;
 }
 
 // pass 2: bits per chunk
-__global__ __launch_bounds__(kPackThreads) void k_token_count(const u8 *__restrict__ src, u64 n, const u32 *__restrict__ table, u32 dist,
-                                                              u32 min_match, u32 *__restrict__ chunk_bits)
+__global__ __launch_bounds__(kPackThreads) void k_token_count(const u8 *__restrict__ src, u64 n, u64 stride, u32 nchunks,
+                                                          const DeflatePlan *__restrict__ plans, u32 dist, u32 *__restrict__ chunk_bits)
 {
     __shared__ u32 stab[kDeflateSymbols];
-    __shared__ u32 scan[16];
-    __shared__ u32 wsum[kPackThreads / 64];
-    for (int i = threadIdx.x; i < kDeflateSymbols; i += kPackThreads) stab[i] = table[i];
-    const Tokens tk = tokens_of_thread(src, n, (u64)blockIdx.x * kChunk, scan);      // (its barriers publish stab too)
-    unsigned __int128 val;
-    u32 bits;
-    pack_tokens(tk, min_match, stab, dist, val, bits);
-    for (int o = 32; o > 0; o >>= 1) bits += __shfl_down(bits, o, 64);
-    if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = bits;
+    const DeflatePlan &plan = plans[blockIdx.y];
+    for (int i = threadIdx.x; i < kDeflateSymbols; i += kPackThreads) stab[i] = plan.table[i];
+    const u32 min_match = plan.min_match;
     __syncthreads();
-    if (threadIdx.x == 0) chunk_bits[blockIdx.x] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+    src += (u64)blockIdx.y * stride;
+    chunk_bits += (u64)blockIdx.y * nchunks;
+    const u32 lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const u32 step = gridDim.x * kWaves;
+    u32 chunk = blockIdx.x * kWaves + wave;
+    Lane cur = {};
+    if (chunk < nchunks) cur = load_lane(src, n, (u64)chunk * kChunk, lane);
+    while (chunk < nchunks) {
+        const u32 next = chunk + step;
+        Lane nxt = {};
+        if (next < nchunks) nxt = load_lane(src, n, (u64)next * kChunk, lane);
+        const u64 left = n - (u64)chunk * kChunk;
+        const Runs R = find_runs(cur, lane, left < (u64)kChunk ? (u32)left : (u32)kChunk);
+        u32 tok[kLaneBytes];
+        u32 bits = lane_tokens(cur, R, lane, min_match, stab, dist, tok);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) bits += __shfl_down(bits, o, 64);
+        if (lane == 0) chunk_bits[chunk] = bits;
+        cur = nxt;
+        chunk = next;
+    }
 }
 
-// exclusive scan of the chunk sizes into bit offsets; one workgroup walks the chunks 1024 at a time (coalesced reads and
-// writes; shuffle scan inside each wave, the sixteen wave totals through LDS, a running total carried between blocks)
+// exclusive scan of a frame's chunk sizes into bit offsets (grid.x = the frame); one workgroup walks the chunks 1024 at a
+// time (coalesced reads and writes; shuffle scan inside each wave, the sixteen wave totals through LDS, a running total
+// carried between blocks).  It also clears the stream's words in which a chunk starts or the tokens end: those are the
+// words two writers share in pass 3 (they OR into them); every other word has one owner who stores it whole, so the
+// stream needs no clearing beyond this.
 __global__ __launch_bounds__(1024) void k_huff_scan(const u32 *__restrict__ chunk_bits, u64 *__restrict__ chunk_off, u32 nchunks,
-                                                    u64 *__restrict__ total)
+                                                    u64 *__restrict__ totals, const DeflatePlan *__restrict__ plans, u8 *__restrict__ outs,
+                                                    u64 out_stride)
 {
     __shared__ u64 wtot[16];
+    chunk_bits += (u64)blockIdx.x * nchunks;
+    chunk_off += (u64)blockIdx.x * nchunks;
+    u32 *out = reinterpret_cast<u32 *>(outs + (u64)blockIdx.x * out_stride);
+    const u64 base = plans[blockIdx.x].base_bits;
     const u32 lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     u64 carry = 0;                      // every thread keeps its own copy of the running total
     constexpr u32 kAhead = 8;           // blocks of 1024 whose loads are issued together (the loop is a latency chain otherwise)
@@ -485,93 +513,170 @@ __global__ __launch_bounds__(1024) void k_huff_scan(const u32 *__restrict__ chun
                 before += wv < wave ? t : 0;
                 all += t;
             }
-            if (i < nchunks) chunk_off[i] = carry + before + incl - mine[k];
+            if (i < nchunks) {
+                const u64 off = carry + before + incl - mine[k];
+                chunk_off[i] = off;
+                out[(base + off) >> 5] = 0;
+            }
             carry += all;
             __syncthreads();            // wtot is rewritten by the next block
         }
     }
-    if (threadIdx.x == 0) *total = carry;
+    if (threadIdx.x == 0) {
+        totals[blockIdx.x] = carry;
+        out[(base + carry) >> 5] = 0;
+    }
 }
 
-// pass 3: the chunk's tokens are OR-ed into an LDS image of the chunk's part of the stream (<= 1024 x 21 bits), which then
-// goes out as whole words -- plain coalesced stores for the words the chunk owns alone, atomicOr only for its first and
-// last word, which it shares with its neighbours (the stream was zeroed)
-__global__ __launch_bounds__(kPackThreads) void k_token_pack(const u8 *__restrict__ src, u64 n, const u32 *__restrict__ table, u32 dist,
-                                                             u32 min_match, const u64 *__restrict__ chunk_off, u64 base_bits,
-                                                             u32 *__restrict__ out)
+// pass 3: a wave ORs its chunk's tokens into an LDS image of the chunk's part of the stream (<= 1024 x 15 bits), which
+// then goes out as whole words -- plain coalesced stores for the words the chunk owns alone, atomicOr for its first word
+// and, when the next chunk starts inside it, its last (k_huff_scan cleared exactly those).  The frame's first workgroup
+// also writes what precedes the tokens, the wave that codes the last chunk what follows them: the stream leaves the
+// device complete.
+__global__ __launch_bounds__(kPackThreads) void k_token_pack(const u8 *__restrict__ src, u64 n, u64 stride, u32 nchunks,
+                                                         const DeflatePlan *__restrict__ plans, u32 dist, const u64 *__restrict__ chunk_off,
+                                                         u8 *__restrict__ outs, u64 out_stride)
 {
-    constexpr int kWords = (kChunk * 21 + 31) / 32 + 3;      // worst case: every byte a 15-bit literal; matches are rarer
+    constexpr int kWords = (kChunk * 15 + 31) / 32 + 4;      // every byte a 15-bit literal (a match spends 21 bits on >= 3 bytes)
     __shared__ u32 stab[kDeflateSymbols];
-    __shared__ u32 scan[16];
-    __shared__ u32 wsum[kPackThreads / 64];
-    __shared__ u32 img[kWords];
-    for (int i = threadIdx.x; i < kDeflateSymbols; i += kPackThreads) stab[i] = table[i];
-    for (int i = threadIdx.x; i < kWords; i += kPackThreads) img[i] = 0;
-    const Tokens tk = tokens_of_thread(src, n, (u64)blockIdx.x * kChunk, scan);      // (its barriers publish stab and img)
-    unsigned __int128 val;
-    u32 bits;
-    pack_tokens(tk, min_match, stab, dist, val, bits);
-    // exclusive scan of `bits` over the workgroup: inside the wave by shuffles, across the four waves through LDS
-    u32 incl = bits;
+    __shared__ u32 imgs[kWaves][kWords];
+    const DeflatePlan &plan = plans[blockIdx.y];
+    for (int i = threadIdx.x; i < kDeflateSymbols; i += kPackThreads) stab[i] = plan.table[i];
+    for (int i = threadIdx.x; i < kWaves * kWords; i += kPackThreads) (&imgs[0][0])[i] = 0;
+    const u32 min_match = plan.min_match;
+    const u64 base = plan.base_bits;
+    __syncthreads();
+    src += (u64)blockIdx.y * stride;
+    chunk_off += (u64)blockIdx.y * nchunks;
+    u32 *out = reinterpret_cast<u32 *>(outs + (u64)blockIdx.y * out_stride);
     const u32 lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-    for (int o = 1; o < 64; o <<= 1) {
-        const u32 up = __shfl_up(incl, o, 64);
-        if ((int)lane >= o) incl += up;
-    }
-    if (lane == 63) wsum[wave] = incl;
-    __syncthreads();
-    u32 before = incl - bits;
-    for (u32 wv = 0; wv < wave; ++wv) before += wsum[wv];
-    const u32 chunk_total = wsum[0] + wsum[1] + wsum[2] + wsum[3];
-    const u64 pos0 = base_bits + chunk_off[blockIdx.x];      // the chunk's first bit in the stream
-    const u32 sh0 = (u32)(pos0 & 31u);                       // ... and where that is inside its first word
-    if (bits) {
-        const u32 at = sh0 + before, sh = at & 31u;
-        const unsigned __int128 shifted = val << sh;          // <= 66 + 31 bits
-        const u32 o0 = (u32)shifted, o1 = (u32)(shifted >> 32), o2 = (u32)(shifted >> 64), o3 = (u32)(shifted >> 96);
-        u32 *dst = img + (at >> 5);
-        if (o0) atomicOr(dst, o0);
-        if (o1) atomicOr(dst + 1, o1);
-        if (o2) atomicOr(dst + 2, o2);
-        if (o3) atomicOr(dst + 3, o3);
-    }
-    __syncthreads();
-    if (!chunk_total) return;
-    const u32 nwords = (sh0 + chunk_total + 31u) >> 5;
-    u32 *dst = out + (pos0 >> 5);
-    for (u32 w = threadIdx.x; w < nwords; w += kPackThreads) {
-        const u32 v = img[w];
-        if (w == 0 || w == nwords - 1) {
-            if (v) atomicOr(dst + w, v);
-        } else {
-            dst[w] = v;
+    u32 *img = imgs[wave];
+    if (blockIdx.x == 0 && wave == 0) {
+        // the front: whole words are this wave's alone; the word the tokens start in is shared with the first chunk
+        const u32 own = (u32)(base >> 5);
+        for (u32 w = lane; 4 * w < plan.front_bytes; w += 64) {
+            u32 v;
+            __builtin_memcpy(&v, plan.front + 4 * w, 4);
+            if (w < own)
+                out[w] = v;
+            else if (v)
+                atomicOr(out + w, v);
         }
     }
+    const u32 step = gridDim.x * kWaves;
+    u32 chunk = blockIdx.x * kWaves + wave;
+    Lane cur = {};
+    u64 off = 0;
+    if (chunk < nchunks) {
+        cur = load_lane(src, n, (u64)chunk * kChunk, lane);
+        off = chunk_off[chunk];
+    }
+    while (chunk < nchunks) {
+        const u32 next = chunk + step;
+        Lane nxt = {};
+        u64 off_next = 0;
+        if (next < nchunks) {
+            nxt = load_lane(src, n, (u64)next * kChunk, lane);
+            off_next = chunk_off[next];
+        }
+        const u64 left = n - (u64)chunk * kChunk;
+        const Runs R = find_runs(cur, lane, left < (u64)kChunk ? (u32)left : (u32)kChunk);
+        u32 tok[kLaneBytes];
+        const u32 bits = lane_tokens(cur, R, lane, min_match, stab, dist, tok);
+        u32 incl = bits;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const u32 up = __shfl_up(incl, o, 64);
+            if ((int)lane >= o) incl += up;
+        }
+        const u32 chunk_total = __shfl(incl, 63, 64);
+        const u64 pos0 = base + off;                             // the chunk's first bit in the stream
+        const u32 sh0 = (u32)(pos0 & 31u);                       // ... and where that is inside its first word
+        {
+            const u32 at = sh0 + incl - bits;
+            u32 wi = at >> 5, nb = at & 31u;
+            u64 acc = 0;
+#pragma unroll
+            for (int i = 0; i < kLaneBytes; ++i) {
+                const u32 t = tok[i];
+                if (!t) continue;
+                acc |= (u64)(t & 0xFFFFFFu) << nb;
+                nb += t >> 24;
+                if (nb >= 32u) {
+                    atomicOr(img + wi, (u32)acc);
+                    ++wi;
+                    acc >>= 32;
+                    nb -= 32u;
+                }
+            }
+            if (acc) atomicOr(img + wi, (u32)acc);
+        }
+        WAVE_LDS_ORDER();
+        const u32 nwords = (sh0 + chunk_total + 31u) >> 5;
+        const bool last_shared = ((sh0 + chunk_total) & 31u) != 0u;
+        u32 *dst = out + (pos0 >> 5);
+        for (u32 w = lane; w < nwords; w += 64) {
+            const u32 v = img[w];
+            img[w] = 0;
+            if (w == 0 || (w == nwords - 1 && last_shared)) {
+                if (v) atomicOr(dst + w, v);
+            } else {
+                dst[w] = v;
+            }
+        }
+        WAVE_LDS_ORDER();
+        if (chunk == nchunks - 1 && lane < 6) {
+            // what follows the tokens: its first word is shared with the last chunk (or was cleared), the rest is new
+            const u64 end = pos0 + chunk_total;
+            const u32 sh = (u32)(end & 31u);
+            const u32 hi = lane < 5 ? plan.tail[lane] : 0u, lo = lane ? plan.tail[lane - 1] : 0u;
+            const u32 v = (u32)((((u64)hi << 32) | lo) >> (32u - sh));
+            u32 *t = out + (end >> 5) + lane;
+            if (lane == 0) {
+                if (v) atomicOr(t, v);
+            } else if (32u * lane < sh + plan.tail_bits) {
+                *t = v;
+            }
+        }
+        cur = nxt;
+        off = off_next;
+        chunk = next;
+    }
+}
+
+u32 blocks_for(u32 nchunks, u32 frames)
+{
+    // enough workgroups to fill the device (256 CUs x 8) over all frames, and no more than there are chunks
+    const u32 per_frame_max = (nchunks + kWaves - 1) / kWaves;
+    u32 b = (2048 + frames - 1) / frames;
+    if (b > per_frame_max) b = per_frame_max;
+    return b ? b : 1;
 }
 
 }  // namespace
 
 u32 huffman_chunks(u64 n) { return (u32)((n + kChunk - 1) / kChunk); }
 
-hipError_t launch_token_histogram(const uint8_t *src, uint64_t n, unsigned long long *d_hist, hipStream_t s)
+hipError_t launch_token_histogram(const uint8_t *src, uint64_t n, uint64_t stride, uint32_t frames, unsigned long long *d_hist, hipStream_t s)
 {
-    hipError_t e = hipMemsetAsync(d_hist, 0, (kMatchThresholds + 1) * kDeflateSymbols * sizeof(unsigned long long), s);
-    if (e != hipSuccess || n == 0) return e;
-    u32 blocks = huffman_chunks(n);
-    if (blocks > 4096) blocks = 4096;
-    hipLaunchKernelGGL(k_token_hist, dim3(blocks), dim3(kPackThreads), 0, s, src, n, d_hist);
+    hipError_t e = hipMemsetAsync(d_hist, 0, (size_t)frames * (kMatchThresholds + 1) * kDeflateSymbols * sizeof(unsigned long long), s);
+    if (e != hipSuccess || n == 0 || frames == 0) return e;
+    const u32 nchunks = huffman_chunks(n);
+    hipLaunchKernelGGL(k_token_hist, dim3(blocks_for(nchunks, frames), frames), dim3(kPackThreads), 0, s, src, n, stride, nchunks, d_hist);
     return hipGetLastError();
 }
 
-hipError_t launch_huffman_pack(const uint8_t *src, uint64_t n, const uint32_t *d_table, uint32_t dist_code, uint32_t min_match,
-                               uint32_t *d_chunk_bits, uint64_t *d_chunk_off, uint64_t *d_total, uint64_t base_bits, uint32_t *d_out,
+hipError_t launch_huffman_pack(const uint8_t *src, uint64_t n, uint64_t stride, uint32_t frames, const void *d_plans, uint32_t dist_code,
+                               uint32_t *d_chunk_bits, uint64_t *d_chunk_off, uint64_t *d_totals, uint8_t *d_outs, uint64_t out_stride,
                                hipStream_t s)
 {
     const u32 nchunks = huffman_chunks(n);
-    if (nchunks == 0) return hipSuccess;
-    hipLaunchKernelGGL(k_token_count, dim3(nchunks), dim3(kPackThreads), 0, s, src, n, d_table, dist_code, min_match, d_chunk_bits);
-    hipLaunchKernelGGL(k_huff_scan, dim3(1), dim3(1024), 0, s, d_chunk_bits, d_chunk_off, nchunks, d_total);
-    hipLaunchKernelGGL(k_token_pack, dim3(nchunks), dim3(kPackThreads), 0, s, src, n, d_table, dist_code, min_match, d_chunk_off, base_bits, d_out);
+    if (nchunks == 0 || frames == 0) return hipSuccess;
+    const DeflatePlan *plans = static_cast<const DeflatePlan *>(d_plans);
+    const dim3 grid(blocks_for(nchunks, frames), frames);
+    hipLaunchKernelGGL(k_token_count, grid, dim3(kPackThreads), 0, s, src, n, stride, nchunks, plans, dist_code, d_chunk_bits);
+    hipLaunchKernelGGL(k_huff_scan, dim3(frames), dim3(1024), 0, s, d_chunk_bits, d_chunk_off, nchunks, d_totals, plans, d_outs, out_stride);
+    hipLaunchKernelGGL(k_token_pack, grid, dim3(kPackThreads), 0, s, src, n, stride, nchunks, plans, dist_code, d_chunk_off, d_outs, out_stride);
     return hipGetLastError();
 }
 

@@ -90,16 +90,32 @@ size_t huffman_plan(const uint64_t hist[kDeflateSymbols], uint8_t lens[kDeflateS
                     uint8_t *header, size_t header_cap);
 void deflate_length_symbol(uint32_t length, uint32_t *symbol, uint32_t *extra_bits, uint32_t *extra);
 uint64_t huffman_payload_bits(const uint64_t hist[kDeflateSymbols]);      // token bits under the best code, header excluded
-// device, pass 1: d_hist[kMatchThresholds + 1][kDeflateSymbols] = how often the tokens of src[0..n) use each symbol (runs ->
-// distance-1 matches, cut at 1 KiB chunk boundaries): slot v < kMatchThresholds counts the tokens that depend on the
-// candidate threshold v, slot kMatchThresholds those that do not -- the histogram of candidate v is the sum of the two
-hipError_t launch_token_histogram(const uint8_t *src, uint64_t n, unsigned long long *d_hist, hipStream_t s);
-// device, passes 2 + 3: the tokens' codes OR-ed into the zeroed stream d_out from bit `base_bits` on (table[s] = reversed
-// code | length << 16; dist_code likewise for the one distance code); *d_total = their bits.  Scratch:
-// huffman_chunks(n) u32 + as many u64.
+// What the host hands each frame's passes 2 and 3 (one upload for a whole group of frames): the code, the chosen
+// threshold, the bytes in front of the grid's tokens and the bits behind them.
+constexpr size_t kPlanBytes = 2048;
+struct DeflatePlan {
+    uint32_t table[kDeflateSymbols];      // reversed code | length << 16
+    uint32_t min_match;
+    uint32_t front_bytes;                 // block header + the eight literals of the u64 length: ceil(base_bits / 8)
+    uint64_t base_bits;                   // where the grid's tokens start
+    uint32_t tail_bits;                   // the eight literals of the u64 width + end of block: <= 9 x 15 bits
+    uint32_t tail[5];
+    uint32_t reserved[6];
+    uint8_t front[kPlanBytes - 1208];     // zero padded
+};
+static_assert(sizeof(DeflatePlan) == kPlanBytes, "plan block layout");
+// device, pass 1, for `frames` grids `stride` bytes apart: d_hist[frame][kMatchThresholds + 1][kDeflateSymbols] = how often
+// the tokens of the frame's n bytes use each symbol (runs -> distance-1 matches, cut at 1 KiB chunk boundaries): slot
+// v < kMatchThresholds counts the tokens that depend on the candidate threshold v, slot kMatchThresholds those that do
+// not -- the histogram of candidate v is the sum of the two
+hipError_t launch_token_histogram(const uint8_t *src, uint64_t n, uint64_t stride, uint32_t frames, unsigned long long *d_hist,
+                                  hipStream_t s);
+// device, passes 2 + 3: each frame's complete stream (front, tokens, tail) written to d_outs + frame * out_stride, which
+// need not be cleared (dist_code = reversed code | length << 16 of the one distance code); d_totals[frame] = the tokens'
+// bits.  Scratch: frames * huffman_chunks(n) u32 + as many u64.
 uint32_t huffman_chunks(uint64_t n);
-hipError_t launch_huffman_pack(const uint8_t *src, uint64_t n, const uint32_t *d_table, uint32_t dist_code, uint32_t min_match,
-                               uint32_t *d_chunk_bits, uint64_t *d_chunk_off, uint64_t *d_total, uint64_t base_bits, uint32_t *d_out,
+hipError_t launch_huffman_pack(const uint8_t *src, uint64_t n, uint64_t stride, uint32_t frames, const void *d_plans, uint32_t dist_code,
+                               uint32_t *d_chunk_bits, uint64_t *d_chunk_off, uint64_t *d_totals, uint8_t *d_outs, uint64_t out_stride,
                                hipStream_t s);
 
 }  // namespace hgi

@@ -21,9 +21,12 @@ def length_symbol(length):
     return 257 + s, LBITS[s], length - LBASE[s]
 
 
-def tokens(data):
+THRESHOLDS = (3, 4, 6, 10)          # kMatchThresholdHost (rustyhgi_amd/csrc/hgi_kernels.h)
+
+
+def tokens(data, min_match=3):
     """Literal bytes and ('m', length) run matches: a byte equal to its predecessor inside its 1 KiB chunk continues a
-    run; the run's bytes after its head are cut into pieces of 258, pieces of >= 3 become matches of distance 1."""
+    run; the run's bytes after its head are cut into pieces of 258, pieces of >= min_match become matches of distance 1."""
     out = []
     for c0 in range(0, len(data), CHUNK):
         chunk = data[c0:c0 + CHUNK]
@@ -36,7 +39,7 @@ def tokens(data):
             m = j - i - 1                        # continuing bytes
             while m > 0:
                 piece = min(m, 258)
-                if piece >= 3:
+                if piece >= min_match:
                     out.append(("m", piece))
                 else:
                     out.extend([chunk[i]] * piece)
@@ -106,6 +109,38 @@ def roundtrip(data):
     return len(stream)
 
 
+def token_bits(toks, lens):
+    total = 0
+    for t in toks:
+        if isinstance(t, tuple):
+            sym, eb, _ = length_symbol(t[1])
+            total += int(lens[sym]) + eb + 1
+        else:
+            total += int(lens[t])
+    return total
+
+
+def stage_stream(grid_bytes, width):
+    """The whole stream the entropy stage writes for a grid, restated: the grid's tokens under each candidate threshold,
+    the code each histogram asks for, the smallest payload wins (first on a tie); around the tokens the eight literals of
+    the u64 length and of the u64 width (never part of a run), then end of block."""
+    import struct
+    grid_bytes = bytes(grid_bytes)
+    prefix, suffix = list(struct.pack("<Q", len(grid_bytes))), list(struct.pack("<Q", width))
+    best = None
+    for mm in THRESHOLDS:
+        toks = prefix + tokens(grid_bytes, mm) + suffix
+        hist = histogram(toks)
+        lens, codes, header, bits = plan(hist)
+        payload = token_bits(toks + [256], lens)
+        if best is None or payload < best[0]:
+            best = (payload, toks, lens, codes, header, bits)
+        if not grid_bytes:
+            break
+    _, toks, lens, codes, header, bits = best
+    return pack(toks, lens, codes, header, bits)
+
+
 def zlib_size(data, strategy):
     co = zlib.compressobj(9, zlib.DEFLATED, -15, 9, strategy)
     return len(co.compress(data) + co.flush())
@@ -173,3 +208,14 @@ def test_plan_rejects_bad_arguments():
     z[256] = 1
     assert L.hgi_huffman_plan(z.ctypes.data, lens.ctypes.data, codes.ctypes.data, header.ctypes.data, 2, ctypes.byref(bits)) == _ffi.EINVAL
     assert L.hgi_huffman_plan(None, lens.ctypes.data, codes.ctypes.data, header.ctypes.data, 640, ctypes.byref(bits)) == _ffi.EINVAL
+
+
+def test_restated_stage_stream_is_ordinary_deflate():
+    """stage_stream (what the GPU tests compare the device's bytes with) inflates to the grid's bincode image, and its
+    adaptive threshold never loses to the fixed one."""
+    import struct
+    rng = np.random.default_rng(11)
+    for w, h in ((64, 40), (259, 9), (1, 1), (5, 0)):
+        data = (rng.geometric(0.5, w * h) - 1).astype(np.uint8).tobytes() if w * h else b""
+        s = stage_stream(data, w)
+        assert zlib.decompressobj(-15).decompress(s) == struct.pack("<Q", w * h) + data + struct.pack("<Q", w)

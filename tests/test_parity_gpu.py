@@ -912,3 +912,58 @@ def test_device_entropy_stage_batch(H, oracle, lena):
         assert zlib.decompressobj(-15).decompress(streams[f]) == body, f
         assert streams[f] == entropy.deflate_grid(d[f]), f
     assert len(streams[3]) < 200          # an all-zero grid: a few run matches per KiB chunk
+
+
+def _run_structured(rng, n, max_run, nvalues):
+    """bytes in runs of 1..max_run of values drawn from a skewed distribution: exercises every match threshold"""
+    out = np.empty(n + max_run, np.uint8)
+    at = 0
+    while at < n:
+        r = int(rng.integers(1, max_run + 1))
+        out[at:at + r] = min(int(rng.geometric(0.35)) - 1, nvalues - 1)
+        at += r
+    return out[:n]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", ["lena", "runs12", "runs40", "runs700", "zeros", "ones", "noise", "ragged", "one_byte", "fifteen", "kib_plus_one",
+                                  "two_values"])
+def test_device_entropy_stream_equals_the_restated_one(H, oracle, lena, case):
+    """Byte for byte: the stream hgi_deflate_grid_dev writes is the one tests/test_entropy.py's restatement of the rule
+    (tokens per 1 KiB chunk, threshold by exact payload size, canonical code from hgi_huffman_plan) packs -- run lengths
+    around every candidate threshold, runs crossing lanes, chunks and the 258-byte piece limit, sizes that end inside
+    a lane."""
+    import struct
+    import zlib
+    import torch
+    from rustyhgi_amd import entropy
+    from test_entropy import stage_stream
+    rng = np.random.default_rng(SEED0 + 77)
+    if case == "lena":
+        grid = oracle.encode(lena[:96, :160].copy(), 3, oracle.linear_lut(2)[0])
+    elif case.startswith("runs"):
+        m = int(case[4:])
+        grid = _run_structured(rng, 200 * 123, m, 5 if m < 100 else 3).reshape(123, 200)
+    elif case == "zeros":
+        grid = np.zeros((70, 300), np.uint8)
+    elif case == "ones":
+        grid = np.full((37, 259), 1, np.uint8)
+    elif case == "noise":
+        grid = rng.integers(0, 256, (64, 200), dtype=np.uint8)
+    elif case == "ragged":
+        grid = _run_structured(rng, 61 * 107, 9, 4).reshape(61, 107)
+    elif case == "one_byte":
+        grid = np.full((1, 1), 7, np.uint8)
+    elif case == "fifteen":
+        grid = np.zeros((3, 5), np.uint8)
+    elif case == "kib_plus_one":
+        grid = np.zeros((1, 1025), np.uint8)
+    else:
+        grid = (rng.integers(0, 8, (90, 90)) == 0).astype(np.uint8) * 255
+    grid = np.ascontiguousarray(grid)
+    h, w = grid.shape
+    got = entropy.deflate_grid(torch.from_numpy(grid).cuda())
+    want = stage_stream(grid.tobytes(), w)
+    assert zlib.decompressobj(-15).decompress(got) == struct.pack("<Q", w * h) + grid.tobytes() + struct.pack("<Q", w)
+    assert got == want, (len(got), len(want))
+
