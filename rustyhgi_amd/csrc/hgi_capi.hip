@@ -6,6 +6,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <cstring>
+#include <thread>
 #include <vector>
 
 #include "../../include/hgi.h"
@@ -57,6 +58,8 @@ struct hgi_ctx {
     hipEvent_t ev_up[3], ev_free[3];
     hipEvent_t ev_band[16];   // banded single-frame calls: "band uploaded"
     bool have_pipe;
+    uint8_t *pin;             // pinned host memory (entropy stage: histograms and stream sizes come down without stalling the host)
+    size_t pin_bytes;
 };
 
 namespace {
@@ -311,6 +314,8 @@ hgi_status hgi_ctx_create(int device, hgi_ctx **out)
     c->ws = nullptr;
     c->ws_bytes = c->ws_used = 0;
     c->have_pipe = false;
+    c->pin = nullptr;
+    c->pin_bytes = 0;
     if (hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess) {
         delete c;
@@ -327,6 +332,7 @@ void hgi_ctx_destroy(hgi_ctx *c)
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
     if (c->ws) (void)hipFree(c->ws);
+    if (c->pin) (void)hipHostFree(c->pin);
     (void)hipEventDestroy(c->ev0);
     (void)hipEventDestroy(c->ev1);
     (void)hipStreamDestroy(c->own_stream);
@@ -779,7 +785,8 @@ DeflateGeom deflate_geom(uint64_t n, size_t batch)
     g.n = n;
     g.nchunks = huffman_chunks(n);
     g.dev_cap = align_up((size_t)(n + n / 4) + 4096, 256);      // an optimal code averages < 9 bits per byte
-    size_t group = ((size_t)1 << 30) / g.dev_cap;               // at most 1 GiB of stream buffers in flight
+    // a group's stream buffers: 256 MiB (two groups are in flight: one being packed, one being downloaded)
+    size_t group = ((size_t)256 << 20) / g.dev_cap;
     if (group < 1) group = 1;
     if (group > batch) group = batch ? batch : 1;
     if (group > 256) group = 256;
@@ -787,7 +794,8 @@ DeflateGeom deflate_geom(uint64_t n, size_t batch)
     const size_t ngroups = batch ? (batch + group - 1) / group : 1;
     if (batch) group = (batch + ngroups - 1) / ngroups;
     g.group = group;
-    g.need = group * (kHistBytes + kPlanBytes + 8 + g.dev_cap + (size_t)g.nchunks * 12 + 64) + 4096;
+    const size_t sets = ngroups > 1 ? 2 : 1;
+    g.need = group * (sets * (kHistBytes + g.dev_cap) + kPlanBytes + (size_t)g.nchunks * 12 + 64) + (batch ? batch : 1) * 8 + 4096;
     return g;
 }
 
@@ -842,10 +850,29 @@ hgi_status plan_frame(uint64_t (*hists)[kDeflateSymbols], bool have_grid, const 
     put_bits(tail, tb, codes[256], lens[256]);
     d.tail_bits = (uint32_t)tb;
     std::memcpy(d.tail, tail, sizeof(tail));
-    for (int v = 0; v < kDeflateSymbols; ++v) d.table[v] = (uint32_t)codes[v] | ((uint32_t)lens[v] << 16);
+    for (int v = 0; v < kDeflateSymbols; ++v) d.table[v] = (uint32_t)codes[v] | ((uint32_t)lens[v] << 24);
     return HGI_OK;
 }
 
+hgi_status pin_ensure(hgi_ctx *c, size_t bytes)
+{
+    if (bytes <= c->pin_bytes) return HGI_OK;
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (c->pin) HIP_TRY(hipHostFree(c->pin));
+    c->pin = nullptr;
+    c->pin_bytes = 0;
+    HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&c->pin), bytes, hipHostMallocDefault));
+    c->pin_bytes = bytes;
+    return HGI_OK;
+}
+
+// The stage over `batch` grids, in groups of g.group frames, software-pipelined so that the device always has the next
+// thing queued while the host builds codes or waits for a download:
+//     device, c->stream :  hist(0) | hist(1) pack(0) | hist(2) pack(1) | ...
+//     host              :          | plan(0)         | plan(1)         | ...      (several threads, one frame each)
+//     device, pipe[1]   :                            | streams(0) down | streams(1) down ...
+// hist = token histograms (one launch per group), plan = codes + headers, pack = count / scan / pack (three launches per
+// group).  Stream sizes are known from the histograms, so the downloads are queued without waiting for the pack.
 hgi_status deflate_frames(hgi_ctx *c, const uint8_t *d_grids, uint32_t w, uint32_t h, size_t batch, size_t stride, uint8_t *out,
                           size_t out_stride, size_t cap, size_t *sizes)
 {
@@ -857,73 +884,143 @@ hgi_status deflate_frames(hgi_ctx *c, const uint8_t *d_grids, uint32_t w, uint32
         prefix[i] = (uint8_t)(n >> (8 * i));
         suffix[i] = (uint8_t)((uint64_t)w >> (8 * i));
     }
+    const size_t ngroups = (batch + g.group - 1) / g.group;
+    const bool piped = ngroups > 1;
+    if (!n) {
+        // nothing for the device to code: the front, then the tail, here
+        std::vector<uint64_t> hist0((kMatchThresholds + 1) * kDeflateSymbols, 0);
+        FramePlan p;
+        HGI_TRY(plan_frame(reinterpret_cast<uint64_t (*)[kDeflateSymbols]>(hist0.data()), false, prefix, suffix, p));
+        const size_t total_bytes = (size_t)((p.exact_bits + 7) / 8);
+        if (total_bytes > cap) return fail(HGI_EINVAL, "output buffer too small: %zu bytes needed", total_bytes);
+        for (size_t f = 0; f < batch; ++f) {
+            uint8_t *dst = out + f * out_stride;
+            std::memset(dst, 0, total_bytes);
+            std::memcpy(dst, p.block.front, p.block.front_bytes);
+            uint64_t at = p.block.base_bits;
+            const uint8_t *tail = reinterpret_cast<const uint8_t *>(p.block.tail);
+            for (uint32_t i = 0; i < p.block.tail_bits; ++i, ++at) dst[at >> 3] |= (uint8_t)(((tail[i >> 3] >> (i & 7)) & 1u) << (at & 7));
+            sizes[f] = total_bytes;
+        }
+        return HGI_OK;
+    }
     HGI_TRY(ws_ensure(c, g.need));
+    HGI_TRY(pin_ensure(c, 2 * g.group * kHistBytes + batch * 8));
+    if (piped) HGI_TRY(pipe_ensure(c));
     c->ws_used = 0;
-    uint8_t *d_hist = ws_take(c, g.group * kHistBytes);
+    uint8_t *d_hist[2], *d_outs[2];
+    for (int k = 0; k < 2; ++k) d_hist[k] = (k == 0 || piped) ? ws_take(c, g.group * kHistBytes) : d_hist[0];
     uint8_t *d_plans = ws_take(c, g.group * kPlanBytes);
-    uint64_t *d_totals = reinterpret_cast<uint64_t *>(ws_take(c, g.group * 8));
+    uint64_t *d_totals = reinterpret_cast<uint64_t *>(ws_take(c, batch * 8));
     uint64_t *d_off = reinterpret_cast<uint64_t *>(ws_take(c, g.group * (size_t)g.nchunks * 8 + 8));
     uint32_t *d_cbits = reinterpret_cast<uint32_t *>(ws_take(c, g.group * (size_t)g.nchunks * 4 + 8));
-    uint8_t *d_outs = ws_take(c, g.group * g.dev_cap);
+    for (int k = 0; k < 2; ++k) d_outs[k] = (k == 0 || piped) ? ws_take(c, g.group * g.dev_cap) : d_outs[0];
     c->ws_used = 0;
-    if (!d_hist || !d_plans || !d_totals || !d_off || !d_cbits || !d_outs) return fail(HGI_ENOMEM, "scratch exhausted (entropy stage)");
-    const uint32_t dist_code = 0u | (1u << 16);      // distance symbol 0 (= distance 1): the one-bit code "0"
-    std::vector<uint64_t> hists(g.group * (kHistBytes / 8));
+    if (!d_hist[0] || !d_hist[1] || !d_plans || !d_totals || !d_off || !d_cbits || !d_outs[0] || !d_outs[1])
+        return fail(HGI_ENOMEM, "scratch exhausted (entropy stage)");
+    uint64_t *h_hist[2] = {reinterpret_cast<uint64_t *>(c->pin), reinterpret_cast<uint64_t *>(c->pin + g.group * kHistBytes)};
+    uint64_t *h_totals = reinterpret_cast<uint64_t *>(c->pin + 2 * g.group * kHistBytes);
+    const uint32_t dist_code = 0u | (1u << 24);      // distance symbol 0 (= distance 1): the one-bit code "0"
     std::vector<FramePlan> plans(g.group);
     std::vector<DeflatePlan> blocks(g.group);
-    std::vector<uint64_t> totals(g.group);
-    for (size_t g0 = 0; g0 < batch; g0 += g.group) {
-        const size_t cnt = batch - g0 < g.group ? batch - g0 : g.group;
-        // phase 1: token histograms of the group, one launch, one download
-        std::fill(hists.begin(), hists.end(), 0);
-        if (n) {
-            HIP_TRY(launch_token_histogram(d_grids + g0 * stride, n, stride, (uint32_t)cnt, reinterpret_cast<unsigned long long *>(d_hist), c->stream));
-            HIP_TRY(hipMemcpyAsync(hists.data(), d_hist, cnt * kHistBytes, hipMemcpyDeviceToHost, c->stream));
-            HIP_TRY(hipStreamSynchronize(c->stream));
+    std::vector<uint64_t> promised(batch), fixed_bits(batch);      // per frame: the stream's bits, and those that are not tokens
+    hipStream_t down = piped ? c->pipe[1] : c->stream;
+    hipEvent_t ev_hist[2] = {c->ev0, c->ev1};
+    auto first_of = [&](size_t gi) { return gi * g.group; };
+    auto count_of = [&](size_t gi) { return batch - first_of(gi) < g.group ? batch - first_of(gi) : g.group; };
+    auto queue_hist = [&](size_t gi) -> hipError_t {
+        const int set = (int)(gi & 1);
+        hipError_t e = launch_token_histogram(d_grids + first_of(gi) * stride, n, stride, (uint32_t)count_of(gi),
+                                              reinterpret_cast<unsigned long long *>(d_hist[set]), c->stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(h_hist[set], d_hist[set], count_of(gi) * kHistBytes, hipMemcpyDeviceToHost, c->stream);
+        if (e == hipSuccess) e = hipEventRecord(ev_hist[set], c->stream);
+        return e;
+    };
+    auto queue_downloads = [&](size_t gi) -> hipError_t {
+        const int set = (int)(gi & 1);
+        hipError_t e = hipSuccess;
+        if (piped) e = hipStreamWaitEvent(down, c->ev_free[set], 0);
+        for (size_t f = 0; f < count_of(gi) && e == hipSuccess; ++f) {
+            const size_t frame = first_of(gi) + f;
+            e = hipMemcpyAsync(out + frame * out_stride, d_outs[set] + f * g.dev_cap, (size_t)((promised[frame] + 7) / 8), hipMemcpyDeviceToHost, down);
         }
-        // phase 2: codes on the host.  The histograms say exactly how long each stream will be: never start packing into
-        // a buffer it would overrun
-        for (size_t f = 0; f < cnt; ++f) {
-            FramePlan &p = plans[f];
-            HGI_TRY(plan_frame(reinterpret_cast<uint64_t (*)[kDeflateSymbols]>(hists.data() + f * (kHistBytes / 8)), n != 0, prefix, suffix, p));
-            if (p.exact_bits / 8 + 64 > g.dev_cap)
-                return fail(HGI_EDEVICE, "entropy stage: stream of %llu bytes exceeds its scratch", (unsigned long long)(p.exact_bits / 8));
-            if (p.exact_bits / 8 + 1 > cap) return fail(HGI_EINVAL, "output buffer too small: %llu bytes needed", (unsigned long long)(p.exact_bits / 8 + 1));
-            blocks[f] = p.block;
-        }
-        if (!n) {
-            // nothing for the device to code: the front, then the tail, here
-            for (size_t f = 0; f < cnt; ++f) {
-                const DeflatePlan &d = plans[f].block;
-                uint8_t *dst = out + (g0 + f) * out_stride;
-                const size_t total_bytes = (size_t)((plans[f].exact_bits + 7) / 8);
-                std::memset(dst, 0, total_bytes);
-                std::memcpy(dst, d.front, d.front_bytes);
-                uint64_t at = d.base_bits;
-                const uint8_t *tail = reinterpret_cast<const uint8_t *>(d.tail);
-                for (uint32_t i = 0; i < d.tail_bits; ++i, ++at) dst[at >> 3] |= (uint8_t)(((tail[i >> 3] >> (i & 7)) & 1u) << (at & 7));
-                sizes[g0 + f] = total_bytes;
+        if (piped && e == hipSuccess) e = hipEventRecord(c->ev_up[set], down);
+        return e;
+    };
+    // anything that fails after work was queued: drain before the host buffers the queue refers to go away
+    auto bail = [&](hgi_status st) {
+        (void)hipStreamSynchronize(c->stream);
+        if (piped) (void)hipStreamSynchronize(down);
+        return st;
+    };
+#define DF_TRY(expr)                                                                                                             \
+    do {                                                                                                                         \
+        hipError_t e_ = (expr);                                                                                                  \
+        if (e_ != hipSuccess) return bail(fail(HGI_EDEVICE, "%s: %s", #expr, hipGetErrorString(e_)));                           \
+    } while (0)
+    DF_TRY(queue_hist(0));
+    for (size_t gi = 0; gi < ngroups; ++gi) {
+        const int set = (int)(gi & 1);
+        const size_t g0 = first_of(gi), cnt = count_of(gi);
+        DF_TRY(hipEventSynchronize(ev_hist[set]));
+        if (gi + 1 < ngroups) DF_TRY(queue_hist(gi + 1));              // the device has this to do while the host plans
+        // codes on the host, a frame per thread
+        {
+            std::vector<int> status(cnt, 0);
+            auto work = [&](size_t t, size_t nt) {
+                for (size_t f = t; f < cnt; f += nt)
+                    status[f] = plan_frame(reinterpret_cast<uint64_t (*)[kDeflateSymbols]>(h_hist[set] + f * (kHistBytes / 8)), true, prefix, suffix,
+                                           plans[f]) == HGI_OK ? 0 : 1;
+            };
+            size_t nt = cnt / 2;
+            if (nt > 8) nt = 8;
+            if (nt <= 1) {
+                work(0, 1);
+            } else {
+                std::vector<std::thread> pool;
+                for (size_t t = 1; t < nt; ++t) pool.emplace_back(work, t, nt);
+                work(0, nt);
+                for (auto &th : pool) th.join();
             }
-            continue;
+            for (size_t f = 0; f < cnt; ++f)
+                if (status[f]) return bail(fail(HGI_EDEVICE, "block header does not fit"));
         }
-        // phase 3: one upload of the plans, count / scan / pack over the whole group, and the downloads queued behind them
-        // (their sizes are known already); one wait
-        HIP_TRY(hipMemcpyAsync(d_plans, blocks.data(), cnt * kPlanBytes, hipMemcpyHostToDevice, c->stream));
-        HIP_TRY(launch_huffman_pack(d_grids + g0 * stride, n, stride, (uint32_t)cnt, d_plans, dist_code, d_cbits, d_off, d_totals, d_outs,
-                                    g.dev_cap, c->stream));
-        HIP_TRY(hipMemcpyAsync(totals.data(), d_totals, cnt * 8, hipMemcpyDeviceToHost, c->stream));
-        for (size_t f = 0; f < cnt; ++f)
-            HIP_TRY(hipMemcpyAsync(out + (g0 + f) * out_stride, d_outs + f * g.dev_cap, (size_t)((plans[f].exact_bits + 7) / 8), hipMemcpyDeviceToHost,
-                                   c->stream));
-        HIP_TRY(hipStreamSynchronize(c->stream));
+        // the histograms say exactly how long each stream will be: never start packing into a buffer it would overrun
         for (size_t f = 0; f < cnt; ++f) {
             const FramePlan &p = plans[f];
-            const uint64_t got = p.block.base_bits + totals[f] + p.block.tail_bits;
-            if (got != p.exact_bits)
-                return fail(HGI_EDEVICE, "entropy stage: packed %llu bits where the histograms promised %llu", (unsigned long long)got,
-                            (unsigned long long)p.exact_bits);
-            sizes[g0 + f] = (size_t)((p.exact_bits + 7) / 8);
+            if (p.exact_bits / 8 + 64 > g.dev_cap)
+                return bail(fail(HGI_EDEVICE, "entropy stage: stream of %llu bytes exceeds its scratch", (unsigned long long)(p.exact_bits / 8)));
+            if ((p.exact_bits + 7) / 8 > cap)
+                return bail(fail(HGI_EINVAL, "output buffer too small: %llu bytes needed", (unsigned long long)((p.exact_bits + 7) / 8)));
+            blocks[f] = p.block;
+            promised[g0 + f] = p.exact_bits;
+            fixed_bits[g0 + f] = p.block.base_bits + p.block.tail_bits;
         }
+        // one upload of the plans, count / scan / pack over the whole group (its stream buffers are free once the group
+        // two back has been downloaded)
+        if (piped && gi >= 2) DF_TRY(hipStreamWaitEvent(c->stream, c->ev_up[set], 0));
+        DF_TRY(hipMemcpyAsync(d_plans, blocks.data(), cnt * kPlanBytes, hipMemcpyHostToDevice, c->stream));
+        DF_TRY(launch_huffman_pack(d_grids + g0 * stride, n, stride, (uint32_t)cnt, d_plans, dist_code, d_cbits, d_off, d_totals + g0, d_outs[set],
+                                   g.dev_cap, c->stream));
+        if (piped) DF_TRY(hipEventRecord(c->ev_free[set], c->stream));
+        // downloads lag one group behind, so that the device has hist(gi + 1) and pack(gi) queued while they run
+        if (piped) {
+            if (gi >= 1) DF_TRY(queue_downloads(gi - 1));
+        } else {
+            DF_TRY(queue_downloads(gi));
+        }
+    }
+    if (piped) DF_TRY(queue_downloads(ngroups - 1));
+    DF_TRY(hipMemcpyAsync(h_totals, d_totals, batch * 8, hipMemcpyDeviceToHost, c->stream));
+    DF_TRY(hipStreamSynchronize(c->stream));
+    if (piped) DF_TRY(hipStreamSynchronize(down));
+#undef DF_TRY
+    for (size_t f = 0; f < batch; ++f) {
+        const uint64_t got = fixed_bits[f] + h_totals[f];
+        if (got != promised[f])
+            return fail(HGI_EDEVICE, "entropy stage: packed %llu bits where the histograms promised %llu", (unsigned long long)got,
+                        (unsigned long long)promised[f]);
+        sizes[f] = (size_t)((promised[f] + 7) / 8);
     }
     return HGI_OK;
 }

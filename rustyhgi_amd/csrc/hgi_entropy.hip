@@ -301,22 +301,55 @@ __device__ __forceinline__ Runs find_runs(const Lane &L, u32 lane, u32 chunk_val
     return R;
 }
 
-// For the continuing byte i of this lane: with k = bytes since the run's head (>= 1) and rem = continuing bytes left
-// including this one, the run's tail of continuing bytes is cut into pieces of 258; o = (k - 1) % 258 is the byte's
-// offset inside its piece and the piece's length is min(258, rem + o).  The first byte of a piece of >= min_match (>= 3)
-// bytes emits the match, the piece's other bytes nothing; bytes of shorter pieces stay literals.
-__device__ __forceinline__ void run_piece(const Runs &R, u32 lane, int i, u32 &piece, bool &first)
+// The continuing bytes after a run's head are cut into PIECES of 258 (the longest DEFLATE match); a piece of at least
+// min_match bytes is coded as one match (distance 1) at its first byte, the bytes of a shorter piece stay literals.  What a
+// lane has to know about the pieces that touch its sixteen bytes:
+struct Pieces {
+    u32 starts;         // its bytes at which a piece starts (mask): a run's second byte, or 258 x m bytes further on
+    u32 inh_cover;      // its leading bytes that belong to a piece started in an earlier lane (mask; 0: none) ...
+    u32 inh_len;        // ... and that piece's whole length
+};
+
+__device__ __forceinline__ u32 mod258(u32 o /* <= 1022 */) { return o - 258u * ((u32)(o >= 258u) + (u32)(o >= 516u) + (u32)(o >= 774u)); }
+
+__device__ __forceinline__ Pieces find_pieces(const Runs &R, u32 lane)
 {
-    const u32 p = kLaneBytes * lane + (u32)i;
-    const u32 below = R.head & ((1u << i) - 1u);
-    const u32 hp = below ? kLaneBytes * lane + (31u - (u32)__clz(below)) : R.head_before - 1u;
-    const u32 above = R.stop >> (i + 1);
+    Pieces P;
+    const u32 p0 = kLaneBytes * lane;
+    P.starts = R.cont & ~(R.cont << 1) & ~1u;                       // runs whose head is one of my bytes
+    P.inh_cover = 0;
+    P.inh_len = 0;
+    const u32 lead = (u32)__builtin_ctz(~R.cont | 0x10000u);        // my leading bytes that continue a run from an earlier lane
+    if (lead) {
+        const u32 o0 = mod258(p0 - R.head_before);                  // byte 0's offset inside its piece (head at head_before - 1)
+        const u32 to_next = o0 ? 258u - o0 : 0u;                    // bytes until the next piece starts
+        if (to_next < lead) P.starts |= 1u << to_next;
+        if (o0) {
+            const u32 sp0 = lead < (u32)kLaneBytes ? p0 + lead : R.stop_after;
+            const u32 len = sp0 - p0 + o0;
+            P.inh_len = len < 258u ? len : 258u;
+            P.inh_cover = (1u << (lead < to_next ? lead : to_next)) - 1u;
+        }
+    }
+    return P;
+}
+
+// the piece that starts at my byte i: its length and which of my bytes it covers
+__device__ __forceinline__ void piece_at(const Runs &R, u32 lane, u32 i, u32 &len, u32 &cover)
+{
+    const u32 p = kLaneBytes * lane + i;
+    const u32 above = R.stop >> (i + 1u);
     const u32 sp = above ? p + 1u + (u32)__builtin_ctz(above) : R.stop_after;
-    u32 o = p - hp - 1u;                          // <= 1022
-    o -= 258u * ((u32)(o >= 258u) + (u32)(o >= 516u) + (u32)(o >= 774u));
-    const u32 len = sp - p + o;
-    piece = len < 258u ? len : 258u;
-    first = o == 0u;
+    const u32 l = sp - p;
+    len = l < 258u ? l : 258u;
+    const u32 here = len < kLaneBytes - i ? len : kLaneBytes - i;
+    cover = ((1u << here) - 1u) << i;
+}
+
+__device__ __forceinline__ u32 byte_at(const Lane &L, u32 i)      // i not known at compile time
+{
+    const u64 lo = ((u64)L.w[1] << 32) | L.w[0], hi = ((u64)L.w[3] << 32) | L.w[2];
+    return (u32)((i < 8u ? lo : hi) >> (8u * (i & 7u))) & 255u;
 }
 
 // length 3..258 -> length symbol, extra bits (RFC 1951 3.2.5)
@@ -337,12 +370,13 @@ __device__ __forceinline__ void length_symbol(u32 length, u32 &symbol, u32 &extr
 // pass 1: histograms of the literal / length symbols the tokens use, for each candidate match threshold at once (a short
 // run of a byte whose literal costs one bit is cheaper as literals than as a match; which threshold pays is decided on
 // the host from the exact stream sizes the histograms imply).  A byte's token is the same under every candidate unless
-// it lies in a run piece of kMatchThreshold[0] .. kMatchThreshold[last] - 1 bytes: those go to a per-candidate histogram,
+// it lies in a piece of kMatchThreshold[0] .. kMatchThreshold[last] - 1 bytes: those go to a per-candidate histogram,
 // everything else to ONE common histogram (slot kMatchThresholds) that the host adds to each.
 __global__ __launch_bounds__(kPackThreads) void k_token_hist(const u8 *__restrict__ src, u64 n, u64 stride, u32 nchunks,
-                                                         unsigned long long *__restrict__ hist)
+                                                             unsigned long long *__restrict__ hist)
 {
     constexpr int kCopies = 4, kHists = kMatchThresholds + 1;
+    constexpr u32 kLo = kMatchThreshold[0], kHi = kMatchThreshold[kMatchThresholds - 1];
     __shared__ u32 h[kHists][kDeflateSymbols * kCopies];      // copies value-major (a handful of symbols dominate)
     for (int i = threadIdx.x; i < kHists * kDeflateSymbols * kCopies; i += kPackThreads) (&h[0][0])[i] = 0;
     __syncthreads();
@@ -351,11 +385,23 @@ __global__ __launch_bounds__(kPackThreads) void k_token_hist(const u8 *__restric
     const u32 lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     const u32 copy = lane & (kCopies - 1);
     u32 zeros = 0;                                            // literal zeros are most of a residual grid: counted privately
-    auto add = [&](int which, u32 sym) { atomicAdd(&h[which][sym * kCopies + copy], 1u); };
-    auto add_match = [&](int which, u32 length) {
+    auto add = [&](int which, u32 sym, u32 count) { atomicAdd(&h[which][sym * kCopies + copy], count); };
+    // a piece of `len` bytes of value b, `mine` of them in this lane, `first`: it starts here
+    auto piece = [&](u32 len, u32 b, u32 mine, bool first) {
         u32 sym, eb, ex;
-        length_symbol(length, sym, eb, ex);
-        add(which, sym);
+        length_symbol(len, sym, eb, ex);
+        if (len >= kHi) {
+            if (first) add(kMatchThresholds, sym, 1u);
+            return;
+        }
+#pragma unroll
+        for (int v = 0; v < kMatchThresholds; ++v) {
+            if (len >= kMatchThreshold[v]) {
+                if (first) add(v, sym, 1u);
+            } else {
+                add(v, b, mine);
+            }
+        }
     };
     const u32 step = gridDim.x * kWaves;
     u32 chunk = blockIdx.x * kWaves + wave;
@@ -367,30 +413,29 @@ __global__ __launch_bounds__(kPackThreads) void k_token_hist(const u8 *__restric
         if (next < nchunks) nxt = load_lane(src, n, (u64)next * kChunk, lane);
         const u64 left = n - (u64)chunk * kChunk;
         const Runs R = find_runs(cur, lane, left < (u64)kChunk ? (u32)left : (u32)kChunk);
+        const Pieces P = find_pieces(R, lane);
+        u32 covered = 0;                                      // my bytes in pieces of >= kLo: not literals under every candidate
+        if (P.inh_len >= kLo) {
+            covered = P.inh_cover;
+            piece(P.inh_len, byte_of(cur, 0), (u32)__popc(P.inh_cover), false);
+        }
+        for (u32 s = P.starts; s; s &= s - 1u) {
+            const u32 i = (u32)__builtin_ctz(s);
+            u32 len, cover;
+            piece_at(R, lane, i, len, cover);
+            if (len < kLo) continue;
+            covered |= cover;
+            piece(len, byte_at(cur, i), (u32)__popc(cover), true);
+        }
+        const u32 lit = R.valid & ~covered;
 #pragma unroll
         for (int i = 0; i < kLaneBytes; ++i) {
-            if (!((R.valid >> i) & 1u)) continue;
+            if (!((lit >> i) & 1u)) continue;
             const u32 b = byte_of(cur, i);
-            u32 piece = 0;
-            bool first = false;
-            if ((R.cont >> i) & 1u) run_piece(R, lane, i, piece, first);
-            if (piece < kMatchThreshold[0]) {                       // a literal under every candidate
-                if (b == 0u)
-                    ++zeros;
-                else
-                    add(kMatchThresholds, b);
-            } else if (piece >= kMatchThreshold[kMatchThresholds - 1]) {      // a match under every candidate
-                if (first) add_match(kMatchThresholds, piece);
-            } else {
-#pragma unroll
-                for (int v = 0; v < kMatchThresholds; ++v) {
-                    if (piece >= kMatchThreshold[v]) {
-                        if (first) add_match(v, piece);
-                    } else {
-                        add(v, b);
-                    }
-                }
-            }
+            if (b == 0u)
+                ++zeros;
+            else
+                add(kMatchThresholds, b, 1u);
         }
         cur = nxt;
         chunk = next;
@@ -406,44 +451,24 @@ __global__ __launch_bounds__(kPackThreads) void k_token_hist(const u8 *__restric
     }
 }
 
-// tok[i] = bits << 24 | code of what byte i emits under the frame's code (0: nothing).  A match is its length code, the
-// length's extra bits and the one distance code: <= 15 + 5 + 1 bits.
-__device__ __forceinline__ u32 lane_tokens(const Lane &L, const Runs &R, u32 lane, u32 min_match, const u32 *stab, u32 dist, u32 tok[kLaneBytes])
+// a match of `len` bytes under the frame's code: its length code, the length's extra bits, the one distance code
+// (<= 15 + 5 + 1 bits), as bits << 24 | code like the table's entries
+__device__ __forceinline__ u32 match_token(u32 len, const u32 *stab, u32 dist)
 {
-    u32 bits = 0;
-#pragma unroll
-    for (int i = 0; i < kLaneBytes; ++i) {
-        tok[i] = 0;
-        if (!((R.valid >> i) & 1u)) continue;
-        u32 piece = 0;
-        bool first = false;
-        if ((R.cont >> i) & 1u) run_piece(R, lane, i, piece, first);
-        u32 code, nb;
-        if (piece >= min_match) {
-            if (!first) continue;
-            u32 sym, eb, ex;
-            length_symbol(piece, sym, eb, ex);
-            const u32 e = stab[sym];
-            code = e & 0xFFFFu;
-            nb = e >> 16;
-            code |= ex << nb;
-            nb += eb;
-            code |= (dist & 0xFFFFu) << nb;
-            nb += dist >> 16;
-        } else {
-            const u32 e = stab[byte_of(L, i)];
-            code = e & 0xFFFFu;
-            nb = e >> 16;
-        }
-        tok[i] = code | (nb << 24);
-        bits += nb;
-    }
-    return bits;
+    u32 sym, eb, ex;
+    length_symbol(len, sym, eb, ex);
+    const u32 e = stab[sym];
+    u32 code = e & 0xFFFFFFu, nb = e >> 24;
+    code |= ex << nb;
+    nb += eb;
+    code |= (dist & 0xFFFFFFu) << nb;
+    nb += dist >> 24;
+    return code | (nb << 24);
 }
 
 // pass 2: bits per chunk
 __global__ __launch_bounds__(kPackThreads) void k_token_count(const u8 *__restrict__ src, u64 n, u64 stride, u32 nchunks,
-                                                          const DeflatePlan *__restrict__ plans, u32 dist, u32 *__restrict__ chunk_bits)
+                                                              const DeflatePlan *__restrict__ plans, u32 dist, u32 *__restrict__ chunk_bits)
 {
     __shared__ u32 stab[kDeflateSymbols];
     const DeflatePlan &plan = plans[blockIdx.y];
@@ -463,8 +488,22 @@ __global__ __launch_bounds__(kPackThreads) void k_token_count(const u8 *__restri
         if (next < nchunks) nxt = load_lane(src, n, (u64)next * kChunk, lane);
         const u64 left = n - (u64)chunk * kChunk;
         const Runs R = find_runs(cur, lane, left < (u64)kChunk ? (u32)left : (u32)kChunk);
-        u32 tok[kLaneBytes];
-        u32 bits = lane_tokens(cur, R, lane, min_match, stab, dist, tok);
+        const Pieces P = find_pieces(R, lane);
+        u32 covered = P.inh_len >= min_match ? P.inh_cover : 0u;
+        u32 bits = 0;
+        for (u32 s = P.starts; s; s &= s - 1u) {
+            u32 len, cover;
+            piece_at(R, lane, (u32)__builtin_ctz(s), len, cover);
+            if (len < min_match) continue;
+            covered |= cover;
+            bits += match_token(len, stab, dist) >> 24;
+        }
+        const u32 lit = R.valid & ~covered;
+#pragma unroll
+        for (int i = 0; i < kLaneBytes; ++i) {
+            const u32 e = stab[byte_of(cur, i)];
+            bits += (lit >> i) & 1u ? e >> 24 : 0u;
+        }
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) bits += __shfl_down(bits, o, 64);
         if (lane == 0) chunk_bits[chunk] = bits;
@@ -534,12 +573,14 @@ __global__ __launch_bounds__(1024) void k_huff_scan(const u32 *__restrict__ chun
 // also writes what precedes the tokens, the wave that codes the last chunk what follows them: the stream leaves the
 // device complete.
 __global__ __launch_bounds__(kPackThreads) void k_token_pack(const u8 *__restrict__ src, u64 n, u64 stride, u32 nchunks,
-                                                         const DeflatePlan *__restrict__ plans, u32 dist, const u64 *__restrict__ chunk_off,
-                                                         u8 *__restrict__ outs, u64 out_stride)
+                                                             const DeflatePlan *__restrict__ plans, u32 dist, const u64 *__restrict__ chunk_off,
+                                                             u8 *__restrict__ outs, u64 out_stride)
 {
     constexpr int kWords = (kChunk * 15 + 31) / 32 + 4;      // every byte a 15-bit literal (a match spends 21 bits on >= 3 bytes)
+    constexpr int kMaxStarts = 9;                            // pieces that can start inside sixteen bytes
     __shared__ u32 stab[kDeflateSymbols];
     __shared__ u32 imgs[kWaves][kWords];
+    __shared__ u32 mtoks[kWaves][kMaxStarts][64];            // a lane's match tokens, in the order its pieces start
     const DeflatePlan &plan = plans[blockIdx.y];
     for (int i = threadIdx.x; i < kDeflateSymbols; i += kPackThreads) stab[i] = plan.table[i];
     for (int i = threadIdx.x; i < kWaves * kWords; i += kPackThreads) (&imgs[0][0])[i] = 0;
@@ -551,6 +592,7 @@ __global__ __launch_bounds__(kPackThreads) void k_token_pack(const u8 *__restric
     u32 *out = reinterpret_cast<u32 *>(outs + (u64)blockIdx.y * out_stride);
     const u32 lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     u32 *img = imgs[wave];
+    u32(*mtok)[64] = mtoks[wave];
     if (blockIdx.x == 0 && wave == 0) {
         // the front: whole words are this wave's alone; the word the tokens start in is shared with the first chunk
         const u32 own = (u32)(base >> 5);
@@ -581,8 +623,31 @@ __global__ __launch_bounds__(kPackThreads) void k_token_pack(const u8 *__restric
         }
         const u64 left = n - (u64)chunk * kChunk;
         const Runs R = find_runs(cur, lane, left < (u64)kChunk ? (u32)left : (u32)kChunk);
+        const Pieces P = find_pieces(R, lane);
+        // the pieces that become matches: their tokens into my column of mtok (slot = the piece's rank among my starts)
+        u32 covered = P.inh_len >= min_match ? P.inh_cover : 0u, matches = 0, bits = 0;
+        {
+            u32 k = 0;
+            for (u32 s = P.starts; s; s &= s - 1u, ++k) {
+                const u32 i = (u32)__builtin_ctz(s);
+                u32 len, cover;
+                piece_at(R, lane, i, len, cover);
+                if (len < min_match) continue;
+                covered |= cover;
+                matches |= 1u << i;
+                const u32 t = match_token(len, stab, dist);
+                mtok[k][lane] = t;
+                bits += t >> 24;
+            }
+        }
+        const u32 lit = R.valid & ~covered;
         u32 tok[kLaneBytes];
-        const u32 bits = lane_tokens(cur, R, lane, min_match, stab, dist, tok);
+#pragma unroll
+        for (int i = 0; i < kLaneBytes; ++i) {
+            const u32 e = stab[byte_of(cur, i)];
+            tok[i] = (lit >> i) & 1u ? e : 0u;
+            bits += tok[i] >> 24;
+        }
         u32 incl = bits;
 #pragma unroll
         for (int o = 1; o < 64; o <<= 1) {
@@ -592,13 +657,15 @@ __global__ __launch_bounds__(kPackThreads) void k_token_pack(const u8 *__restric
         const u32 chunk_total = __shfl(incl, 63, 64);
         const u64 pos0 = base + off;                             // the chunk's first bit in the stream
         const u32 sh0 = (u32)(pos0 & 31u);                       // ... and where that is inside its first word
+        WAVE_LDS_ORDER();
         {
             const u32 at = sh0 + incl - bits;
             u32 wi = at >> 5, nb = at & 31u;
             u64 acc = 0;
 #pragma unroll
             for (int i = 0; i < kLaneBytes; ++i) {
-                const u32 t = tok[i];
+                u32 t = tok[i];
+                if ((matches >> i) & 1u) t = mtok[__popc(P.starts & ((1u << i) - 1u))][lane];
                 if (!t) continue;
                 acc |= (u64)(t & 0xFFFFFFu) << nb;
                 nb += t >> 24;

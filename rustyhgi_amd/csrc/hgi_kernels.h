@@ -94,7 +94,7 @@ uint64_t huffman_payload_bits(const uint64_t hist[kDeflateSymbols]);      // tok
 // threshold, the bytes in front of the grid's tokens and the bits behind them.
 constexpr size_t kPlanBytes = 2048;
 struct DeflatePlan {
-    uint32_t table[kDeflateSymbols];      // reversed code | length << 16
+    uint32_t table[kDeflateSymbols];      // reversed code | length << 24
     uint32_t min_match;
     uint32_t front_bytes;                 // block header + the eight literals of the u64 length: ceil(base_bits / 8)
     uint64_t base_bits;                   // where the grid's tokens start
@@ -111,7 +111,7 @@ static_assert(sizeof(DeflatePlan) == kPlanBytes, "plan block layout");
 hipError_t launch_token_histogram(const uint8_t *src, uint64_t n, uint64_t stride, uint32_t frames, unsigned long long *d_hist,
                                   hipStream_t s);
 // device, passes 2 + 3: each frame's complete stream (front, tokens, tail) written to d_outs + frame * out_stride, which
-// need not be cleared (dist_code = reversed code | length << 16 of the one distance code); d_totals[frame] = the tokens'
+// need not be cleared (dist_code = reversed code | length << 24 of the one distance code); d_totals[frame] = the tokens'
 // bits.  Scratch: frames * huffman_chunks(n) u32 + as many u64.
 uint32_t huffman_chunks(uint64_t n);
 hipError_t launch_huffman_pack(const uint8_t *src, uint64_t n, uint64_t stride, uint32_t frames, const void *d_plans, uint32_t dist_code,
