@@ -159,8 +159,11 @@ hgi_status hgi_deflate_grid_dev(hgi_ctx *ctx, const void *d_grid, uint32_t width
                                 uint8_t *out, size_t cap, size_t *bytes);
 /* `batch` grids `frame_stride` bytes apart in device memory: stream f is written to            */
 /* out + f * out_stride (host memory; out_stride is also each stream's capacity), sizes[f] = its */
-/* length.  The phases run group-wise, so the host waits three times per group of frames (up  */
-/* to 1 GiB of stream buffers at once), not three times per frame.                             */
+/* length.  The batch is pipelined in groups of frames (256 MiB of stream buffer each): one    */
+/* launch per phase per group, the host building a group's codes while the device histograms   */
+/* the next, a group's streams going down while the next is coded.  The downloads bound the    */
+/* call; they are faster into pinned host memory (a 1 GiB batch: 5.5 ms pageable, 4.5 pinned). */
+/* `out` is written from a second stream internally; the call returns when everything is done. */
 hgi_status hgi_deflate_grids_dev(hgi_ctx *ctx, const void *d_grids, uint32_t width, uint32_t height, size_t batch,
                                  size_t frame_stride, uint8_t *out, size_t out_stride, size_t *sizes);
 /* The same with the grid in host memory (what pairs with hgi_encode_u8).                      */

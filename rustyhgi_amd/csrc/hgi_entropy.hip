@@ -17,6 +17,7 @@
 // The stream is ordinary DEFLATE: flate2 / zlib / miniz inflate it; `Archive::deserialize_from_reader`
 // (src/archive.rs:43-55) reads archives written this way unchanged.
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -236,6 +237,53 @@ __device__ constexpr u32 kMatchThreshold[kMatchThresholds] = {3, 4, 6, 10};     
 // to keep the accesses where they are
 #define WAVE_LDS_ORDER() asm volatile("" ::: "memory")
 
+// Wave-wide scans on the DPP lanes of the VALU (no LDS crossbar round trips): four row_shr / row_shl steps scan each row
+// of sixteen lanes, then the rows are joined -- forward by the row broadcasts, backward through three scalar reads.
+template <int kCtrl, int kRows = 0xF>
+__device__ __forceinline__ u32 dpp(u32 fill, u32 v)      // lanes the pattern gives no source keep `fill`
+{
+    return (u32)__builtin_amdgcn_update_dpp((int)fill, (int)v, kCtrl, kRows, 0xF, false);
+}
+constexpr int kRowShr = 0x110, kRowShl = 0x100, kWaveShl1 = 0x130, kWaveShr1 = 0x138, kRowBcast15 = 0x142, kRowBcast31 = 0x143;
+
+__device__ __forceinline__ u32 umax(u32 a, u32 b) { return a > b ? a : b; }
+__device__ __forceinline__ u32 umin(u32 a, u32 b) { return a < b ? a : b; }
+
+__device__ __forceinline__ u32 wave_scan_max(u32 v)      // inclusive, lanes 0 -> 63; identity 0
+{
+    v = umax(v, dpp<kRowShr + 1>(0u, v));
+    v = umax(v, dpp<kRowShr + 2>(0u, v));
+    v = umax(v, dpp<kRowShr + 4>(0u, v));
+    v = umax(v, dpp<kRowShr + 8>(0u, v));
+    v = umax(v, dpp<kRowBcast15, 0xA>(0u, v));
+    v = umax(v, dpp<kRowBcast31, 0xC>(0u, v));
+    return v;
+}
+
+__device__ __forceinline__ u32 wave_scan_add(u32 v)      // inclusive, lanes 0 -> 63
+{
+    v += dpp<kRowShr + 1>(0u, v);
+    v += dpp<kRowShr + 2>(0u, v);
+    v += dpp<kRowShr + 4>(0u, v);
+    v += dpp<kRowShr + 8>(0u, v);
+    v += dpp<kRowBcast15, 0xA>(0u, v);
+    v += dpp<kRowBcast31, 0xC>(0u, v);
+    return v;
+}
+
+__device__ __forceinline__ u32 wave_rscan_min(u32 v, u32 lane)      // inclusive, lanes 63 -> 0; identity 0xFFFFFFFF
+{
+    v = umin(v, dpp<kRowShl + 1>(0xFFFFFFFFu, v));
+    v = umin(v, dpp<kRowShl + 2>(0xFFFFFFFFu, v));
+    v = umin(v, dpp<kRowShl + 4>(0xFFFFFFFFu, v));
+    v = umin(v, dpp<kRowShl + 8>(0xFFFFFFFFu, v));
+    const u32 r1 = (u32)__builtin_amdgcn_readlane((int)v, 16), r2 = (u32)__builtin_amdgcn_readlane((int)v, 32),
+              r3 = (u32)__builtin_amdgcn_readlane((int)v, 48);
+    const u32 row = lane >> 4;
+    const u32 later = row == 0 ? umin(r1, umin(r2, r3)) : row == 1 ? umin(r2, r3) : row == 2 ? r3 : 0xFFFFFFFFu;
+    return umin(v, later);
+}
+
 struct Lane {
     u32 w[4];      // the lane's sixteen bytes, little endian
     u32 cnt;       // how many of them exist (16 except at the end of the data)
@@ -273,8 +321,8 @@ __device__ __forceinline__ Runs find_runs(const Lane &L, u32 lane, u32 chunk_val
 {
     Runs R;
     R.valid = (1u << L.cnt) - 1u;
-    u32 prev = __shfl_up(L.w[3], 1, 64) >> 24;
-    if (lane == 0) prev = 0x100u;                 // the chunk's first byte never continues
+    u32 prev = dpp<kWaveShr1>(0u, L.w[3]) >> 24;      // the previous lane's last byte
+    if (lane == 0) prev = 0x100u;                     // the chunk's first byte never continues
     u32 cont = 0;
 #pragma unroll
     for (int i = 0; i < kLaneBytes; ++i) {
@@ -285,18 +333,11 @@ __device__ __forceinline__ Runs find_runs(const Lane &L, u32 lane, u32 chunk_val
     R.cont = cont & R.valid;
     R.head = R.valid & ~R.cont;
     R.stop = (R.head | ~R.valid) & 0xFFFFu;
-    u32 fi = R.head ? kLaneBytes * lane + (31u - (u32)__clz(R.head)) + 1u : 0u;            // inclusive max-scan, forward
-    u32 bi = R.stop ? kLaneBytes * lane + (u32)__builtin_ctz(R.stop) : kNone;                // inclusive min-scan, backward
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        const u32 up = __shfl_up(fi, o, 64), dn = __shfl_down(bi, o, 64);
-        if ((int)lane >= o) fi = fi > up ? fi : up;
-        if ((int)lane + o < 64) bi = bi < dn ? bi : dn;
-    }
-    R.head_before = __shfl_up(fi, 1, 64);
-    if (lane == 0) R.head_before = 0;
-    u32 sa = __shfl_down(bi, 1, 64);
-    if (lane == 63 || sa > chunk_valid) sa = chunk_valid;
+    const u32 fi = wave_scan_max(R.head ? kLaneBytes * lane + (31u - (u32)__clz(R.head)) + 1u : 0u);
+    const u32 bi = wave_rscan_min(R.stop ? kLaneBytes * lane + (u32)__builtin_ctz(R.stop) : kNone, lane);
+    R.head_before = dpp<kWaveShr1>(0u, fi);           // lane 0: none
+    u32 sa = dpp<kWaveShl1>(kNone, bi);               // lane 63: none
+    if (sa > chunk_valid) sa = chunk_valid;
     R.stop_after = sa;
     return R;
 }
@@ -504,9 +545,8 @@ __global__ __launch_bounds__(kPackThreads) void k_token_count(const u8 *__restri
             const u32 e = stab[byte_of(cur, i)];
             bits += (lit >> i) & 1u ? e >> 24 : 0u;
         }
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) bits += __shfl_down(bits, o, 64);
-        if (lane == 0) chunk_bits[chunk] = bits;
+        bits = wave_scan_add(bits);
+        if (lane == 63) chunk_bits[chunk] = bits;
         cur = nxt;
         chunk = next;
     }
@@ -648,13 +688,8 @@ __global__ __launch_bounds__(kPackThreads) void k_token_pack(const u8 *__restric
             tok[i] = (lit >> i) & 1u ? e : 0u;
             bits += tok[i] >> 24;
         }
-        u32 incl = bits;
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) {
-            const u32 up = __shfl_up(incl, o, 64);
-            if ((int)lane >= o) incl += up;
-        }
-        const u32 chunk_total = __shfl(incl, 63, 64);
+        const u32 incl = wave_scan_add(bits);
+        const u32 chunk_total = (u32)__builtin_amdgcn_readlane((int)incl, 63);
         const u64 pos0 = base + off;                             // the chunk's first bit in the stream
         const u32 sh0 = (u32)(pos0 & 31u);                       // ... and where that is inside its first word
         WAVE_LDS_ORDER();
@@ -711,11 +746,26 @@ __global__ __launch_bounds__(kPackThreads) void k_token_pack(const u8 *__restric
     }
 }
 
-u32 blocks_for(u32 nchunks, u32 frames)
+// Workgroups per frame: all of a launch's workgroups resident at once (a second round would run at a fraction of the
+// occupancy), and no more than there are chunks.  What fits is asked of the runtime once per kernel.
+template <typename K>
+u32 resident_workgroups(K kernel)
 {
-    // enough workgroups to fill the device (256 CUs x 8) over all frames, and no more than there are chunks
+    int per_cu = 0, dev = 0;
+    hipDeviceProp_t prop;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, kPackThreads, 0) != hipSuccess || per_cu < 1) per_cu = 4;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess || prop.multiProcessorCount < 1) {
+        (void)hipGetLastError();
+        return 4u * 256u;
+    }
+    if (const char *e = getenv("HGI_ENTROPY_WGS_PER_CU")) per_cu = atoi(e) > 0 ? atoi(e) : per_cu;      // experiments
+    return (u32)per_cu * (u32)prop.multiProcessorCount;
+}
+
+u32 blocks_for(u32 nchunks, u32 frames, u32 resident)
+{
     const u32 per_frame_max = (nchunks + kWaves - 1) / kWaves;
-    u32 b = (2048 + frames - 1) / frames;
+    u32 b = resident / frames;
     if (b > per_frame_max) b = per_frame_max;
     return b ? b : 1;
 }
@@ -729,7 +779,8 @@ hipError_t launch_token_histogram(const uint8_t *src, uint64_t n, uint64_t strid
     hipError_t e = hipMemsetAsync(d_hist, 0, (size_t)frames * (kMatchThresholds + 1) * kDeflateSymbols * sizeof(unsigned long long), s);
     if (e != hipSuccess || n == 0 || frames == 0) return e;
     const u32 nchunks = huffman_chunks(n);
-    hipLaunchKernelGGL(k_token_hist, dim3(blocks_for(nchunks, frames), frames), dim3(kPackThreads), 0, s, src, n, stride, nchunks, d_hist);
+    static const u32 resident = resident_workgroups(k_token_hist);
+    hipLaunchKernelGGL(k_token_hist, dim3(blocks_for(nchunks, frames, resident), frames), dim3(kPackThreads), 0, s, src, n, stride, nchunks, d_hist);
     return hipGetLastError();
 }
 
@@ -740,8 +791,9 @@ hipError_t launch_huffman_pack(const uint8_t *src, uint64_t n, uint64_t stride, 
     const u32 nchunks = huffman_chunks(n);
     if (nchunks == 0 || frames == 0) return hipSuccess;
     const DeflatePlan *plans = static_cast<const DeflatePlan *>(d_plans);
-    const dim3 grid(blocks_for(nchunks, frames), frames);
-    hipLaunchKernelGGL(k_token_count, grid, dim3(kPackThreads), 0, s, src, n, stride, nchunks, plans, dist_code, d_chunk_bits);
+    static const u32 resident_count = resident_workgroups(k_token_count), resident_pack = resident_workgroups(k_token_pack);
+    const dim3 grid_count(blocks_for(nchunks, frames, resident_count), frames), grid(blocks_for(nchunks, frames, resident_pack), frames);
+    hipLaunchKernelGGL(k_token_count, grid_count, dim3(kPackThreads), 0, s, src, n, stride, nchunks, plans, dist_code, d_chunk_bits);
     hipLaunchKernelGGL(k_huff_scan, dim3(frames), dim3(1024), 0, s, d_chunk_bits, d_chunk_off, nchunks, d_totals, plans, d_outs, out_stride);
     hipLaunchKernelGGL(k_token_pack, grid, dim3(kPackThreads), 0, s, src, n, stride, nchunks, plans, dist_code, d_chunk_off, d_outs, out_stride);
     return hipGetLastError();

@@ -12,9 +12,9 @@ _ffi.check(L.hgi_synth_u8_dev(ctx.handle, _ffi.SYNTH_RAMP, 0x48474930 + 3, 0, S,
 _ffi.check(L.hgi_encode_u8_dev(ctx.handle, imgs.data_ptr(), S, S, 4, 1, lut.ctypes.data, grids.data_ptr(), F, S * S))
 torch.cuda.synchronize()
 cap = S * S // 2
-out = np.zeros((F, cap), np.uint8)
+out = torch.zeros((F, cap), dtype=torch.uint8, pin_memory=bool(os.environ.get("PINNED")))
 sizes = (ctypes.c_size_t * F)()
 for i in range(4):
     t0 = time.perf_counter()
-    _ffi.check(L.hgi_deflate_grids_dev(ctx.handle, grids.data_ptr(), S, S, F, S * S, out.ctypes.data, cap, sizes))
+    _ffi.check(L.hgi_deflate_grids_dev(ctx.handle, grids.data_ptr(), S, S, F, S * S, out.data_ptr(), cap, sizes))
     print("call %d: %.2f ms, %d bytes" % (i, (time.perf_counter() - t0) * 1e3, sum(sizes)))
