@@ -41,7 +41,10 @@ def test_every_translation_unit_is_hazard_free(tmp_path):
         r = check_isa.check(_isa(tmp_path, tu))
         assert r["adjacent_dependent"] == 0, (tu, r["examples"])
         assert r["store_data_overwritten"] == 0, (tu, "data VGPR of a buffer store redefined too early", r["examples"])
-        assert r["dpp"] == 0, (tu, "DPP next to opaque SDWA asm is not allowed", r)
+        # DPP is ruled out where inline SDWA asm hides register writes from the compiler's hazard bookkeeping (the codec
+        # kernels); a unit without partial-register writes (the entropy stage's scans) leaves DPP hazards to the compiler
+        if r["partial_writes"]:
+            assert r["dpp"] == 0, (tu, "DPP next to opaque SDWA asm is not allowed", r)
         assert r["scratch_bytes"] == 0 and r["vgpr_spills"] == 0, (tu, r)
         assert r["traps"] == 0, (tu, "s_trap in shipped ISA: the device must never abort", r)
 

@@ -105,5 +105,6 @@ if __name__ == "__main__":
     print({k: v for k, v in r.items() if k != "examples"})
     for cur, nxt in r["examples"]:
         print("  ", cur, "\n     ->", nxt)
-    sys.exit(1 if r["adjacent_dependent"] or r["scratch_bytes"] or r["vgpr_spills"] or r["dpp"] or r["store_data_overwritten"]
-             or r["traps"] else 0)
+    # DPP only counts against a unit that also has inline SDWA asm (partial writes the compiler cannot see)
+    sys.exit(1 if r["adjacent_dependent"] or r["scratch_bytes"] or r["vgpr_spills"] or (r["dpp"] and r["partial_writes"])
+             or r["store_data_overwritten"] or r["traps"] else 0)
