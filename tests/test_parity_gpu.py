@@ -967,3 +967,83 @@ def test_device_entropy_stream_equals_the_restated_one(H, oracle, lena, case):
     assert zlib.decompressobj(-15).decompress(got) == struct.pack("<Q", w * h) + grid.tobytes() + struct.pack("<Q", w)
     assert got == want, (len(got), len(want))
 
+
+
+@pytest.mark.gpu
+def test_device_entropy_random_shapes_byte_exact(H, oracle):
+    """Thirty random shapes and byte distributions (1 .. ~60 000 bytes; ends inside a lane, inside a chunk, on a chunk
+    boundary): the device's stream equals the restated one byte for byte."""
+    import torch
+    from rustyhgi_amd import entropy
+    from test_entropy import stage_stream
+    rng = np.random.default_rng(SEED0 + 101)
+    for case in range(30):
+        w, h = int(rng.integers(1, 400)), int(rng.integers(1, 150))
+        if case == 0:
+            w, h = 1024, 3          # ends on a chunk boundary
+        kind = case % 5
+        if kind == 0:
+            grid = (rng.geometric(0.6, (h, w)) - 1).astype(np.uint8)
+        elif kind == 1:
+            grid = _run_structured(rng, w * h, int(rng.integers(2, 30)), 6).reshape(h, w)
+        elif kind == 2:
+            grid = rng.integers(0, 256, (h, w), dtype=np.uint8)
+        elif kind == 3:
+            grid = _run_structured(rng, w * h, 600, 2).reshape(h, w)
+        else:
+            grid = np.where(rng.random((h, w)) < 0.03, rng.integers(1, 256, (h, w)), 0).astype(np.uint8)
+        grid = np.ascontiguousarray(grid)
+        got = entropy.deflate_grid(torch.from_numpy(grid).cuda())
+        assert got == stage_stream(grid.tobytes(), w), (case, w, h, kind)
+
+
+@pytest.mark.gpu
+def test_device_entropy_batch_with_unaligned_stride(H, oracle):
+    """hgi_deflate_grids_dev with frames an odd number of bytes apart (nothing about the stage needs aligned frames) and
+    more frames than one group holds is not needed for that: seven frames, stride = n + 3, each stream equal to the
+    single-frame call's."""
+    import ctypes
+    import torch
+    from rustyhgi_amd import _ffi, entropy
+    rng = np.random.default_rng(SEED0 + 102)
+    w, h, frames = 333, 97, 7
+    n, stride = w * h, w * h + 3
+    flat = np.zeros(frames * stride, np.uint8)
+    grids = []
+    for f in range(frames):
+        g = _run_structured(rng, n, 3 + 5 * f, 5)
+        flat[f * stride:f * stride + n] = g
+        flat[f * stride + n:(f + 1) * stride] = 0xAB          # must not leak into any stream
+        grids.append(g)
+    d = torch.from_numpy(flat).cuda()
+    ctx = H.Context(0)
+    cap = n + n // 8 + 1024
+    out = np.zeros((frames, cap), np.uint8)
+    sizes = (ctypes.c_size_t * frames)()
+    _ffi.check(_ffi.lib().hgi_deflate_grids_dev(ctx.handle, d.data_ptr(), w, h, frames, stride, out.ctypes.data, cap, sizes))
+    for f in range(frames):
+        one = entropy.deflate_grid(torch.from_numpy(grids[f].reshape(h, w)).cuda(), context=ctx)
+        assert out[f, :sizes[f]].tobytes() == one, f
+    ctx.close()
+
+
+@pytest.mark.gpu
+def test_device_entropy_many_groups_pipeline(H, oracle):
+    """A batch large enough to be pipelined in several groups (frames of 2.4 MB: a group holds ~ 85): 200 frames, every
+    stream inflates to its grid and frames that are equal give equal streams."""
+    import struct
+    import zlib
+    import torch
+    from rustyhgi_amd import entropy
+    rng = np.random.default_rng(SEED0 + 103)
+    w, h, frames = 1600, 1500, 200
+    base = [np.ascontiguousarray(_run_structured(rng, w * h, 4 + 3 * i, 4).reshape(h, w)) for i in range(4)]
+    d = torch.empty((frames, h, w), dtype=torch.uint8, device="cuda")
+    for i in range(4):
+        d[i::4] = torch.from_numpy(base[i]).cuda()
+    streams = entropy.deflate_grids(d)
+    assert len(streams) == frames
+    for i in range(4):
+        body = struct.pack("<Q", w * h) + base[i].tobytes() + struct.pack("<Q", w)
+        assert zlib.decompressobj(-15).decompress(streams[i]) == body
+        assert all(streams[f] == streams[i] for f in range(i, frames, 4)), i
