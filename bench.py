@@ -268,6 +268,7 @@ def run_rank(args):
     pfine = codec.p_fine() if rank == 0 and not (args.no_pfine or args.no_extras) else None
     placement = codec.placement(compare=not args.no_extras) if rank == 0 else None
     xgmi = codec.xgmi(dist, world, rank, fence, args.steps) if args.xgmi_scatter and not args.share_gpu else None
+    entropy = codec.entropy_stage() if rank == 0 and world == 1 and not args.no_extras else None
 
     # ---- per-rank checks + stats gather (RCCL all-gather) ----
     allst = batch.gather_stats(dist, codec.stats().to(cdev))
@@ -316,6 +317,8 @@ def run_rank(args):
             line["p_fine"] = pfine
         if xgmi is not None:
             line["xgmi_scatter_gather"] = xgmi
+        if entropy is not None:
+            line["entropy_stage"] = entropy
         if world == 1 and not args.no_cpu:
             line["cpu_baseline"] = cpu_baseline(args, lut, codec.sample())
         emit(json.dumps(line))
@@ -567,6 +570,40 @@ class Codec:
                                            "same_bytes_as_timed_run": same}
         del a, b, c
         return info
+
+    def entropy_stage(self):
+        """SURVEY 8(f4) and beyond: the archive's DEFLATE step (src/archive.rs:34-40) for this shard's grids, on the
+        device (hgi_deflate_grids_dev) -- bytes out and time, streams into a pinned host buffer.  An
+        extra beside the headline, never part of it; one stream is inflated with zlib as a check."""
+        import ctypes
+        import struct
+        import time
+        import zlib
+        torch, _ffi, F, S = self.torch, self._ffi, self.F, self.S
+        try:
+            cap = S * S // 2 + 4096
+            out = torch.empty((F, cap), dtype=torch.uint8, pin_memory=True)
+            sizes = (ctypes.c_size_t * F)()
+            def call():
+                _ffi.check(_ffi.lib().hgi_deflate_grids_dev(self.ctx.handle, self.grids.data_ptr(), S, S, F, S * S, out.data_ptr(), cap, sizes))
+            call()
+            ts = []
+            for _ in range(3):
+                t0 = time.perf_counter()
+                call()
+                ts.append(time.perf_counter() - t0)
+            t = sorted(ts)[1]
+            total = int(sum(sizes))
+            body = zlib.decompressobj(-15).decompress(bytes(out[0, :sizes[0]].numpy()))
+            ok = body == struct.pack("<Q", S * S) + self.grids[0].cpu().numpy().tobytes() + struct.pack("<Q", S)
+            res = {"api": "hgi_deflate_grids_dev: raw DEFLATE (dynamic Huffman, literals + run matches) of each grid's bincode image",
+                   "frames": F, "grid_bytes": F * S * S, "stream_bytes": total, "ratio": round(F * S * S / max(total, 1), 2),
+                   "ms": round(t * 1e3, 3), "grid_gb_s": round(F * S * S / t / 1e9, 1), "host_buffer": "pinned",
+                   "first_stream_inflates_to_its_grid": bool(ok)}
+            del out
+            return res
+        except Exception as e:      # an extra: never let it cost the line
+            return {"error": "%s: %s" % (type(e).__name__, e)}
 
     def stats(self):
         torch, _ffi, F, S = self.torch, self._ffi, self.F, self.S
