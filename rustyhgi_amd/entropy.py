@@ -62,7 +62,8 @@ def deflate_grid(grid, context=None):
 
 def deflate_grids(grids, context=None):
     """(B, H, W) uint8 CUDA tensor -> list of B bytes objects, each the raw DEFLATE stream of that grid's bincode image
-    (hgi_deflate_grids_dev: the stage's phases run over the whole batch, three host waits per group of frames)."""
+    (hgi_deflate_grids_dev: the batch is pipelined in groups of frames -- one launch per phase per group, codes built on
+    the host while the device histograms the next group, streams downloaded while the next group is coded)."""
     import ctypes
     import torch
     if grids.dim() != 3 or grids.dtype != torch.uint8 or not grids.is_cuda or not grids.is_contiguous():
