@@ -106,26 +106,49 @@ SubGeom sub_geom(uint32_t w, uint32_t h, uint32_t k)
 // (the reconstruction feeds the tile kernel as seeds), each of which recurses on its own.
 size_t plane_bytes(const SubGeom &g, size_t batch) { return align_up(batch * g.stride, 256) + 256; }
 
+// How many of a pyramid's levels the tile kernel takes when the pyramid is deeper than a tile (the rest is the lattice
+// plane's own pyramid, coded first).  Six -- everything a 64-row tile holds -- unless the frame is so large that its
+// stride-64 lattice is itself a sizeable image (>= 200 x 200 points: a lone 16384^2 frame): there the encoder's tile
+// kernel at k = 4 saves more than the larger lattice plane costs (measured, tools/c4_time.py, 16384^2 level 8 encode:
+// 125.5 us at k = 6, 119.5 at 5, 115.8 at 4; decode 105.9 / 107.8 / 108.0; smaller frames and batches of 4K frames
+// are faster at 6 in both directions).  Any depth from kSeededMinLevels up gives the same bytes.
+// HGI_DEEP_K_ENC / HGI_DEEP_K_DEC in the environment force one (experiments, tests).
+uint32_t fused_depth(uint32_t w, uint32_t h, uint32_t levels, bool encode)
+{
+    if (levels <= (uint32_t)kFusedMaxLevels) return levels;
+    static const int forced[2] = {getenv("HGI_DEEP_K_DEC") ? atoi(getenv("HGI_DEEP_K_DEC")) : 0,
+                                  getenv("HGI_DEEP_K_ENC") ? atoi(getenv("HGI_DEEP_K_ENC")) : 0};
+    const int f = forced[encode ? 1 : 0];
+    if (f >= kSeededMinLevels && f <= kFusedMaxLevels) return (uint32_t)f;
+    if (encode) {
+        const SubGeom g = sub_geom(w, h, kFusedMaxLevels);
+        if ((uint64_t)g.sw * g.sh >= 40000) return 4;
+    }
+    return (uint32_t)kFusedMaxLevels;
+}
+
 size_t ws_need_decode(uint32_t w, uint32_t h, uint32_t levels, size_t batch)
 {
     if (levels <= (uint32_t)kFusedMaxLevels) return 0;
-    const SubGeom g = sub_geom(w, h, kFusedMaxLevels);
-    return 2 * plane_bytes(g, batch) + ws_need_decode(g.sw, g.sh, levels - kFusedMaxLevels, batch);
+    const uint32_t k = fused_depth(w, h, levels, false);
+    const SubGeom g = sub_geom(w, h, k);
+    return 2 * plane_bytes(g, batch) + ws_need_decode(g.sw, g.sh, levels - k, batch);
 }
 
 size_t ws_need_encode(uint32_t w, uint32_t h, uint32_t levels, size_t batch)
 {
     if (levels <= (uint32_t)kFusedMaxLevels) return 0;
-    const SubGeom g = sub_geom(w, h, kFusedMaxLevels);
-    return 3 * plane_bytes(g, batch) + ws_need_encode(g.sw, g.sh, levels - kFusedMaxLevels, batch) +
-           ws_need_decode(g.sw, g.sh, levels - kFusedMaxLevels, batch);
+    const uint32_t k = fused_depth(w, h, levels, true);
+    const SubGeom g = sub_geom(w, h, k);
+    return 3 * plane_bytes(g, batch) + ws_need_encode(g.sw, g.sh, levels - k, batch) + ws_need_decode(g.sw, g.sh, levels - k, batch);
 }
 
 size_t ws_need(const hgi_ctx *c, uint32_t w, uint32_t h, uint32_t levels, size_t batch, size_t stride)
 {
     if (levels == 0) return 0;
     if (c->path == HGI_PATH_LEVELWISE) return align_up(batch * stride, 256) + 256;
-    return ws_need_encode(w, h, levels, batch);   // >= the decode need
+    const size_t e = ws_need_encode(w, h, levels, batch), d = ws_need_decode(w, h, levels, batch);
+    return e > d ? e : d;
 }
 
 // Tile geometry of a fused launch.  128 x 64 tiles are the throughput shape; a call whose 64-row tiles would not
@@ -206,7 +229,7 @@ hgi_status encode_impl(hgi_ctx *c, const uint8_t *img, uint32_t w, uint32_t h, u
             HIP_TRY(launch_encode_level(rec, grid, f, levels - level - 1, interp, l, c->stream));
         return HGI_OK;
     }
-    const uint32_t k = levels < (uint32_t)kFusedMaxLevels ? levels : (uint32_t)kFusedMaxLevels;
+    const uint32_t k = fused_depth(w, h, levels, true);
     if (levels > k) {
         // Deeper pyramid: the lattice = 0 (mod 2^k) is itself an HGI image with levels-k levels
         // (same OOB rule: x < W <=> x >> k < ceil(W / 2^k) on the lattice).  Code it first, then
@@ -247,7 +270,7 @@ hgi_status decode_impl(hgi_ctx *c, const uint8_t *grid, uint32_t w, uint32_t h, 
             HIP_TRY(launch_decode_level(grid, img, f, levels - level - 1, interp, c->stream));
         return HGI_OK;
     }
-    const uint32_t k = levels < (uint32_t)kFusedMaxLevels ? levels : (uint32_t)kFusedMaxLevels;
+    const uint32_t k = fused_depth(w, h, levels, false);
     if (levels > k) {
         SubGeom g = sub_geom(w, h, k);
         uint8_t *sub_grid = ws_take(c, batch * g.stride);

@@ -1618,6 +1618,7 @@ hipError_t HGI_TILED(launch_decode_fused)(const uint8_t *grid, uint8_t *img, con
     FusedGeom r = fused_geom(grid, img, f, row_limit);
     if (!r.ok || k < 1 || k > (u32)MAXK) return hipErrorInvalidValue;
     const TileGrid &g = r.g;
+    if (seeds && k < (uint32_t)kSeededMinLevels) return hipErrorInvalidValue;      // one lane per lattice point (seed_issue)
     Seeds sd = seeds ? *seeds : Seeds{nullptr, nullptr, 0, 0, 0};
     const dim3 b(NL);
     const int nh = k >= 2 ? (int)k : 1;
@@ -1652,6 +1653,7 @@ hipError_t HGI_TILED(launch_encode_fused)(const uint8_t *img, uint8_t *grid, con
     FusedGeom r = fused_geom(img, grid, f, row_limit);
     if (!r.ok || k < 1 || k > (u32)MAXK) return hipErrorInvalidValue;
     const TileGrid &g = r.g;
+    if (seeds && k < (uint32_t)kSeededMinLevels) return hipErrorInvalidValue;      // one lane per lattice point (seed_issue)
     Seeds sd = seeds ? *seeds : Seeds{nullptr, nullptr, 0, 0, 0};
     const dim3 b(NL);
     const int nh = k >= 2 ? (int)k : 1;

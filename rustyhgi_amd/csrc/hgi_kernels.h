@@ -15,6 +15,7 @@ constexpr int kInterpCrossed = 1;
 constexpr int kTileW = 128;   // pixels per tile row: 8 lanes x 16 B = one 128-B line
 constexpr int kFusedMaxLevels = 6;        // 2^k <= 64: deepest pyramid a 64-row tile can hold
 constexpr int kFusedMaxLevelsSmall = 5;   // ... and a 32-row tile
+constexpr int kSeededMinLevels = 4;       // a seeded launch gives each lattice point of a tile's halo frame a lane: (128 >> k) + 2 by (64 >> k) + 2 <= 64
 constexpr int kThreads = 64;  // ONE wave owns a tile: no workgroup barriers anywhere
 
 // 256-entry quantizer table passed BY VALUE in the kernarg segment: no device-side table to

@@ -1,0 +1,36 @@
+"""C4 (16384^2, level 8, High) device-resident, steady state: encode and decode times by HIP events, and bit-exactness
+of the round trip against the default split (HGI_DEEP_K_ENC / HGI_DEEP_K_DEC select how many levels the tile kernel takes)."""
+import os, sys, hashlib, numpy as np, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import rustyhgi_amd as H
+from rustyhgi_amd import _ffi
+L = _ffi.lib()
+ctx = H.Context(0); ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+W = Hh = int(os.environ.get("C4_SIZE", "16384")); n = W * Hh
+LEVELS = int(os.environ.get("C4_LEVELS", "8"))
+lut = np.zeros(256, np.uint8); err = np.zeros(1, np.uint8)
+_ffi.check(L.hgi_linear_lut(3, lut.ctypes.data, err.ctypes.data))
+F = int(os.environ.get("C4_FRAMES", "1"))
+planes = H.Planes(ctx, F * n, 3)
+img, grid, out = (planes.torch(i, (F, Hh, W)) for i in range(3))
+_ffi.check(L.hgi_synth_u8_dev(ctx.handle, _ffi.SYNTH_RAMP, 0x48474933 + 4, 0, W, Hh, img.data_ptr(), F, n))
+def enc(): _ffi.check(L.hgi_encode_u8_dev(ctx.handle, img.data_ptr(), W, Hh, LEVELS, 1, lut.ctypes.data, grid.data_ptr(), F, n))
+def dec(): _ffi.check(L.hgi_decode_u8_dev(ctx.handle, grid.data_ptr(), W, Hh, LEVELS, 1, out.data_ptr(), F, n))
+for _ in range(60): enc(); dec()
+reps = 40
+ev = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(reps)]
+for e in ev:
+    e[0].record(); enc(); e[1].record(); dec(); e[2].record()
+torch.cuda.synchronize()
+te = np.median([e[0].elapsed_time(e[1]) for e in ev]) * 1e3; td = np.median([e[1].elapsed_time(e[2]) for e in ev]) * 1e3
+def alone(fn):
+    for _ in range(40): fn()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(reps): fn()
+    b.record(); torch.cuda.synchronize()
+    return a.elapsed_time(b) / reps * 1e3
+te1, td1 = alone(enc), alone(dec)
+hg = hashlib.sha256(grid.cpu().numpy().tobytes()).hexdigest()[:16]; ho = hashlib.sha256(out.cpu().numpy().tobytes()).hexdigest()[:16]
+print("k_enc=%s k_dec=%s  %d x %dx%d L%d: encode %.1f us (%.0f GB/s)  decode %.1f us (%.0f GB/s)  | back to back: encode %.1f decode %.1f us | grid %s out %s" % (
+    os.environ.get("HGI_DEEP_K_ENC", "6"), os.environ.get("HGI_DEEP_K_DEC", "6"), F, W, Hh, LEVELS, te, 2 * F * n / te / 1e3, td, 2 * F * n / td / 1e3, te1, td1, hg, ho))
