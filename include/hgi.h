@@ -28,6 +28,14 @@
 #include <stddef.h>
 #include <stdint.h>
 
+/* The shared object exports the entry points declared here and nothing else (built with        */
+/* -fvisibility=hidden and a linker version script; tests/test_abi.py compares both directions). */
+#if defined(__GNUC__) || defined(__clang__)
+#define HGI_API __attribute__((visibility("default")))
+#else
+#define HGI_API
+#endif
+
 #ifdef __cplusplus
 extern "C" {
 #endif
@@ -66,47 +74,47 @@ typedef enum { HGI_SYNTH_XY = 0, HGI_SYNTH_NOISE = 1, HGI_SYNTH_RAMP = 2 } hgi_s
 
 /* ---- context ---------------------------------------------------------------------- */
 /* Owns the device id, a stream and scratch memory.  device >= 0 is a HIP ordinal.     */
-hgi_status hgi_ctx_create(int device, hgi_ctx **out);
-void hgi_ctx_destroy(hgi_ctx *ctx);
+HGI_API hgi_status hgi_ctx_create(int device, hgi_ctx **out);
+HGI_API void hgi_ctx_destroy(hgi_ctx *ctx);
 /* Borrow the caller's hipStream_t, used verbatim: NULL is HIP's default (null) stream,   */
 /* which is what torch.cuda.current_stream() is unless a side stream is active.           */
-hgi_status hgi_ctx_set_stream(hgi_ctx *ctx, void *hip_stream);
+HGI_API hgi_status hgi_ctx_set_stream(hgi_ctx *ctx, void *hip_stream);
 /* Return to the ctx's private non-blocking stream (the state after hgi_ctx_create).      */
-hgi_status hgi_ctx_use_own_stream(hgi_ctx *ctx);
-hgi_status hgi_ctx_set_path(hgi_ctx *ctx, hgi_path path);
+HGI_API hgi_status hgi_ctx_use_own_stream(hgi_ctx *ctx);
+HGI_API hgi_status hgi_ctx_set_path(hgi_ctx *ctx, hgi_path path);
 /* Pre-size scratch so later *_dev calls allocate nothing (needed before graph capture). */
 /* Scratch only grows, and growing it FREES the old block: a HIP graph captured from calls */
 /* that used scratch (levels > 6) keeps pointing at the block it was captured with, so     */
 /* reserve for the largest shape the ctx will ever see BEFORE capturing, and do not let a  */
 /* later, larger call on the same ctx grow it while such graphs are alive.                 */
-hgi_status hgi_ctx_reserve(hgi_ctx *ctx, uint32_t width, uint32_t height, uint32_t levels,
+HGI_API hgi_status hgi_ctx_reserve(hgi_ctx *ctx, uint32_t width, uint32_t height, uint32_t levels,
                            size_t batch);
-hgi_status hgi_sync(hgi_ctx *ctx);
-const char *hgi_last_error(void);
-const char *hgi_version(void);
+HGI_API hgi_status hgi_sync(hgi_ctx *ctx);
+HGI_API const char *hgi_last_error(void);
+HGI_API const char *hgi_version(void);
 
 /* ---- quantizers (host side: any Quantizator is tabulated into 256 bytes) ----------- */
 /* replaces Linear::from(QuantizationLevel) + Linear::error, src/quantizator.rs:41-63,71 */
-hgi_status hgi_linear_lut(int level, uint8_t lut[256], uint8_t *max_err);
+HGI_API hgi_status hgi_linear_lut(int level, uint8_t lut[256], uint8_t *max_err);
 /* replaces NoOp::quantize, src/quantizator.rs:26-29 */
-void hgi_noop_lut(uint8_t lut[256]);
+HGI_API void hgi_noop_lut(uint8_t lut[256]);
 
 /* ---- host-pointer, synchronous ------------------------------------------------------ */
 /* replaces Encoder::<I,Q>::new(..).encode(image) -> Grid, src/encoder.rs:18,39          */
-hgi_status hgi_encode_u8(hgi_ctx *ctx, const uint8_t *img, uint32_t width, uint32_t height,
+HGI_API hgi_status hgi_encode_u8(hgi_ctx *ctx, const uint8_t *img, uint32_t width, uint32_t height,
                          uint32_t levels, hgi_interp interp, const uint8_t lut[256],
                          uint8_t *grid_out);
 /* replaces Decoder::<I>::new(..).decode((w,h), levels, &grid) -> GrayImage, src/decoder.rs:14,18 */
-hgi_status hgi_decode_u8(hgi_ctx *ctx, const uint8_t *grid, uint32_t width, uint32_t height,
+HGI_API hgi_status hgi_decode_u8(hgi_ctx *ctx, const uint8_t *grid, uint32_t width, uint32_t height,
                          uint32_t levels, hgi_interp interp, uint8_t *img_out);
 
 /* ---- device-pointer, asynchronous on the ctx stream, batched -------------------------- */
 /* Same semantics per frame; `lut` is a HOST pointer (256 bytes, copied into the launch).   */
 /* frame_stride >= width*height; d_img / d_grid must not alias.                            */
-hgi_status hgi_encode_u8_dev(hgi_ctx *ctx, const void *d_img, uint32_t width, uint32_t height,
+HGI_API hgi_status hgi_encode_u8_dev(hgi_ctx *ctx, const void *d_img, uint32_t width, uint32_t height,
                              uint32_t levels, hgi_interp interp, const uint8_t lut[256],
                              void *d_grid, size_t batch, size_t frame_stride);
-hgi_status hgi_decode_u8_dev(hgi_ctx *ctx, const void *d_grid, uint32_t width, uint32_t height,
+HGI_API hgi_status hgi_decode_u8_dev(hgi_ctx *ctx, const void *d_grid, uint32_t width, uint32_t height,
                              uint32_t levels, hgi_interp interp, void *d_img, size_t batch,
                              size_t frame_stride);
 
@@ -115,10 +123,10 @@ hgi_status hgi_decode_u8_dev(hgi_ctx *ctx, const void *d_grid, uint32_t width, u
 /* Synchronous like hgi_encode_u8 / hgi_decode_u8, but the frames are pipelined through the  */
 /* device in chunks on two internal streams, so uploads overlap downloads (PCIe is full      */
 /* duplex) and the kernels disappear behind the transfers.  Input and output must not alias. */
-hgi_status hgi_encode_u8_batch(hgi_ctx *ctx, const uint8_t *imgs, uint32_t width, uint32_t height,
+HGI_API hgi_status hgi_encode_u8_batch(hgi_ctx *ctx, const uint8_t *imgs, uint32_t width, uint32_t height,
                                uint32_t levels, hgi_interp interp, const uint8_t lut[256],
                                uint8_t *grids_out, size_t batch, size_t frame_stride);
-hgi_status hgi_decode_u8_batch(hgi_ctx *ctx, const uint8_t *grids, uint32_t width, uint32_t height,
+HGI_API hgi_status hgi_decode_u8_batch(hgi_ctx *ctx, const uint8_t *grids, uint32_t width, uint32_t height,
                                uint32_t levels, hgi_interp interp, uint8_t *imgs_out, size_t batch,
                                size_t frame_stride);
 
@@ -127,20 +135,20 @@ hgi_status hgi_decode_u8_batch(hgi_ctx *ctx, const uint8_t *grids, uint32_t widt
 /* Byte histogram of each frame of a grid batch, on the device, async on the ctx stream:     */
 /* d_hist[256*f + v] = number of pixels of frame f equal to v.  d_hist: 256*batch uint64 of  */
 /* device memory (overwritten).  Any width, stride and alignment.                            */
-hgi_status hgi_histogram_u8_dev(hgi_ctx *ctx, const void *d_grid, uint32_t width, uint32_t height,
+HGI_API hgi_status hgi_histogram_u8_dev(hgi_ctx *ctx, const void *d_grid, uint32_t width, uint32_t height,
                                 size_t batch, size_t frame_stride, void *d_hist);
 
 /* ---- harness helpers (not part of the reference surface) ------------------------------ */
 /* Fill `batch` frames with a synthetic pattern; frame f uses index first_frame + f.        */
-hgi_status hgi_synth_u8_dev(hgi_ctx *ctx, hgi_synth_kind kind, uint64_t seed,
+HGI_API hgi_status hgi_synth_u8_dev(hgi_ctx *ctx, hgi_synth_kind kind, uint64_t seed,
                             uint64_t first_frame, uint32_t width, uint32_t height, void *d_out,
                             size_t batch, size_t frame_stride);
 /* Streaming copy of n bytes (16-B vectors): the same-run HBM copy ceiling.                 */
-hgi_status hgi_copy_u8_dev(hgi_ctx *ctx, const void *d_src, void *d_dst, size_t n);
+HGI_API hgi_status hgi_copy_u8_dev(hgi_ctx *ctx, const void *d_src, void *d_dst, size_t n);
 /* Per-frame statistics of before/after pairs as `hgi test` prints them (src/main.rs:84-92): */
 /* out[3*f+0] = sum of squared differences, +1 = max abs difference, +2 = count of differing */
 /* pixels.  d_out is device memory for 3*batch uint64.                                       */
-hgi_status hgi_diff_stats_dev(hgi_ctx *ctx, const void *d_before, const void *d_after,
+HGI_API hgi_status hgi_diff_stats_dev(hgi_ctx *ctx, const void *d_before, const void *d_after,
                               uint32_t width, uint32_t height, size_t batch, size_t frame_stride,
                               void *d_out);
 /* ---- entropy stage on the device (the step behind src/archive.rs:34-40) ------------------- */
@@ -155,7 +163,7 @@ hgi_status hgi_diff_stats_dev(hgi_ctx *ctx, const void *d_before, const void *d_
 /* Medium: 14.5 against 16.0 kB) -- and written two to four orders of magnitude sooner.        */
 /* `out` is host memory; *bytes receives the stream length; HGI_EINVAL if cap is too small     */
 /* (w*h + w*h/8 + 1024 always suffices).  Synchronous on the ctx stream.                        */
-hgi_status hgi_deflate_grid_dev(hgi_ctx *ctx, const void *d_grid, uint32_t width, uint32_t height,
+HGI_API hgi_status hgi_deflate_grid_dev(hgi_ctx *ctx, const void *d_grid, uint32_t width, uint32_t height,
                                 uint8_t *out, size_t cap, size_t *bytes);
 /* `batch` grids `frame_stride` bytes apart in device memory: stream f is written to            */
 /* out + f * out_stride (host memory; out_stride is also each stream's capacity), sizes[f] = its */
@@ -164,16 +172,16 @@ hgi_status hgi_deflate_grid_dev(hgi_ctx *ctx, const void *d_grid, uint32_t width
 /* the next, a group's streams going down while the next is coded.  The downloads bound the    */
 /* call; they are faster into pinned host memory (a 1 GiB batch: 5.5 ms pageable, 4.5 pinned). */
 /* `out` is written from a second stream internally; the call returns when everything is done. */
-hgi_status hgi_deflate_grids_dev(hgi_ctx *ctx, const void *d_grids, uint32_t width, uint32_t height, size_t batch,
+HGI_API hgi_status hgi_deflate_grids_dev(hgi_ctx *ctx, const void *d_grids, uint32_t width, uint32_t height, size_t batch,
                                  size_t frame_stride, uint8_t *out, size_t out_stride, size_t *sizes);
 /* The same with the grid in host memory (what pairs with hgi_encode_u8).                      */
-hgi_status hgi_deflate_grid(hgi_ctx *ctx, const uint8_t *grid, uint32_t width, uint32_t height,
+HGI_API hgi_status hgi_deflate_grid(hgi_ctx *ctx, const uint8_t *grid, uint32_t width, uint32_t height,
                             uint8_t *out, size_t cap, size_t *bytes);
 /* The code construction alone (host only): lengths (<= 15) and bit-reversed canonical codes    */
 /* of the 286 symbols -- literals 0..255, end of block 256 (hist[256]), match lengths 257..285 */
 /* -- for the given counts, and the block header (BFINAL = 1, dynamic, 286 + 2 codes; distance */
 /* code 0 = distance 1 is the one-bit code "0") that announces them; *header_bits = its length.*/
-hgi_status hgi_huffman_plan(const uint64_t hist[286], uint8_t lens[286], uint16_t codes[286],
+HGI_API hgi_status hgi_huffman_plan(const uint64_t hist[286], uint8_t lens[286], uint16_t codes[286],
                             uint8_t *header, size_t header_cap, size_t *header_bits);
 
 /* ---- plane placement (no reference counterpart: the reference's buffers are Vec<u8>) ---- */
@@ -189,15 +197,15 @@ hgi_status hgi_huffman_plan(const uint64_t hist[286], uint8_t lens[286], uint16_
 /* regions, 0 when that could not be established (planes below 512 MiB are not probed: such   */
 /* streams live in the Infinity Cache) -- the planes are valid either way.  Call it while the */
 /* device is otherwise idle: it measures.                                                      */
-hgi_status hgi_planes_alloc(hgi_ctx *ctx, size_t bytes, uint32_t count, void **planes, int *separated);
-hgi_status hgi_planes_free(hgi_ctx *ctx, uint32_t count, void **planes);
+HGI_API hgi_status hgi_planes_alloc(hgi_ctx *ctx, size_t bytes, uint32_t count, void **planes, int *separated);
+HGI_API hgi_status hgi_planes_free(hgi_ctx *ctx, uint32_t count, void **planes);
 /* The probe itself: mean milliseconds of one decode launch streaming d_src -> d_dst over      */
 /* min(bytes, 2 GiB).  Overwrites d_dst.  Compare pairings of the caller's own buffers with it. */
-hgi_status hgi_probe_pair_u8_dev(hgi_ctx *ctx, const void *d_src, void *d_dst, size_t bytes, float *ms);
+HGI_API hgi_status hgi_probe_pair_u8_dev(hgi_ctx *ctx, const void *d_src, void *d_dst, size_t bytes, float *ms);
 
 /* hipEvent pair on the ctx stream: start, ...launches..., stop -> elapsed milliseconds.     */
-hgi_status hgi_timer_start(hgi_ctx *ctx);
-hgi_status hgi_timer_stop(hgi_ctx *ctx, float *elapsed_ms);
+HGI_API hgi_status hgi_timer_start(hgi_ctx *ctx);
+HGI_API hgi_status hgi_timer_stop(hgi_ctx *ctx, float *elapsed_ms);
 
 #ifdef __cplusplus
 }

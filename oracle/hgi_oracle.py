@@ -9,7 +9,8 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_SO = os.path.join(_HERE, "_build", "libhgi_oracle.so")
+# HGI_ORACLE_SO: another build of the same source (tests/test_sanitizers.py loads the ASan/UBSan one in a child process)
+_SO = os.environ.get("HGI_ORACLE_SO") or os.path.join(_HERE, "_build", "libhgi_oracle.so")
 
 LEFTTOP, CROSSED = 0, 1
 LOSSLESS, LOW, MEDIUM, HIGH = 0, 1, 2, 3

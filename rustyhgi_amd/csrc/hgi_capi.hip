@@ -51,7 +51,9 @@ struct hgi_ctx {
     hgi_path path;
     uint8_t *ws;
     size_t ws_bytes, ws_used;
-    hipEvent_t ev0, ev1;
+    hipEvent_t ev0, ev1;      // hgi_timer_start / hgi_timer_stop, nothing else
+    hipEvent_t ev_hist[2];    // entropy stage: "histograms of group set k are down"
+    hipEvent_t ev_probe[2];   // placement probe
     // host-pointer batch calls (created on first use): pipe[0] uploads, pipe[1] runs the kernels and downloads;
     // three device slots, per slot one event "uploaded" and one "kernels done, input slot free"
     hipStream_t pipe[2];
@@ -302,13 +304,25 @@ hgi_status check_common(hgi_ctx *c, const void *a, const void *b, uint32_t level
     if (!a || !b) return fail(HGI_EINVAL, "NULL buffer");
     if (batch > 1 && stride < (size_t)w * h) return fail(HGI_EINVAL, "frame_stride %zu < width*height", stride);
     if (batch > 0x7fffffffu) return fail(HGI_EINVAL, "batch too large");
-    // The byte ranges [p, p + span) of input and output must be disjoint: the kernels read a tile's halo from frames the
-    // neighbouring tiles are writing.  (The reference consumes its input by value, src/encoder.rs:39: aliasing cannot
-    // happen there.)  Host and device pointers are compared alike -- under unified addressing they share one space.
+    // No input frame may share a byte with an output frame: the kernels read a tile's halo from frames the neighbouring
+    // tiles are writing.  (The reference consumes its input by value, src/encoder.rs:39: aliasing cannot happen there.)
+    // Frames are w*h bytes every `stride` bytes, so two frame trains that interleave inside one allocation (in = base,
+    // out = base + w*h, stride = 2*w*h) are fine; what is refused is a pair of frames i, j with
+    // |pa + i*stride - pb - j*stride| < w*h.  Host and device pointers are compared alike -- under unified addressing
+    // they share one space.
     const uintptr_t pa = reinterpret_cast<uintptr_t>(a), pb = reinterpret_cast<uintptr_t>(b);
-    const uintptr_t span = (uintptr_t)(batch - 1) * (batch > 1 ? stride : 0) + (uintptr_t)w * h;
-    if (pa < pb + span && pb < pa + span)
-        return fail(HGI_EINVAL, "input and output overlap (%zu bytes each): they must not alias", (size_t)span);
+    const uintptr_t n = (uintptr_t)w * h, delta = pa > pb ? pa - pb : pb - pa;
+    bool overlap;
+    if (batch == 1) {
+        overlap = delta < n;
+    } else {
+        // the frame-index difference m that brings the trains closest is delta / stride or one more
+        const uintptr_t q = delta / stride, r = delta % stride;
+        overlap = (q <= batch - 1 && r < n) || (q + 1 <= batch - 1 && stride - r < n);
+    }
+    if (overlap)
+        return fail(HGI_EINVAL, "an input frame and an output frame overlap (%zu bytes each, %zu apart): they must not alias",
+                    (size_t)n, (size_t)delta);
     return HGI_OK;
 }
 
@@ -340,8 +354,11 @@ hgi_status hgi_ctx_create(int device, hgi_ctx **out)
     c->pin = nullptr;
     c->pin_bytes = 0;
     if (hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) != hipSuccess ||
-        hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess) {
-        delete c;
+        hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ev_hist[0], hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ev_hist[1], hipEventDisableTiming) != hipSuccess ||
+        hipEventCreate(&c->ev_probe[0]) != hipSuccess || hipEventCreate(&c->ev_probe[1]) != hipSuccess) {
+        delete c;      // (a partial set is reclaimed with the process)
         return fail(HGI_EDEVICE, "stream/event creation failed");
     }
     c->stream = c->own_stream;
@@ -358,6 +375,10 @@ void hgi_ctx_destroy(hgi_ctx *c)
     if (c->pin) (void)hipHostFree(c->pin);
     (void)hipEventDestroy(c->ev0);
     (void)hipEventDestroy(c->ev1);
+    for (int i = 0; i < 2; ++i) {
+        (void)hipEventDestroy(c->ev_hist[i]);
+        (void)hipEventDestroy(c->ev_probe[i]);
+    }
     (void)hipStreamDestroy(c->own_stream);
     if (c->have_pipe) {
         (void)hipStreamDestroy(c->pipe[0]);
@@ -525,7 +546,9 @@ static hgi_status host_banded(hgi_ctx *c, const uint8_t *in, uint8_t *out, uint3
     if (!d_in || !d_out) return fail(HGI_ENOMEM, "scratch exhausted (host staging)");
     HIP_TRY(hipStreamSynchronize(c->stream));
     // Pyramids deeper than a tile: the stride-2^k lattice (every 64th pixel of every 64th row) is gathered on the host --
-    // it is tiny -- and goes up first; its seeds are ready long before the first band is.
+    // it is tiny -- and goes up first; its seeds are ready long before the first band is.  The split stays at six levels
+    // here whatever fused_depth() picks for device-resident frames: this path is bound by PCIe (6 ms for 16384^2 against
+    // 0.1 ms of kernels), so the tile kernel's depth does not show, and six keeps the host-side gather at w*h / 4096 bytes.
     const uint32_t k = levels < (uint32_t)kFusedMaxLevels ? levels : (uint32_t)kFusedMaxLevels;
     const bool deep = levels > k;
     SubGeom g = {0, 0, 0};
@@ -822,60 +845,7 @@ DeflateGeom deflate_geom(uint64_t n, size_t batch)
     return g;
 }
 
-struct FramePlan {
-    DeflatePlan block;               // what the device gets
-    uint64_t exact_bits = 0;         // length of the whole stream, known from the histograms
-};
-
-void put_bits(uint8_t *v, uint64_t &at, uint32_t value, int nb)
-{
-    for (int i = 0; i < nb; ++i, ++at) v[at >> 3] |= (uint8_t)(((value >> i) & 1u) << (at & 7));
-}
-
-// hists: [kMatchThresholds + 1][kDeflateSymbols] as downloaded (modified in place)
-hgi_status plan_frame(uint64_t (*hists)[kDeflateSymbols], bool have_grid, const uint8_t prefix[8], const uint8_t suffix[8], FramePlan &p)
-{
-    if (have_grid)
-        for (int v = 0; v < kMatchThresholds; ++v)
-            for (int sym = 0; sym < kDeflateSymbols; ++sym) hists[v][sym] += hists[kMatchThresholds][sym];
-    // for each candidate threshold: the code its histogram asks for and the exact size of the tokens under it; keep the
-    // smallest (the 16 bytes around the grid are literals under every threshold)
-    uint64_t best = ~0ull;
-    int pick = 0;
-    for (int v = 0; v < kMatchThresholds; ++v) {
-        uint64_t *hv = hists[v];
-        for (int i = 0; i < 8; ++i) {
-            ++hv[prefix[i]];
-            ++hv[suffix[i]];
-        }
-        hv[256] = 1;      // end of block
-        const uint64_t total = huffman_payload_bits(hv);
-        if (total < best) {
-            best = total;
-            pick = v;
-        }
-        if (!have_grid) break;
-    }
-    uint8_t lens[kDeflateSymbols];
-    uint16_t codes[kDeflateSymbols];
-    DeflatePlan &d = p.block;
-    std::memset(&d, 0, sizeof(d));
-    const size_t bits = huffman_plan(hists[pick], lens, codes, d.front, sizeof(d.front) - 32);
-    if (!bits) return fail(HGI_EDEVICE, "block header does not fit");
-    d.min_match = kMatchThresholdHost[pick];
-    p.exact_bits = best + bits;
-    d.base_bits = bits;
-    for (int i = 0; i < 8; ++i) put_bits(d.front, d.base_bits, codes[prefix[i]], lens[prefix[i]]);
-    d.front_bytes = (uint32_t)((d.base_bits + 7) / 8);
-    uint64_t tb = 0;
-    uint8_t tail[sizeof(d.tail)] = {};
-    for (int i = 0; i < 8; ++i) put_bits(tail, tb, codes[suffix[i]], lens[suffix[i]]);
-    put_bits(tail, tb, codes[256], lens[256]);
-    d.tail_bits = (uint32_t)tb;
-    std::memcpy(d.tail, tail, sizeof(tail));
-    for (int v = 0; v < kDeflateSymbols; ++v) d.table[v] = (uint32_t)codes[v] | ((uint32_t)lens[v] << 24);
-    return HGI_OK;
-}
+using huff::FramePlan;
 
 hgi_status pin_ensure(hgi_ctx *c, size_t bytes)
 {
@@ -913,7 +883,8 @@ hgi_status deflate_frames(hgi_ctx *c, const uint8_t *d_grids, uint32_t w, uint32
         // nothing for the device to code: the front, then the tail, here
         std::vector<uint64_t> hist0((kMatchThresholds + 1) * kDeflateSymbols, 0);
         FramePlan p;
-        HGI_TRY(plan_frame(reinterpret_cast<uint64_t (*)[kDeflateSymbols]>(hist0.data()), false, prefix, suffix, p));
+        if (!huff::plan_frame(reinterpret_cast<uint64_t (*)[kDeflateSymbols]>(hist0.data()), false, prefix, suffix, p))
+            return fail(HGI_EDEVICE, "block header does not fit");
         const size_t total_bytes = (size_t)((p.exact_bits + 7) / 8);
         if (total_bytes > cap) return fail(HGI_EINVAL, "output buffer too small: %zu bytes needed", total_bytes);
         for (size_t f = 0; f < batch; ++f) {
@@ -928,7 +899,7 @@ hgi_status deflate_frames(hgi_ctx *c, const uint8_t *d_grids, uint32_t w, uint32
         return HGI_OK;
     }
     HGI_TRY(ws_ensure(c, g.need));
-    HGI_TRY(pin_ensure(c, 2 * g.group * kHistBytes + batch * 8));
+    HGI_TRY(pin_ensure(c, 2 * g.group * kHistBytes + align_up(batch * 8, 256) + 2 * g.group * kPlanBytes));
     if (piped) HGI_TRY(pipe_ensure(c));
     c->ws_used = 0;
     uint8_t *d_hist[2], *d_outs[2];
@@ -945,10 +916,15 @@ hgi_status deflate_frames(hgi_ctx *c, const uint8_t *d_grids, uint32_t w, uint32
     uint64_t *h_totals = reinterpret_cast<uint64_t *>(c->pin + 2 * g.group * kHistBytes);
     const uint32_t dist_code = 0u | (1u << 24);      // distance symbol 0 (= distance 1): the one-bit code "0"
     std::vector<FramePlan> plans(g.group);
-    std::vector<DeflatePlan> blocks(g.group);
+    // The plan blocks go up from pinned memory, two sets: the copy is then truly asynchronous (the host plans group gi + 1
+    // while the device still packs group gi), and a set is rewritten only after ev_hist of two groups later -- which the
+    // stream reaches behind this set's upload -- has been waited for.
+    DeflatePlan *h_plans[2];
+    h_plans[0] = reinterpret_cast<DeflatePlan *>(c->pin + 2 * g.group * kHistBytes + align_up(batch * 8, 256));
+    h_plans[1] = h_plans[0] + g.group;
     std::vector<uint64_t> promised(batch), fixed_bits(batch);      // per frame: the stream's bits, and those that are not tokens
     hipStream_t down = piped ? c->pipe[1] : c->stream;
-    hipEvent_t ev_hist[2] = {c->ev0, c->ev1};
+    hipEvent_t *ev_hist = c->ev_hist;
     auto first_of = [&](size_t gi) { return gi * g.group; };
     auto count_of = [&](size_t gi) { return batch - first_of(gi) < g.group ? batch - first_of(gi) : g.group; };
     auto queue_hist = [&](size_t gi) -> hipError_t {
@@ -992,8 +968,8 @@ hgi_status deflate_frames(hgi_ctx *c, const uint8_t *d_grids, uint32_t w, uint32
             std::vector<int> status(cnt, 0);
             auto work = [&](size_t t, size_t nt) {
                 for (size_t f = t; f < cnt; f += nt)
-                    status[f] = plan_frame(reinterpret_cast<uint64_t (*)[kDeflateSymbols]>(h_hist[set] + f * (kHistBytes / 8)), true, prefix, suffix,
-                                           plans[f]) == HGI_OK ? 0 : 1;
+                    status[f] = huff::plan_frame(reinterpret_cast<uint64_t (*)[kDeflateSymbols]>(h_hist[set] + f * (kHistBytes / 8)), true, prefix,
+                                                 suffix, plans[f]) ? 0 : 1;
             };
             size_t nt = cnt / 2;
             if (nt > 8) nt = 8;
@@ -1015,14 +991,14 @@ hgi_status deflate_frames(hgi_ctx *c, const uint8_t *d_grids, uint32_t w, uint32
                 return bail(fail(HGI_EDEVICE, "entropy stage: stream of %llu bytes exceeds its scratch", (unsigned long long)(p.exact_bits / 8)));
             if ((p.exact_bits + 7) / 8 > cap)
                 return bail(fail(HGI_EINVAL, "output buffer too small: %llu bytes needed", (unsigned long long)((p.exact_bits + 7) / 8)));
-            blocks[f] = p.block;
+            h_plans[set][f] = p.block;
             promised[g0 + f] = p.exact_bits;
             fixed_bits[g0 + f] = p.block.base_bits + p.block.tail_bits;
         }
         // one upload of the plans, count / scan / pack over the whole group (its stream buffers are free once the group
         // two back has been downloaded)
         if (piped && gi >= 2) DF_TRY(hipStreamWaitEvent(c->stream, c->ev_up[set], 0));
-        DF_TRY(hipMemcpyAsync(d_plans, blocks.data(), cnt * kPlanBytes, hipMemcpyHostToDevice, c->stream));
+        DF_TRY(hipMemcpyAsync(d_plans, h_plans[set], cnt * kPlanBytes, hipMemcpyHostToDevice, c->stream));
         DF_TRY(launch_huffman_pack(d_grids + g0 * stride, n, stride, (uint32_t)cnt, d_plans, dist_code, d_cbits, d_off, d_totals + g0, d_outs[set],
                                    g.dev_cap, c->stream));
         if (piped) DF_TRY(hipEventRecord(c->ev_free[set], c->stream));
@@ -1104,15 +1080,15 @@ hgi_status probe_pair_ms(hgi_ctx *c, const uint8_t *prev, uint8_t *cand, size_t 
     const uint32_t h = (uint32_t)rows;
     constexpr int kWarm = 2, kTimed = 4;
     for (int i = 0; i < kWarm + kTimed; ++i) {
-        if (i == kWarm) HIP_TRY(hipEventRecord(c->ev0, c->stream));
+        if (i == kWarm) HIP_TRY(hipEventRecord(c->ev_probe[0], c->stream));
         c->ws_used = 0;
         // LeftTop: the same memory-access structure as Crossed, and a kernel name of its own in profiles
         // (k_dec_tiles<0, ...>), so that probe launches are never counted among the workload's k_dec_tiles<1, ...>
         HGI_TRY(decode_impl(c, prev, w, h, 4, HGI_INTERP_LEFTTOP, cand, 1, (size_t)w * h));
     }
-    HIP_TRY(hipEventRecord(c->ev1, c->stream));
-    HIP_TRY(hipEventSynchronize(c->ev1));
-    HIP_TRY(hipEventElapsedTime(ms, c->ev0, c->ev1));
+    HIP_TRY(hipEventRecord(c->ev_probe[1], c->stream));
+    HIP_TRY(hipEventSynchronize(c->ev_probe[1]));
+    HIP_TRY(hipEventElapsedTime(ms, c->ev_probe[0], c->ev_probe[1]));
     *ms /= kTimed;
     return HGI_OK;
 }
@@ -1321,3 +1297,12 @@ hgi_status hgi_timer_stop(hgi_ctx *c, float *elapsed_ms)
 }
 
 }  // extern "C"
+
+#ifdef HGI_TIMELINE
+// Experiment builds only (make VARIANT=_tl EXTRA=-DHGI_TIMELINE; tools/timeline.py): a device buffer of four u64 per
+// block into which the tile kernels log their interior blocks.  Not part of include/hgi.h, never in the shipped library.
+namespace hgi {
+uint64_t *g_timeline = nullptr;
+}
+extern "C" HGI_API void hgi_debug_timeline(void *device_buffer) { hgi::g_timeline = static_cast<uint64_t *>(device_buffer); }
+#endif

@@ -103,6 +103,9 @@ static_assert(TH != 64 || 18 * (buf_bytes(4) + rbuf_bytes(4) + 256) <= 160 * 102
 #define HGI_ABL 0   // timing experiments: 1 no coarse levels, 2 no fine arithmetic, 4 no halo cells, 8 no sub==2 level,
                     // 16 no halo-column loads, 32 no halo-row loads
 #endif
+#ifndef HGI_DEC_REVERSE_DEFAULT
+#define HGI_DEC_REVERSE_DEFAULT 0
+#endif
 #ifndef HGI_TILE_ORDER
 #define HGI_TILE_ORDER 0      // order of the interior tiles inside a frame: 0 row-major (shipped); 1..3 experiments
 #endif
@@ -272,6 +275,38 @@ __device__ __forceinline__ u32 range_first(u32 ntiles, u32 x) { return x * (ntil
 // kept from moving accesses across (it cannot see that lanes exchange data).  No s_barrier, no
 // vmcnt drain: the workgroup is one wave.
 #define LDS_ORDER() asm volatile("" ::: "memory")
+
+// Timeline builds (-DHGI_TIMELINE, never shipped): every interior block records when it started, when its staging
+// loads had landed, when its last store was acknowledged (100 MHz s_memrealtime) and where it ran (XCC, HW_ID).
+#ifdef HGI_TIMELINE
+__device__ __forceinline__ u64 tl_now(bool drain)
+{
+    u64 t;
+    if (drain)
+        asm volatile("s_waitcnt vmcnt(0)\n\ts_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+    else
+        asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+    return t;
+}
+__device__ __forceinline__ void tl_write(u64 *tl, u64 te, u64 t0, u64 t1)
+{
+    const u64 t2 = tl_now(true);
+    const u32 hw = __builtin_amdgcn_s_getreg(4 | (31 << 11)), xcc = __builtin_amdgcn_s_getreg(20 | (31 << 11));
+    if (tl && threadIdx.x == 0) {
+        u64 *r = tl + 8 * (size_t)blockIdx.x;
+        r[0] = t0; r[1] = t1; r[2] = t2; r[3] = ((u64)xcc << 32) | hw; r[4] = te;
+    }
+}
+#define HGI_TL_ENTRY() const u64 tl_te = tl_now(false)      /* first statement of the kernel: the wave is on its CU */
+#define HGI_TL_START() const u64 tl_t0 = tl_now(false)      /* prologue done (arguments, table, tile index): loads go out */
+#define HGI_TL_STAGED() const u64 tl_t1 = tl_now(true)
+#define HGI_TL_END() tl_write(g.timeline, tl_te, tl_t0, tl_t1)
+#else
+#define HGI_TL_ENTRY()
+#define HGI_TL_START()
+#define HGI_TL_STAGED()
+#define HGI_TL_END()
+#endif
 
 // The two 16-B row stores of a lane's fine-level task, then two wait states during which the eight
 // data registers stay allocated.  A VALU write to a data VGPR of a > 64-bit store in the issue slot
@@ -1161,11 +1196,15 @@ struct TileGrid {
     u32 tiles_x, tiles_y;   // all tiles of a frame
     u32 full_x, full_y;     // tiles whose body is inside the image (0 x 0 when the fast path is off)
     u32 nfast, nedge;       // totals over the batch
+    u32 reverse;            // walk the interior tile list backwards (speed only: see launch_decode_fused)
+#ifdef HGI_TIMELINE
+    u64 *timeline;          // experiment builds (tools/timeline.py): eight u64 per block -- start, staged, end, hardware id, entry
+#endif
 };
 
 __device__ __forceinline__ Tile fast_tile(u32 t, const TileGrid &g)
 {
-    t = __builtin_amdgcn_readfirstlane(t);
+    t = __builtin_amdgcn_readfirstlane(g.reverse ? g.nfast - 1u - t : t);
     const u32 tpf = g.full_x * g.full_y;
     Tile tl;
     tl.frame = t / tpf;
@@ -1370,6 +1409,7 @@ template <int INTERP, bool SEEDED, int TILE_ROWS>   // TILE_ROWS == TH: only the
 __global__ __launch_bounds__(NL) __attribute__((amdgpu_waves_per_eu(HGI_DEC_WAVES_PER_EU))) void k_dec_tiles(const u8 *__restrict__ src, u8 *__restrict__ dst, Frames f, u32 k,
                                                   Seeds sd, TileGrid g, u32 aligned)
 {
+    HGI_TL_ENTRY();
     extern __shared__ __attribute__((aligned(16))) u8 smem[];
     u8 *buf = smem - HCOL;
 #ifdef HGI_ANALYZE_K
@@ -1389,14 +1429,17 @@ __global__ __launch_bounds__(NL) __attribute__((amdgpu_waves_per_eu(HGI_DEC_WAVE
         Stage st;
         SeedRegs seeds;
         HGI_MARK("stage_issue");
+        HGI_TL_START();
         stage_issue<false>(st, cur.b, cur.tl, (int)k, nh);
         if (SEEDED) seeds = seed_issue<false>(sd, cur.tl, k);
         HGI_MARK("stage_commit");
         stage_commit<false>(buf, nullptr, st, nh);
         LDS_ORDER();
+        HGI_TL_STAGED();
         if (SEEDED) dec_seed_commit(buf, seeds, k);
         dec_tile_fast<INTERP>(buf, cur, st.o, k, W, H);
         HGI_MARK("end");
+        HGI_TL_END();
         return;
     }
     // ragged tile (body crosses the image edge), unaligned rows, or offsets beyond 32 bits: every access checked
@@ -1496,6 +1539,7 @@ template <int INTERP, bool IDENT, bool SEEDED, int TILE_ROWS>
 __global__ __launch_bounds__(NL) __attribute__((amdgpu_waves_per_eu(IDENT ? HGI_ENC_WAVES_PER_EU - 1 : HGI_ENC_WAVES_PER_EU))) void k_enc_tiles(const u8 *__restrict__ src, u8 *__restrict__ dst, Frames f, u32 k,
                                                   Lut256 lut, Seeds sd, TileGrid g, u32 aligned)
 {
+    HGI_TL_ENTRY();
     extern __shared__ __attribute__((aligned(16))) u8 smem[];
 #ifdef HGI_ANALYZE_K
     k = HGI_ANALYZE_K;
@@ -1522,14 +1566,17 @@ __global__ __launch_bounds__(NL) __attribute__((amdgpu_waves_per_eu(IDENT ? HGI_
         Stage st;
         SeedRegs seeds;
         HGI_MARK("stage_issue");
+        HGI_TL_START();
         stage_issue<false>(st, cur.b, cur.tl, (int)k, nh);
         if (SEEDED) seeds = seed_issue<true>(sd, cur.tl, k);
         HGI_MARK("stage_commit");
         stage_commit<true>(buf, rbuf, st, nh);
         LDS_ORDER();
+        HGI_TL_STAGED();
         enc_seed_commit<SEEDED>(buf, rbuf, seeds, k);
         enc_tile_fast<INTERP, IDENT>(buf, rbuf, slut, cur, st.o, k, W, H);
         HGI_MARK("end");
+        HGI_TL_END();
         return;
     }
     const Tile tl = edge_tile(role.index, g);
@@ -1603,9 +1650,13 @@ FusedGeom fused_geom(const void *a, const void *b, const Frames &f, u32 row_limi
     r.ok = all > 0 && all + 8 < (1ull << 31);
     g.nfast = (u32)nfast;
     g.nedge = (u32)(all - nfast);
+    g.reverse = 0;
     // bit 0: 16-B aligned rows and pointers (vector accesses of the byte-checked path); bit 1: check-free paths allowed
     // (32-bit buffer offsets); bit 2: read descriptors carry 3 extra records (rows not a multiple of 4 bytes)
     r.aligned = (aligned ? 1u : 0u) | (fast ? 2u : 0u) | (fast && !dword_rows ? 4u : 0u);
+#ifdef HGI_TIMELINE
+    g.timeline = g_timeline;
+#endif
     return r;
 }
 
@@ -1617,6 +1668,15 @@ hipError_t HGI_TILED(launch_decode_fused)(const uint8_t *grid, uint8_t *img, con
 {
     FusedGeom r = fused_geom(grid, img, f, row_limit);
     if (!r.ok || k < 1 || k > (u32)MAXK) return hipErrorInvalidValue;
+    // The decoder walks the tile list BACKWARDS: in an encode -> decode chain the grid bytes the encoder wrote last are
+    // the ones still in the 256 MiB Infinity Cache, so reading them first takes them from there instead of evicting them
+    // unread (measured on 16384^2 and on the 64 x 4096^2 shard: tools/ab_reverse.py).  Order never changes
+    // the bytes.  HGI_DEC_REVERSE=0|1 in the environment forces it (experiments).
+    static const int dec_reverse = [] {
+        const char *e = getenv("HGI_DEC_REVERSE");
+        return e ? atoi(e) : HGI_DEC_REVERSE_DEFAULT;
+    }();
+    r.g.reverse = dec_reverse ? 1u : 0u;
     const TileGrid &g = r.g;
     if (seeds && k < (uint32_t)kSeededMinLevels) return hipErrorInvalidValue;      // one lane per lattice point (seed_issue)
     Seeds sd = seeds ? *seeds : Seeds{nullptr, nullptr, 0, 0, 0};

@@ -4,6 +4,8 @@
 #include <stddef.h>
 #include <stdint.h>
 
+#include "hgi_huffman_host.h"
+
 namespace hgi {
 
 constexpr int kInterpLeftTop = 0;
@@ -38,6 +40,10 @@ struct Seeds {
     uint32_t sw, sh;
     uint64_t stride;
 };
+
+#ifdef HGI_TIMELINE
+extern uint64_t *g_timeline;   // experiment builds only (tools/timeline.py): where the tile kernels log their blocks
+#endif
 
 // ---- level-wise path: one launch per level, straight global-memory stencil -----------------
 hipError_t launch_seed(const uint8_t *src, uint8_t *dst, const Frames &f, uint32_t levels,
@@ -82,29 +88,7 @@ hipError_t launch_diff_stats(const uint8_t *a, const uint8_t *b, const Frames &f
                              unsigned long long *out, hipStream_t s);
 
 // ---- entropy stage (hgi_entropy.hip): raw DEFLATE of a grid as one dynamic-Huffman block of literals + run matches ----
-constexpr int kDeflateSymbols = 286;      // literals 0..255, end of block 256, match lengths 257..285 (RFC 1951 3.2.5)
-constexpr int kMatchThresholds = 4;       // run pieces become matches from this length on: candidates, the host picks
-constexpr uint32_t kMatchThresholdHost[kMatchThresholds] = {3, 4, 6, 10};
-// host: code for those symbols + the block header (two distance codes of one bit; code 0 = distance 1); returns the
-// header's bits (0: no room)
-size_t huffman_plan(const uint64_t hist[kDeflateSymbols], uint8_t lens[kDeflateSymbols], uint16_t codes[kDeflateSymbols],
-                    uint8_t *header, size_t header_cap);
-void deflate_length_symbol(uint32_t length, uint32_t *symbol, uint32_t *extra_bits, uint32_t *extra);
-uint64_t huffman_payload_bits(const uint64_t hist[kDeflateSymbols]);      // token bits under the best code, header excluded
-// What the host hands each frame's passes 2 and 3 (one upload for a whole group of frames): the code, the chosen
-// threshold, the bytes in front of the grid's tokens and the bits behind them.
-constexpr size_t kPlanBytes = 2048;
-struct DeflatePlan {
-    uint32_t table[kDeflateSymbols];      // reversed code | length << 24
-    uint32_t min_match;
-    uint32_t front_bytes;                 // block header + the eight literals of the u64 length: ceil(base_bits / 8)
-    uint64_t base_bits;                   // where the grid's tokens start
-    uint32_t tail_bits;                   // the eight literals of the u64 width + end of block: <= 9 x 15 bits
-    uint32_t tail[5];
-    uint32_t reserved[6];
-    uint8_t front[kPlanBytes - 1208];     // zero padded
-};
-static_assert(sizeof(DeflatePlan) == kPlanBytes, "plan block layout");
+// (symbol counts, the plan block and the host-side code construction: hgi_huffman_host.h, plain C++)
 // device, pass 1, for `frames` grids `stride` bytes apart: d_hist[frame][kMatchThresholds + 1][kDeflateSymbols] = how often
 // the tokens of the frame's n bytes use each symbol (runs -> distance-1 matches, cut at 1 KiB chunk boundaries): slot
 // v < kMatchThresholds counts the tokens that depend on the candidate threshold v, slot kMatchThresholds those that do

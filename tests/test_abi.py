@@ -26,6 +26,17 @@ def test_library_exports_every_declared_symbol():
     assert sorted(s[0] for s in _ffi.SYMBOLS) == names     # the binding covers the whole header
 
 
+def test_library_exports_nothing_but_the_header():
+    """Both directions: what `nm -D --defined-only` lists IS the header's symbol set -- no internal helper (put_bits,
+    plan_frame ... once leaked as unmangled globals), no mangled hgi::launch_* and no template instantiation may be
+    visible to a program that links this library beside others (the crate it replaces exports six names,
+    src/lib.rs:16-23).  Built with -fvisibility=hidden and the version script csrc/hgi.map."""
+    import subprocess
+    out = subprocess.check_output(["nm", "-D", "--defined-only", _ffi.LIB_PATH], text=True)
+    exported = sorted(line.split()[-1] for line in out.splitlines() if line.strip())
+    assert exported == header_symbols(), sorted(set(exported) ^ set(header_symbols()))
+
+
 def test_version_and_error_strings():
     assert b"gfx950" in _ffi.lib().hgi_version()
     assert isinstance(_ffi.lib().hgi_last_error(), bytes)
