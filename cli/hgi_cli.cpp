@@ -4,7 +4,7 @@
 //   hgi encode -i <input> -o <output> [-l <level>=4] [-q lossless|low|medium|high = medium]
 //   hgi decode -i <input.hgi> -o <output>
 //   hgi test <input> [-s <suffix>=""] [-l <level>=4] [-q <quantizator>=medium]
-//   (encode / test also take --entropy zlib|device, default zlib: `device` has the GPU write the archive's DEFLATE stream
+//   (encode / test also take --entropy zlib|device|auto, default zlib: `device` has the GPU write the archive's DEFLATE stream
 //    as Huffman-coded literals -- same container, readable by the same readers; no counterpart in the reference)
 //
 // `hgi test` prints the reference's four report lines (src/main.rs:108-111, integer MSE division at
@@ -157,12 +157,14 @@ struct Opts {
     std::string cmd, input, output, suffix;
     size_t level = 4;                                            // src/options.rs:54
     QuantizationLevel quant = QuantizationLevel::Medium;         // src/options.rs:62
-    bool device_entropy = false;   // --entropy device: the DEFLATE stream from the GPU's entropy stage (no reference flag)
+    int entropy = 0;   // --entropy zlib (0, the reference's writer) | device (1: the GPU's entropy stage) | auto (2: device unless an LZ77 probe says zlib wins); no reference flag
 };
 
 std::vector<uint8_t> write_archive(const Opts &o, const Metadata &metadata, const Grid &grid)
 {
-    return o.device_entropy ? hgi::serialize_device(metadata, grid, hgi::Context::global().get()) : serialize(metadata, grid);
+    if (o.entropy == 1) return hgi::serialize_device(metadata, grid, hgi::Context::global().get());
+    if (o.entropy == 2) return hgi::serialize_auto(metadata, grid, hgi::Context::global().get());
+    return serialize(metadata, grid);
 }
 
 Opts parse(int argc, char **argv)
@@ -183,8 +185,8 @@ Opts parse(int argc, char **argv)
         else if (a == "-s" || a == "--suffix") o.suffix = next();
         else if (a == "--entropy") {
             const std::string v = next();
-            if (v != "device" && v != "zlib") throw Failure("'" + v + "' isn't a valid value for '--entropy' [values: zlib, device]");
-            o.device_entropy = v == "device";
+            if (v != "device" && v != "zlib" && v != "auto") throw Failure("'" + v + "' isn't a valid value for '--entropy' [values: zlib, device, auto]");
+            o.entropy = v == "device" ? 1 : v == "auto" ? 2 : 0;
         }
         else if (o.cmd == "test" && o.input.empty() && a[0] != '-') o.input = a;   // positional <input>
         else throw Failure("unexpected argument '" + a + "'");

@@ -160,7 +160,7 @@ HGI_API hgi_status hgi_diff_stats_dev(hgi_ctx *ctx, const void *d_before, const 
 /* reads the result (the reference's flate2 DeflateDecoder included).  Residual grids are      */
 /* noise around zero, in which LZ77 finds runs and nothing else: the stream is within a few %  */
 /* of DEFLATE at the best level on smooth images and smaller than it on busy ones (LENA /      */
-/* Medium: 14.5 against 16.0 kB) -- and written two to four orders of magnitude sooner.        */
+/* Medium: 14.0 against 16.0 kB) -- and written two to four orders of magnitude sooner.        */
 /* `out` is host memory; *bytes receives the stream length; HGI_EINVAL if cap is too small     */
 /* (w*h + w*h/8 + 1024 always suffices).  Synchronous on the ctx stream.                        */
 HGI_API hgi_status hgi_deflate_grid_dev(hgi_ctx *ctx, const void *d_grid, uint32_t width, uint32_t height,
@@ -174,6 +174,14 @@ HGI_API hgi_status hgi_deflate_grid_dev(hgi_ctx *ctx, const void *d_grid, uint32
 /* `out` is written from a second stream internally; the call returns when everything is done. */
 HGI_API hgi_status hgi_deflate_grids_dev(hgi_ctx *ctx, const void *d_grids, uint32_t width, uint32_t height, size_t batch,
                                  size_t frame_stride, uint8_t *out, size_t out_stride, size_t *sizes);
+/* The same batch with the streams PACKED into one host buffer of `cap` bytes: stream f occupies */
+/* out[offsets[f] .. offsets[f] + sizes[f]), offsets ascending and multiples of 64.  The sizes are */
+/* known from the histograms before anything is packed, so a group's streams lie back to back on  */
+/* the device and come down with ONE copy per group instead of one per frame (each copy costs a   */
+/* fixed ~12 us on top of its bytes).  HGI_EINVAL when `cap` does not hold them all                */
+/* (batch * (w*h + w*h/8 + 1088) always suffices).                                                  */
+HGI_API hgi_status hgi_deflate_grids_packed_dev(hgi_ctx *ctx, const void *d_grids, uint32_t width, uint32_t height, size_t batch,
+                                                size_t frame_stride, uint8_t *out, size_t cap, size_t *offsets, size_t *sizes);
 /* The same with the grid in host memory (what pairs with hgi_encode_u8).                      */
 HGI_API hgi_status hgi_deflate_grid(hgi_ctx *ctx, const uint8_t *grid, uint32_t width, uint32_t height,
                             uint8_t *out, size_t cap, size_t *bytes);

@@ -13,6 +13,8 @@
 #pragma once
 #include <zlib.h>
 
+#include <algorithm>
+
 #include <cstdint>
 #include <stdexcept>
 #include <string>
@@ -75,16 +77,29 @@ inline void serialize_into(std::vector<uint8_t> &out, const Metadata &m, const G
     put_le(body, grid.width, 8);
     z_stream z{};
     if (deflateInit2(&z, 9, Z_DEFLATED, -15, 9, Z_DEFAULT_STRATEGY) != Z_OK) throw ArchiveError("deflateInit2 failed");
-    const size_t head = out.size(), bound = deflateBound(&z, (uLong)body.size());
-    out.resize(head + bound);
-    z.next_in = body.data();
-    z.avail_in = (uInt)body.size();
-    z.next_out = out.data() + head;
-    z.avail_out = (uInt)bound;
-    const int rc = deflate(&z, Z_FINISH);
+    // zlib counts in 32-bit `uInt`s: feed and drain in pieces of at most 1 GiB so that grids of 4 GiB and more stream through
+    constexpr size_t kPiece = size_t(1) << 30;
+    const size_t head = out.size();
+    size_t in_at = 0, out_at = head;
+    int rc = Z_OK;
+    while (rc != Z_STREAM_END) {
+        if (z.avail_in == 0 && in_at < body.size()) {
+            const size_t take = std::min(kPiece, body.size() - in_at);
+            z.next_in = body.data() + in_at;
+            z.avail_in = (uInt)take;
+            in_at += take;
+        }
+        if (out.size() - out_at < 65536) out.resize(out.size() + std::max<size_t>(65536, body.size() / 8));
+        const size_t room = std::min(kPiece, out.size() - out_at);
+        z.next_out = out.data() + out_at;
+        z.avail_out = (uInt)room;
+        rc = deflate(&z, in_at == body.size() ? Z_FINISH : Z_NO_FLUSH);
+        out_at += room - z.avail_out;
+        if (rc != Z_OK && rc != Z_STREAM_END && rc != Z_BUF_ERROR) break;
+    }
     deflateEnd(&z);
     if (rc != Z_STREAM_END) throw ArchiveError("deflate failed");
-    out.resize(head + z.total_out);
+    out.resize(out_at);
 }
 
 // The same container with the entropy stage on the device (hgi_deflate_grid_dev, include/hgi.h): the grid stays where
@@ -105,6 +120,38 @@ inline void serialize_device_into(std::vector<uint8_t> &out, const Metadata &m, 
     if (hgi_deflate_grid_dev(ctx, d_grid, m.width, m.height, out.data() + head, cap, &bytes) != HGI_OK)
         throw ArchiveError(std::string("device entropy stage: ") + hgi_last_error());
     out.resize(head + bytes);
+}
+
+// Selection rule between the two writers (`--entropy auto`).  The device stream codes literals and runs only; where a
+// grid repeats itself at a distance (synthetic, periodic images: the criterion harness's `(x*y) as u8` frame is 19x
+// smaller under LZ77) zlib must write the archive.  The rule costs one fast probe: the device stream is produced first
+// (fractions of a millisecond; its size is exact), then up to 1 MiB from the middle of the grid goes through zlib at
+// level 1 -- which finds long-distance repeats as surely as level 9, at memcpy-like speed on such data -- and if that
+// ratio, applied to the whole grid, undercuts the device stream by more than a quarter, the grid is compressed the
+// reference's way (level 9).  Returns true when the device stream was kept.  `grid` is the host copy of d_grid.
+namespace archive_detail {
+// true: an LZ77 probe of the grid predicts a stream more than a quarter smaller than the device's `device_stream_bytes`
+inline bool lz77_would_win(const Grid &grid, size_t device_stream_bytes)
+{
+    const size_t n = grid.buffer.size(), probe = std::min<size_t>(n, size_t(1) << 20), at = (n - probe) / 2;
+    if (probe < 4096) return false;
+    uLongf got = compressBound((uLong)probe);
+    std::vector<uint8_t> tmp(got);
+    if (compress2(tmp.data(), &got, grid.buffer.data() + at, (uLong)probe, 1) != Z_OK) return false;
+    return double(got) / double(probe) * double(n) <= 0.75 * double(device_stream_bytes);
+}
+}  // namespace archive_detail
+
+inline bool serialize_auto_into(std::vector<uint8_t> &out, const Metadata &m, const Grid &grid, hgi_ctx *ctx, const void *d_grid)
+{
+    std::vector<uint8_t> dev;
+    serialize_device_into(dev, m, ctx, d_grid);
+    const bool keep = !archive_detail::lz77_would_win(grid, dev.size() - 28);
+    if (keep)
+        out.insert(out.end(), dev.begin(), dev.end());
+    else
+        serialize_into(out, m, grid);
+    return keep;
 }
 
 // ... and with the grid in host memory (hgi_deflate_grid): what the CLI's `--entropy device` writes
@@ -128,6 +175,18 @@ inline std::vector<uint8_t> serialize_device(const Metadata &m, const Grid &grid
     return out;
 }
 
+// `--entropy auto` with the grid in host memory (the CLI): the rule of serialize_auto_into(); *used_device says which
+inline std::vector<uint8_t> serialize_auto(const Metadata &m, const Grid &grid, hgi_ctx *ctx, bool *used_device = nullptr)
+{
+    std::vector<uint8_t> dev = serialize_device(m, grid, ctx);
+    const bool keep = !archive_detail::lz77_would_win(grid, dev.size() - 28);
+    if (used_device) *used_device = keep;
+    if (keep) return dev;
+    std::vector<uint8_t> out;
+    serialize_into(out, m, grid);
+    return out;
+}
+
 inline std::vector<uint8_t> serialize(const Metadata &m, const Grid &grid)
 {
     std::vector<uint8_t> out;
@@ -145,20 +204,44 @@ inline void deserialize(const std::vector<uint8_t> &b, Metadata &m, Grid &grid)
     m.width = (uint32_t)get_le(b, 12, 4);
     m.height = (uint32_t)get_le(b, 16, 4);
     m.scale_level = get_le(b, 20, 8);
-    std::vector<uint8_t> body(size_t(m.width) * m.height + 16);
+    if (b.size() < 28) throw ArchiveError("truncated archive");
+    // The header is untrusted: never allocate width * height up front.  DEFLATE expands at most 1032 : 1, so the stream
+    // that follows bounds what the body can be; the buffer grows as inflate produces output, in pieces of at most 1 GiB
+    // per call (zlib counts in 32-bit uInts).
+    const uint64_t want = uint64_t(m.width) * m.height + 16;
+    const uint64_t most = uint64_t(b.size() - 28) * 1032 + 64;
+    if (want > most) throw ArchiveError("grid size in the metadata exceeds what the stream can hold");
+    constexpr size_t kPiece = size_t(1) << 30;
+    std::vector<uint8_t> body;
     z_stream z{};
     if (inflateInit2(&z, -15) != Z_OK) throw ArchiveError("inflateInit2 failed");
-    z.next_in = const_cast<uint8_t *>(b.data()) + 28;
-    z.avail_in = (uInt)(b.size() - 28);
-    z.next_out = body.data();
-    z.avail_out = (uInt)body.size();
-    const int rc = inflate(&z, Z_FINISH);
+    size_t in_at = 28, out_at = 0;
+    int rc = Z_OK;
+    while (rc != Z_STREAM_END) {
+        if (z.avail_in == 0 && in_at < b.size()) {
+            const size_t take = std::min(kPiece, b.size() - in_at);
+            z.next_in = const_cast<uint8_t *>(b.data()) + in_at;
+            z.avail_in = (uInt)take;
+            in_at += take;
+        }
+        if (out_at == body.size()) {
+            if (body.size() >= want) break;                      // more output than the metadata announces
+            body.resize((size_t)std::min<uint64_t>(want, std::max<uint64_t>(uint64_t(body.size()) * 2, 1 << 16)));
+        }
+        const size_t room = std::min(kPiece, body.size() - out_at);
+        z.next_out = body.data() + out_at;
+        z.avail_out = (uInt)room;
+        rc = inflate(&z, Z_NO_FLUSH);
+        out_at += room - z.avail_out;
+        if (rc != Z_OK && rc != Z_STREAM_END) break;             // Z_BUF_ERROR: no input left and the stream has not ended
+    }
     inflateEnd(&z);
-    if (rc != Z_STREAM_END || z.total_out != body.size()) throw ArchiveError("corrupt grid stream");
+    if (rc != Z_STREAM_END || out_at != want) throw ArchiveError("corrupt grid stream");
     const uint64_t n = get_le(body, 0, 8);
-    if (n != size_t(m.width) * m.height) throw ArchiveError("grid size does not match the metadata");
+    if (n != uint64_t(m.width) * m.height) throw ArchiveError("grid size does not match the metadata");
     grid.buffer.assign(body.begin() + 8, body.begin() + 8 + n);
     grid.width = get_le(body, 8 + n, 8);
+    if (grid.width != m.width) throw ArchiveError("grid width does not match the metadata");
 }
 
 }  // namespace hgi

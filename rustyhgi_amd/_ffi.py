@@ -41,6 +41,7 @@ SYMBOLS = [
     ("hgi_diff_stats_dev", _int, [_vp, _vp, _vp, _u32, _u32, _sz, _sz, _vp]),
     ("hgi_deflate_grid_dev", _int, [_vp, _vp, _u32, _u32, _vp, _sz, ctypes.POINTER(_sz)]),
     ("hgi_deflate_grids_dev", _int, [_vp, _vp, _u32, _u32, _sz, _sz, _vp, _sz, _vp]),
+    ("hgi_deflate_grids_packed_dev", _int, [_vp, _vp, _u32, _u32, _sz, _sz, _vp, _sz, _vp, _vp]),
     ("hgi_deflate_grid", _int, [_vp, _vp, _u32, _u32, _vp, _sz, ctypes.POINTER(_sz)]),
     ("hgi_huffman_plan", _int, [_vp, _vp, _vp, _vp, _sz, ctypes.POINTER(_sz)]),
     ("hgi_planes_alloc", _int, [_vp, _sz, _u32, ctypes.POINTER(_vp), ctypes.POINTER(_int)]),

@@ -866,9 +866,14 @@ hgi_status pin_ensure(hgi_ctx *c, size_t bytes)
 //     device, pipe[1]   :                            | streams(0) down | streams(1) down ...
 // hist = token histograms (one launch per group), plan = codes + headers, pack = count / scan / pack (three launches per
 // group).  Stream sizes are known from the histograms, so the downloads are queued without waiting for the pack.
+// offsets == nullptr: stream f goes to out + f * out_stride (cap = room per stream).  offsets != nullptr (packed): the
+// streams of a group lie back to back on the device (64-byte aligned starts) and come down with ONE copy per group into
+// out + offsets[f]; cap = room in `out` altogether.
 hgi_status deflate_frames(hgi_ctx *c, const uint8_t *d_grids, uint32_t w, uint32_t h, size_t batch, size_t stride, uint8_t *out,
-                          size_t out_stride, size_t cap, size_t *sizes)
+                          size_t out_stride, size_t cap, size_t *sizes, size_t *offsets = nullptr)
 {
+    const bool packed = offsets != nullptr;
+    size_t packed_at = 0;                      // packed: where the next group starts in `out`
     const DeflateGeom g = deflate_geom((uint64_t)w * h, batch);
     const uint64_t n = g.n;
     // the bincode image of Grid { buffer: Vec<u8>, width: usize } (src/grid.rs:2-5): u64 length, the bytes, u64 width
@@ -885,10 +890,12 @@ hgi_status deflate_frames(hgi_ctx *c, const uint8_t *d_grids, uint32_t w, uint32
         FramePlan p;
         if (!huff::plan_frame(reinterpret_cast<uint64_t (*)[kDeflateSymbols]>(hist0.data()), false, prefix, suffix, p))
             return fail(HGI_EDEVICE, "block header does not fit");
-        const size_t total_bytes = (size_t)((p.exact_bits + 7) / 8);
-        if (total_bytes > cap) return fail(HGI_EINVAL, "output buffer too small: %zu bytes needed", total_bytes);
+        const size_t total_bytes = (size_t)((p.exact_bits + 7) / 8), slot = align_up(total_bytes, 64);
+        if (packed ? slot * batch > cap : total_bytes > cap)
+            return fail(HGI_EINVAL, "output buffer too small: %zu bytes needed", packed ? slot * batch : total_bytes);
         for (size_t f = 0; f < batch; ++f) {
-            uint8_t *dst = out + f * out_stride;
+            uint8_t *dst = out + (packed ? f * slot : f * out_stride);
+            if (packed) offsets[f] = f * slot;
             std::memset(dst, 0, total_bytes);
             std::memcpy(dst, p.block.front, p.block.front_bytes);
             uint64_t at = p.block.base_bits;
@@ -923,6 +930,7 @@ hgi_status deflate_frames(hgi_ctx *c, const uint8_t *d_grids, uint32_t w, uint32
     h_plans[0] = reinterpret_cast<DeflatePlan *>(c->pin + 2 * g.group * kHistBytes + align_up(batch * 8, 256));
     h_plans[1] = h_plans[0] + g.group;
     std::vector<uint64_t> promised(batch), fixed_bits(batch);      // per frame: the stream's bits, and those that are not tokens
+    std::vector<size_t> group_at(ngroups, 0), group_bytes(ngroups, 0);      // packed: a group's place in `out` and its length
     hipStream_t down = piped ? c->pipe[1] : c->stream;
     hipEvent_t *ev_hist = c->ev_hist;
     auto first_of = [&](size_t gi) { return gi * g.group; };
@@ -939,9 +947,14 @@ hgi_status deflate_frames(hgi_ctx *c, const uint8_t *d_grids, uint32_t w, uint32
         const int set = (int)(gi & 1);
         hipError_t e = hipSuccess;
         if (piped) e = hipStreamWaitEvent(down, c->ev_free[set], 0);
-        for (size_t f = 0; f < count_of(gi) && e == hipSuccess; ++f) {
-            const size_t frame = first_of(gi) + f;
-            e = hipMemcpyAsync(out + frame * out_stride, d_outs[set] + f * g.dev_cap, (size_t)((promised[frame] + 7) / 8), hipMemcpyDeviceToHost, down);
+        if (packed) {      // the group's streams are contiguous on the device: one copy
+            if (e == hipSuccess && group_bytes[gi])
+                e = hipMemcpyAsync(out + group_at[gi], d_outs[set], group_bytes[gi], hipMemcpyDeviceToHost, down);
+        } else {
+            for (size_t f = 0; f < count_of(gi) && e == hipSuccess; ++f) {
+                const size_t frame = first_of(gi) + f;
+                e = hipMemcpyAsync(out + frame * out_stride, d_outs[set] + f * g.dev_cap, (size_t)((promised[frame] + 7) / 8), hipMemcpyDeviceToHost, down);
+            }
         }
         if (piped && e == hipSuccess) e = hipEventRecord(c->ev_up[set], down);
         return e;
@@ -985,22 +998,37 @@ hgi_status deflate_frames(hgi_ctx *c, const uint8_t *d_grids, uint32_t w, uint32
                 if (status[f]) return bail(fail(HGI_EDEVICE, "block header does not fit"));
         }
         // the histograms say exactly how long each stream will be: never start packing into a buffer it would overrun
+        size_t dev_at = 0;                     // packed: running offset inside the group's device buffer
         for (size_t f = 0; f < cnt; ++f) {
             const FramePlan &p = plans[f];
+            const size_t bytes = (size_t)((p.exact_bits + 7) / 8);
             if (p.exact_bits / 8 + 64 > g.dev_cap)
                 return bail(fail(HGI_EDEVICE, "entropy stage: stream of %llu bytes exceeds its scratch", (unsigned long long)(p.exact_bits / 8)));
-            if ((p.exact_bits + 7) / 8 > cap)
-                return bail(fail(HGI_EINVAL, "output buffer too small: %llu bytes needed", (unsigned long long)((p.exact_bits + 7) / 8)));
+            if (!packed && bytes > cap) return bail(fail(HGI_EINVAL, "output buffer too small: %zu bytes needed", bytes));
             h_plans[set][f] = p.block;
+            const uint64_t off = packed ? dev_at : f * g.dev_cap;
+            h_plans[set][f].out_off[0] = (uint32_t)off;
+            h_plans[set][f].out_off[1] = (uint32_t)(off >> 32);
+            if (packed) {
+                offsets[g0 + f] = packed_at + dev_at;
+                dev_at += align_up(bytes, 64);
+            }
             promised[g0 + f] = p.exact_bits;
             fixed_bits[g0 + f] = p.block.base_bits + p.block.tail_bits;
+        }
+        if (packed) {
+            if (packed_at + dev_at > cap)
+                return bail(fail(HGI_EINVAL, "output buffer too small: %zu bytes needed for the first %zu frames", packed_at + dev_at, g0 + cnt));
+            group_at[gi] = packed_at;
+            group_bytes[gi] = dev_at;
+            packed_at += dev_at;
         }
         // one upload of the plans, count / scan / pack over the whole group (its stream buffers are free once the group
         // two back has been downloaded)
         if (piped && gi >= 2) DF_TRY(hipStreamWaitEvent(c->stream, c->ev_up[set], 0));
         DF_TRY(hipMemcpyAsync(d_plans, h_plans[set], cnt * kPlanBytes, hipMemcpyHostToDevice, c->stream));
         DF_TRY(launch_huffman_pack(d_grids + g0 * stride, n, stride, (uint32_t)cnt, d_plans, dist_code, d_cbits, d_off, d_totals + g0, d_outs[set],
-                                   g.dev_cap, c->stream));
+                                   c->stream));
         if (piped) DF_TRY(hipEventRecord(c->ev_free[set], c->stream));
         // downloads lag one group behind, so that the device has hist(gi + 1) and pack(gi) queued while they run
         if (piped) {
@@ -1058,6 +1086,18 @@ hgi_status hgi_deflate_grids_dev(hgi_ctx *c, const void *d_grids, uint32_t w, ui
     if (batch > 1 && frame_stride < n) return fail(HGI_EINVAL, "frame_stride %zu < width*height", frame_stride);
     HIP_TRY(hipSetDevice(c->device));
     return deflate_frames(c, static_cast<const uint8_t *>(d_grids), w, h, batch, frame_stride, out, out_stride, out_stride, sizes);
+}
+
+hgi_status hgi_deflate_grids_packed_dev(hgi_ctx *c, const void *d_grids, uint32_t w, uint32_t h, size_t batch, size_t frame_stride,
+                                        uint8_t *out, size_t cap, size_t *offsets, size_t *sizes)
+{
+    if (!c || (batch && (!out || !sizes || !offsets))) return fail(HGI_EINVAL, "NULL argument");
+    if (batch == 0) return HGI_OK;
+    const size_t n = (size_t)w * h;
+    if (n && !d_grids) return fail(HGI_EINVAL, "NULL buffer");
+    if (batch > 1 && frame_stride < n) return fail(HGI_EINVAL, "frame_stride %zu < width*height", frame_stride);
+    HIP_TRY(hipSetDevice(c->device));
+    return deflate_frames(c, static_cast<const uint8_t *>(d_grids), w, h, batch, frame_stride, out, 0, cap, sizes, offsets);
 }
 
 // ---- plane placement ------------------------------------------------------------------------------------------

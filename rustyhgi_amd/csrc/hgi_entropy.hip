@@ -6,7 +6,7 @@
 // (profiles/r02_bench_cpp.txt), seconds for a 4096 x 4096 one.  Residual grids are noise around zero: what LZ77 finds in
 // them is runs (of zeros, in smooth regions) and nothing else -- zlib's run-length-only strategy (Z_RLE) is within 1 % of
 // its level 9 on them, and where there are no runs the plain Huffman code alone is SMALLER than level 9 (LENA / Medium:
-// 14.5 against 16.0 kB).  Both parallelise:
+// 14.0 against 16.0 kB with run matches, 14.5 with literals alone).  Both parallelise:
 //   tokens     a byte equal to its predecessor continues a run; a run's bytes after its first are covered by matches of
 //              distance 1 and length 3..258 (leftovers of 1-2 bytes stay literals).  Runs are cut at 1 KiB chunk
 //              boundaries, so every token is decided inside one wave (cost: one extra literal per KiB of run).
@@ -56,6 +56,10 @@ __device__ constexpr u32 kMatchThreshold[kMatchThresholds] = {3, 4, 6, 10};     
 // a wave's LDS instructions execute in order: lanes exchange data through LDS without a barrier, the compiler only has
 // to keep the accesses where they are
 #define WAVE_LDS_ORDER() asm volatile("" ::: "memory")
+
+// where a frame's stream starts in the output buffer of the launch (the host lays the streams out: one slot per frame,
+// or back to back for the packed entry point)
+__device__ __forceinline__ u64 plan_out_off(const DeflatePlan &p) { return ((u64)p.out_off[1] << 32) | p.out_off[0]; }
 
 // Wave-wide scans on the DPP lanes of the VALU (no LDS crossbar round trips): four row_shr / row_shl steps scan each row
 // of sixteen lanes, then the rows are joined -- forward by the row broadcasts, backward through three scalar reads.
@@ -378,13 +382,12 @@ __global__ __launch_bounds__(kPackThreads) void k_token_count(const u8 *__restri
 // words two writers share in pass 3 (they OR into them); every other word has one owner who stores it whole, so the
 // stream needs no clearing beyond this.
 __global__ __launch_bounds__(1024) void k_huff_scan(const u32 *__restrict__ chunk_bits, u64 *__restrict__ chunk_off, u32 nchunks,
-                                                    u64 *__restrict__ totals, const DeflatePlan *__restrict__ plans, u8 *__restrict__ outs,
-                                                    u64 out_stride)
+                                                    u64 *__restrict__ totals, const DeflatePlan *__restrict__ plans, u8 *__restrict__ outs)
 {
     __shared__ u64 wtot[16];
     chunk_bits += (u64)blockIdx.x * nchunks;
     chunk_off += (u64)blockIdx.x * nchunks;
-    u32 *out = reinterpret_cast<u32 *>(outs + (u64)blockIdx.x * out_stride);
+    u32 *out = reinterpret_cast<u32 *>(outs + plan_out_off(plans[blockIdx.x]));
     const u64 base = plans[blockIdx.x].base_bits;
     const u32 lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     u64 carry = 0;                      // every thread keeps its own copy of the running total
@@ -434,7 +437,7 @@ __global__ __launch_bounds__(1024) void k_huff_scan(const u32 *__restrict__ chun
 // device complete.
 __global__ __launch_bounds__(kPackThreads) void k_token_pack(const u8 *__restrict__ src, u64 n, u64 stride, u32 nchunks,
                                                              const DeflatePlan *__restrict__ plans, u32 dist, const u64 *__restrict__ chunk_off,
-                                                             u8 *__restrict__ outs, u64 out_stride)
+                                                             u8 *__restrict__ outs)
 {
     constexpr int kWords = (kChunk * 15 + 31) / 32 + 4;      // every byte a 15-bit literal (a match spends 21 bits on >= 3 bytes)
     constexpr int kMaxStarts = 9;                            // pieces that can start inside sixteen bytes
@@ -449,7 +452,7 @@ __global__ __launch_bounds__(kPackThreads) void k_token_pack(const u8 *__restric
     __syncthreads();
     src += (u64)blockIdx.y * stride;
     chunk_off += (u64)blockIdx.y * nchunks;
-    u32 *out = reinterpret_cast<u32 *>(outs + (u64)blockIdx.y * out_stride);
+    u32 *out = reinterpret_cast<u32 *>(outs + plan_out_off(plan));
     const u32 lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     u32 *img = imgs[wave];
     u32(*mtok)[64] = mtoks[wave];
@@ -605,8 +608,7 @@ hipError_t launch_token_histogram(const uint8_t *src, uint64_t n, uint64_t strid
 }
 
 hipError_t launch_huffman_pack(const uint8_t *src, uint64_t n, uint64_t stride, uint32_t frames, const void *d_plans, uint32_t dist_code,
-                               uint32_t *d_chunk_bits, uint64_t *d_chunk_off, uint64_t *d_totals, uint8_t *d_outs, uint64_t out_stride,
-                               hipStream_t s)
+                               uint32_t *d_chunk_bits, uint64_t *d_chunk_off, uint64_t *d_totals, uint8_t *d_outs, hipStream_t s)
 {
     const u32 nchunks = huffman_chunks(n);
     if (nchunks == 0 || frames == 0) return hipSuccess;
@@ -614,8 +616,8 @@ hipError_t launch_huffman_pack(const uint8_t *src, uint64_t n, uint64_t stride, 
     static const u32 resident_count = resident_workgroups(k_token_count), resident_pack = resident_workgroups(k_token_pack);
     const dim3 grid_count(blocks_for(nchunks, frames, resident_count), frames), grid(blocks_for(nchunks, frames, resident_pack), frames);
     hipLaunchKernelGGL(k_token_count, grid_count, dim3(kPackThreads), 0, s, src, n, stride, nchunks, plans, dist_code, d_chunk_bits);
-    hipLaunchKernelGGL(k_huff_scan, dim3(frames), dim3(1024), 0, s, d_chunk_bits, d_chunk_off, nchunks, d_totals, plans, d_outs, out_stride);
-    hipLaunchKernelGGL(k_token_pack, grid, dim3(kPackThreads), 0, s, src, n, stride, nchunks, plans, dist_code, d_chunk_off, d_outs, out_stride);
+    hipLaunchKernelGGL(k_huff_scan, dim3(frames), dim3(1024), 0, s, d_chunk_bits, d_chunk_off, nchunks, d_totals, plans, d_outs);
+    hipLaunchKernelGGL(k_token_pack, grid, dim3(kPackThreads), 0, s, src, n, stride, nchunks, plans, dist_code, d_chunk_off, d_outs);
     return hipGetLastError();
 }
 

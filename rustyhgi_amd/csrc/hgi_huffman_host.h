@@ -24,7 +24,8 @@ struct DeflatePlan {
     uint64_t base_bits;                   // where the grid's tokens start
     uint32_t tail_bits;                   // the eight literals of the u64 width + end of block: <= 9 x 15 bits
     uint32_t tail[5];
-    uint32_t reserved[6];
+    uint32_t out_off[2];                  // where this frame's stream starts in the launch's output buffer (u64, low word first; a multiple of 4)
+    uint32_t reserved[4];
     uint8_t front[kPlanBytes - 1208];     // zero padded
 };
 static_assert(sizeof(DeflatePlan) == kPlanBytes, "plan block layout");

@@ -95,12 +95,11 @@ hipError_t launch_diff_stats(const uint8_t *a, const uint8_t *b, const Frames &f
 // not -- the histogram of candidate v is the sum of the two
 hipError_t launch_token_histogram(const uint8_t *src, uint64_t n, uint64_t stride, uint32_t frames, unsigned long long *d_hist,
                                   hipStream_t s);
-// device, passes 2 + 3: each frame's complete stream (front, tokens, tail) written to d_outs + frame * out_stride, which
+// device, passes 2 + 3: each frame's complete stream (front, tokens, tail) written to d_outs + its plan's out_off, which
 // need not be cleared (dist_code = reversed code | length << 24 of the one distance code); d_totals[frame] = the tokens'
 // bits.  Scratch: frames * huffman_chunks(n) u32 + as many u64.
 uint32_t huffman_chunks(uint64_t n);
 hipError_t launch_huffman_pack(const uint8_t *src, uint64_t n, uint64_t stride, uint32_t frames, const void *d_plans, uint32_t dist_code,
-                               uint32_t *d_chunk_bits, uint64_t *d_chunk_off, uint64_t *d_totals, uint8_t *d_outs, uint64_t out_stride,
-                               hipStream_t s);
+                               uint32_t *d_chunk_bits, uint64_t *d_chunk_off, uint64_t *d_totals, uint8_t *d_outs, hipStream_t s);
 
 }  // namespace hgi

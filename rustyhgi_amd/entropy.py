@@ -75,3 +75,21 @@ def deflate_grids(grids, context=None):
     sizes = (ctypes.c_size_t * b)()
     _ffi.check(_ffi.lib().hgi_deflate_grids_dev(ctx.handle, grids.data_ptr(), w, h, b, h * w, out.ctypes.data, cap, sizes))
     return [out[f, :sizes[f]].tobytes() for f in range(b)]
+
+
+def deflate_grids_packed(grids, context=None, out=None):
+    """As deflate_grids, through hgi_deflate_grids_packed_dev: the streams land back to back (64-byte aligned) in ONE
+    host buffer and a group of frames comes down with one copy instead of one per frame.  Returns (buffer, offsets,
+    sizes); stream f is buffer[offsets[f] : offsets[f] + sizes[f]].  `out`: a uint8 host array to pack into (e.g. a
+    pinned torch tensor's numpy view); by default one of the worst-case size is allocated."""
+    import ctypes
+    import torch
+    if grids.dim() != 3 or grids.dtype != torch.uint8 or not grids.is_cuda or not grids.is_contiguous():
+        raise TypeError("deflate_grids_packed() takes a contiguous uint8 CUDA tensor of shape (B, H, W)")
+    ctx = _torch_ctx(grids, context)
+    b, h, w = grids.shape
+    if out is None:
+        out = np.empty(b * (h * w + h * w // 8 + 1088), np.uint8)
+    sizes, offsets = (ctypes.c_size_t * b)(), (ctypes.c_size_t * b)()
+    _ffi.check(_ffi.lib().hgi_deflate_grids_packed_dev(ctx.handle, grids.data_ptr(), w, h, b, h * w, out.ctypes.data, out.size, offsets, sizes))
+    return out, list(offsets), list(sizes)

@@ -40,6 +40,13 @@ def fullhd():
 
 
 @pytest.fixture(scope="session")
+def fullhd709():
+    """C1's input as image-0.19's to_luma would take it from PIL's RGB decode (truncating BT.709; make_golden.py)."""
+    from PIL import Image
+    return np.array(Image.open(os.path.join(GOLDEN_DIR, "fullhd_luma709.png")))
+
+
+@pytest.fixture(scope="session")
 def oracle():
     from oracle import hgi_oracle
     hgi_oracle.build()

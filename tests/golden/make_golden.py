@@ -10,6 +10,10 @@ numpy restatement (oracle/hgi_numpy.py) before anything is written.
   fullhd_luma.png    1920x1080 luma of res/fullhd.jpg decoded by PIL convert('L')
                      -- INPUT PARITY UNPINNED: the reference decodes JPEG with the `image`
                      crate (different IDCT / luma weights); this file *is* config C1's input.
+  fullhd_luma709.png the same JPEG decoded by PIL to RGB, luma taken the way image-0.19's to_luma does it (truncated f32
+                     0.2126 R + 0.7152 G + 0.0722 B -- the formula the docs pair below confirmed on 625 / 625 lattice
+                     points).  Closer to what `hgi test res/fullhd.jpg` feeds the encoder (src/main.rs:42, 74); the JPEG
+                     IDCT still differs from the crate's, so C1's input stays UNPINNED -- C1 is run on both planes.
   docs_lena_pair.npz the one input/output pair the reference itself holds: docs/static_files/lena_source.png
                      ("source", README.md:6) and lena_hgi.png ("HGI compressed (low)", README.md:8-9), 400x400, as luma
                      planes.  The source is a grey palette PNG; its luma is taken the way image-0.19's to_luma does it
@@ -64,8 +68,32 @@ def run_case(img, levels, q, interp, cross_check=True):
                            sha_dec=sha(dec), fallbacks=int(fb), max_abs=mx, int_mse=mse)
 
 
+def luma709(rgb):
+    """image-0.19 `to_luma` on RGB8: truncated f32 0.2126 R + 0.7152 G + 0.0722 B."""
+    rgb = rgb.astype(np.float32)
+    return np.floor(np.float32(0.2126) * rgb[..., 0] + np.float32(0.7152) * rgb[..., 1] + np.float32(0.0722) * rgb[..., 2]).astype(np.uint8)
+
+
+def add_luma709(golden):
+    from PIL import Image
+    plane = luma709(np.array(Image.open(os.path.join(REF, "res/fullhd.jpg")).convert("RGB")))
+    assert plane.shape == (1080, 1920)
+    Image.fromarray(plane).save(os.path.join(HERE, "fullhd_luma709.png"), optimize=True)
+    for q in (0, 1, 2, 3):
+        for interp in (O.CROSSED, O.LEFTTOP):
+            golden["fullhd_luma709/L4/q%d/i%d" % (q, interp)] = run_case(plane, 4, q, interp)[2]
+
+
 def main():
     from PIL import Image
+    if "--add-luma709" in sys.argv:      # add the BT.709 plane of C1 to the committed golden.json without redoing the big cases
+        with open(os.path.join(HERE, "golden.json")) as f:
+            golden = json.load(f)
+        add_luma709(golden)
+        with open(os.path.join(HERE, "golden.json"), "w") as f:
+            json.dump(golden, f, indent=1, sort_keys=True)
+        print("golden.json now holds %d cases" % len(golden))
+        return
     lena = np.array(Image.open(os.path.join(REF, "res/LENA.TIF")))
     assert lena.shape == (256, 256) and lena.dtype == np.uint8
     assert sha(lena).startswith("f6a26c7641342ed5")
@@ -82,6 +110,7 @@ def main():
     np.savez_compressed(os.path.join(HERE, "docs_lena_pair.npz"), source_luma=luma.astype(np.uint8), hgi_low=after)
 
     golden, small = {}, {}
+    add_luma709(golden)
     rng = np.random.default_rng(SEED0)
     tiny = {
         "xy_12x8": (xy(12, 8), 3), "xy_8x8": (xy(8, 8), 3), "xy_13x7": (xy(13, 7), 3),

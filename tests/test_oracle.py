@@ -90,8 +90,8 @@ def test_small_golden_full_grids(oracle, golden, small):
     assert n >= 100
 
 
-def test_image_golden_hashes(oracle, golden, lena, fullhd):
-    for name, img in (("lena_256", lena), ("fullhd_luma", fullhd)):
+def test_image_golden_hashes(oracle, golden, lena, fullhd, fullhd709):
+    for name, img in (("lena_256", lena), ("fullhd_luma", fullhd), ("fullhd_luma709", fullhd709)):
         for q in range(4):
             for interp in (0, 1):
                 meta = golden["%s/L4/q%d/i%d" % (name, q, interp)]

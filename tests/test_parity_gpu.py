@@ -88,10 +88,12 @@ def test_small_golden_cases(ctxs, oracle, golden, small, path):
 
 
 @pytest.mark.parametrize("path", ["fused", "levelwise"])
-def test_lena_and_fullhd(ctxs, oracle, golden, lena, fullhd, path):
-    """BASELINE configs C0 (LENA.TIF, really 256x256) and C1 (fullhd luma; 1080 is not a multiple of 16)."""
+def test_lena_and_fullhd(ctxs, oracle, golden, lena, fullhd, fullhd709, path):
+    """BASELINE configs C0 (LENA.TIF, really 256x256) and C1 (fullhd luma; 1080 is not a multiple of 16).  C1 runs on
+    both readings of its input: PIL's BT.601 luma and the truncating BT.709 luma of image-0.19's to_luma (src/main.rs:42,
+    74) -- input parity stays unpinned either way (the JPEG IDCT differs), the codec's parity does not depend on it."""
     ctx = ctxs[path]
-    for name, img in (("lena_256", lena), ("fullhd_luma", fullhd)):
+    for name, img in (("lena_256", lena), ("fullhd_luma", fullhd), ("fullhd_luma709", fullhd709)):
         for q in range(4):
             for interp in (0, 1):
                 meta = golden["%s/L4/q%d/i%d" % (name, q, interp)]
@@ -324,6 +326,43 @@ def test_overlapping_buffers_are_refused(ctxs):
     assert L.hgi_encode_u8_dev(ctx.handle, d, w, h, 3, 1, lut.ctypes.data, d + 2 * n, 2, n) == _ffi.OK
     assert L.hgi_decode_u8_dev(ctx.handle, d + 2 * n, w, h, 3, 1, d, 2, n) == _ffi.OK
     torch.cuda.synchronize()
+    ctx.use_own_stream()
+
+
+def test_interleaved_frame_trains_are_accepted(ctxs, oracle):
+    """What must be disjoint is every input frame from every output frame, not the two spans: input and output frames may
+    interleave inside ONE allocation (in = base, out = base + w*h, stride = 2*w*h) -- and give the bytes separate buffers
+    give -- while a train shifted so that frames really intersect is refused, whichever way round."""
+    import torch
+    from rustyhgi_amd import _ffi
+    L, ctx = _ffi.lib(), ctxs["fused"]
+    w, h, levels, nf = 200, 72, 4, 3
+    n = w * h
+    lut, _ = oracle.linear_lut(oracle.MEDIUM)
+    imgs = np.stack([oracle.synth(oracle.SYNTH_NOISE, 11, f, w, h) for f in range(nf)])
+    want = [oracle.encode(imgs[f], levels, lut) for f in range(nf)]
+    both = torch.zeros((nf, 2, n), dtype=torch.uint8, device="cuda")          # [frame][0 = image | 1 = grid]
+    both[:, 0] = torch.from_numpy(imgs.reshape(nf, n)).cuda()
+    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    d = both.data_ptr()
+    _ffi.check(L.hgi_encode_u8_dev(ctx.handle, d, w, h, levels, 1, lut.ctypes.data, d + n, nf, 2 * n))
+    torch.cuda.synchronize()
+    got = both.cpu().numpy()
+    for f in range(nf):
+        assert (got[f, 1].reshape(h, w) == want[f]).all(), "encode, interleaved frame %d" % f
+        assert (got[f, 0].reshape(h, w) == imgs[f]).all(), "encode modified its input"
+    # decode back into the image slots of the same allocation
+    both[:, 0] = 0
+    _ffi.check(L.hgi_decode_u8_dev(ctx.handle, d + n, w, h, levels, 1, d, nf, 2 * n))
+    torch.cuda.synchronize()
+    got = both.cpu().numpy()
+    for f in range(nf):
+        assert (got[f, 0].reshape(h, w) == oracle.decode(want[f], levels)).all(), "decode, interleaved frame %d" % f
+    # the same trains one byte closer: frame i of one intersects frame i (or i + 1) of the other
+    for a, b in ((0, n - 1), (n - 1, 0), (0, n + 1), (n + 1, 0)):
+        assert L.hgi_encode_u8_dev(ctx.handle, d + a, w, h, levels, 1, lut.ctypes.data, d + b, nf - 1, 2 * n) == _ffi.EINVAL, (a, b)
+        assert L.hgi_decode_u8_dev(ctx.handle, d + a, w, h, levels, 1, d + b, nf - 1, 2 * n) == _ffi.EINVAL, (a, b)
+    assert b"overlap" in L.hgi_last_error()
     ctx.use_own_stream()
 
 
@@ -913,6 +952,23 @@ def test_device_entropy_stage_batch(H, oracle, lena):
         assert zlib.decompressobj(-15).decompress(streams[f]) == body, f
         assert streams[f] == entropy.deflate_grid(d[f]), f
     assert len(streams[3]) < 200          # an all-zero grid: a few run matches per KiB chunk
+    # the packed entry point: the same streams back to back in one buffer, 64-byte aligned starts
+    buf, offs, sizes = entropy.deflate_grids_packed(d)
+    assert offs[0] == 0 and all(o % 64 == 0 for o in offs) and all(offs[f + 1] >= offs[f] + sizes[f] for f in range(4))
+    for f in range(5):
+        assert buf[offs[f]:offs[f] + sizes[f]].tobytes() == streams[f], f
+    small = np.empty(offs[4] + sizes[4] - 1, np.uint8)          # one byte short of what the five streams need
+    with pytest.raises(_ffi_error()):
+        entropy.deflate_grids_packed(d, out=small)
+    empty = torch.empty((3, 0, 7), dtype=torch.uint8, device="cuda")          # no pixels: header + the two u64s, three times
+    buf0, offs0, sizes0 = entropy.deflate_grids_packed(empty)
+    for f in range(3):
+        assert zlib.decompressobj(-15).decompress(buf0[offs0[f]:offs0[f] + sizes0[f]].tobytes()) == struct.pack("<QQ", 0, 7)
+
+
+def _ffi_error():
+    from rustyhgi_amd import _ffi
+    return _ffi.HgiError
 
 
 def _run_structured(rng, n, max_run, nvalues):
@@ -1048,3 +1104,8 @@ def test_device_entropy_many_groups_pipeline(H, oracle):
         body = struct.pack("<Q", w * h) + base[i].tobytes() + struct.pack("<Q", w)
         assert zlib.decompressobj(-15).decompress(streams[i]) == body
         assert all(streams[f] == streams[i] for f in range(i, frames, 4)), i
+    # packed: several groups, one copy each; offsets keep ascending across the groups
+    buf, offs, sizes = entropy.deflate_grids_packed(d)
+    assert all(offs[f + 1] >= offs[f] + sizes[f] and offs[f] % 64 == 0 for f in range(frames - 1))
+    for f in (0, 1, 2, 3, 84, 85, 86, 170, 171, 199):
+        assert buf[offs[f]:offs[f] + sizes[f]].tobytes() == streams[f], f

@@ -1,6 +1,7 @@
 """A/B timing of several builds of the library in ONE process on the SAME placed planes (process-to-process and
 placement noise is as large as the effects being looked for).  Interleaves the builds round by round and prints the
-per-build median of the bench step (encode then decode, 64 x 4096^2, L4, Medium).
+per-build median of the bench step (encode then decode; default 64 x 4096^2, L4, Medium; AB_F / AB_W / AB_H / AB_LEVELS /
+AB_QUANT in the environment select another shape, e.g. C4: AB_F=1 AB_W=16384 AB_H=16384 AB_LEVELS=8 AB_QUANT=3).
 usage: ab.py [-r rounds] [-s steps] variant ...      ("-" = rustyhgi_amd/libhgi_hip.so, "_x" = libhgi_hip_x.so)"""
 import ctypes, os, sys, numpy as np, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -13,8 +14,8 @@ while args and args[0] in ("-r", "-s"):
     else: steps = int(args[1])
     args = args[2:]
 variants = args or ["-"]
-NF = 64; W = Hh = 4096; n = NF * W * Hh
-LEVELS = int(os.environ.get("AB_LEVELS", "4"))
+NF = int(os.environ.get("AB_F", "64")); W = int(os.environ.get("AB_W", "4096")); Hh = int(os.environ.get("AB_H", "4096")); n = NF * W * Hh
+LEVELS = int(os.environ.get("AB_LEVELS", "4")); QUANT = int(os.environ.get("AB_QUANT", "2"))      # C4: AB_F=1 AB_W=16384 AB_H=16384 AB_LEVELS=8 AB_QUANT=3
 stream = torch.cuda.Stream(); torch.cuda.set_stream(stream)
 _ffi._share_torch_hip_runtime()
 libs = {}
@@ -35,9 +36,9 @@ L0, h0 = libs[variants[0]]
 planes = (ctypes.c_void_p * 3)(); sep = ctypes.c_int(0)
 assert L0.hgi_planes_alloc(h0, n, 3, planes, ctypes.byref(sep)) == 0, L0.hgi_last_error()
 img, grid, out = [int(p) for p in planes]
-print("planes separated:", bool(sep.value), " levels", LEVELS)
+print("planes separated:", bool(sep.value), " %d x %dx%d levels %d quant %d" % (NF, W, Hh, LEVELS, QUANT))
 lut = np.zeros(256, np.uint8); err = np.zeros(1, np.uint8)
-assert L0.hgi_linear_lut(2, lut.ctypes.data, err.ctypes.data) == 0
+assert L0.hgi_linear_lut(QUANT, lut.ctypes.data, err.ctypes.data) == 0
 assert L0.hgi_synth_u8_dev(h0, _ffi.SYNTH_RAMP, 0x48474930 + 3, 0, W, Hh, img, NF, W * Hh) == 0
 res = {v: ([], []) for v in variants}
 for rnd in range(rounds):
