@@ -91,6 +91,19 @@ def cpu_baseline(args, lut, gpu_check):
             "one_thread_mpix_s": round(px / (r["enc_cpu_s"] + r["dec_cpu_s"]) / 1e6, 1)}
 
 
+def per_rank_record(batch, dist, values, device=None):
+    """All-gather of [plane-placement seconds, planes separated (0/1), encode ms, decode ms, settle steps] -> the
+    `per_rank` block of the line: every rank's numbers in rank order plus min / max of the two launch times."""
+    import torch
+    t = torch.tensor([float(v) for v in values], dtype=torch.float64, device=device or "cpu")
+    rows = batch.gather_stats(dist, t)
+    return {"planes_alloc_s": [round(float(r[0]), 4) for r in rows], "planes_separated": [bool(r[1] > 0.5) for r in rows],
+            "encode_ms": [round(float(r[2]), 4) for r in rows], "decode_ms": [round(float(r[3]), 4) for r in rows],
+            "settle_steps": [int(r[4]) for r in rows],
+            "encode_ms_min_max": [round(float(rows[:, 2].min()), 4), round(float(rows[:, 2].max()), 4)],
+            "decode_ms_min_max": [round(float(rows[:, 3].min()), 4), round(float(rows[:, 3].max()), 4)]}
+
+
 def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -102,6 +115,7 @@ def parse_args(argv=None):
     ap.add_argument("--quant", default="medium")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--no-pfine", action="store_true", help="skip the P_fine (levels = 1) leg")
+    ap.add_argument("--no-c4", action="store_true", help="skip the C4 leg (one 16384x16384 frame, level 8, High)")
     ap.add_argument("--no-extras", action="store_true",
                     help="only the timed steps and the copy yardstick: no P_fine leg, no plain-allocation comparison "
                          "(profiling passes: every k_*_tiles launch in the trace is then a launch of the headline workload)")
@@ -248,6 +262,9 @@ def run_rank(args):
         # launcher test can see that every rank took its own block
         mine = torch.tensor([first, count, rank], dtype=torch.int64)
         allst = batch.gather_stats(dist, mine)
+        # ... and the per-rank timing record of the real run (see per_rank_record): here each rank sends numbers derived
+        # from its rank, so that the launcher test can see every rank's row arrive in rank order
+        per_rank = per_rank_record(batch, dist, [0.001 * (rank + 1), 1.0, 0.5 + rank, 0.25 + rank, 8.0 * (rank + 1)])
         if rank == 0:
             emit(json.dumps({
                 "metric": "Mpixels/s encode+decode, 4K grayscale level=4 Medium", "value": None, "unit": "Mpixels/s",
@@ -257,7 +274,7 @@ def run_rank(args):
                 "config": {"workload": "rehearsal of the rank plumbing on the CPU (gloo): no codec work",
                            "frames_per_gpu": F, "global_frames": world * F, "parallelism": "frames sharded x%d" % world,
                            "levels": levels, "max_error": err, "table_sum": int(np.asarray(lut, np.int64).sum()),
-                           "shards": [[int(a), int(b)] for a, b, _ in allst]}}))
+                           "shards": [[int(a), int(b)] for a, b, _ in allst], "per_rank": per_rank}}))
         if dist is not None:
             dist.barrier()
             dist.destroy_process_group()
@@ -270,7 +287,13 @@ def run_rank(args):
     xgmi = codec.xgmi(dist, world, rank, fence, args.steps) if args.xgmi_scatter and not args.share_gpu else None
     entropy = codec.entropy_stage() if rank == 0 and world == 1 and not args.no_extras else None
 
+    c4 = codec.c4() if rank == 0 and world == 1 and not (args.no_extras or args.no_c4) else None
+
     # ---- per-rank checks + stats gather (RCCL all-gather) ----
+    # every rank's own view of its run, so that a multi-GPU line explains itself: how long plane placement took there and
+    # whether it succeeded (setup skew between ranks), and its own launch times (a slow GPU shows up by rank)
+    per_rank = per_rank_record(batch, dist, [codec.setup_s, 1.0 if codec.separated else 0.0, enc_ms, dec_ms,
+                                             float(settle["steps"]) if settle else 0.0], cdev)
     allst = batch.gather_stats(dist, codec.stats().to(cdev))
     if dist is not None:
         print("bench.py: rank %d gathered the statistics of %d ranks" % (rank, len(allst)), file=sys.stderr)
@@ -309,6 +332,7 @@ def run_rank(args):
                                            "note": "16-B/lane copy kernel moving the same bytes"}},
         }
         line["config"]["placement"] = placement
+        line["config"]["per_rank"] = per_rank
         line["config"]["per_step_ms"] = codec.per_step_ms()
         line["config"]["settle"] = settle
         if args.share_gpu:
@@ -319,6 +343,8 @@ def run_rank(args):
             line["xgmi_scatter_gather"] = xgmi
         if entropy is not None:
             line["entropy_stage"] = entropy
+        if c4 is not None:
+            line["c4"] = c4
         if world == 1 and not args.no_cpu:
             line["cpu_baseline"] = cpu_baseline(args, lut, codec.sample())
         emit(json.dumps(line))
@@ -352,6 +378,7 @@ class Codec:
         # one HBM region and writes another (+4-5 % on MI355X over planes that share a region, which is
         # what plain allocations give about half of the time).  --placement torch: plain torch allocations.
         self.planes = None
+        t_setup = time.perf_counter()
         if args.placement == "planes":
             # best effort inside the library; if it could not establish the separation, ask again while the first set
             # is still held (the new candidates then come from elsewhere), up to twice
@@ -394,6 +421,8 @@ class Codec:
             self.imgs = torch.empty((F, S, S), dtype=torch.uint8, device=dev)
             self.grids = torch.empty_like(self.imgs)
             self.outs = torch.empty_like(self.imgs)
+        self.setup_s = time.perf_counter() - t_setup            # plane placement (probing included) or plain allocation
+        self.separated = bool(self.planes is not None and self.planes.separated)
         _ffi.check(_ffi.lib().hgi_synth_u8_dev(ctx.handle, _ffi.SYNTH_RAMP, SEED0 + 3, first, S, S,
                                                self.imgs.data_ptr(), F, S * S))
         self.quant = table_quantizator(lut, err)
@@ -501,6 +530,72 @@ class Codec:
                 "moved_frac": round(moved / (slow * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                 "note": "1.75 B/px algorithmic (3/4 of the pixels are new); the launch also copies the 1/4 lattice "
                         "through, so 2 B/px cross HBM; frac uses the slower direction"}
+
+    def c4(self):
+        """BASELINE config C4 -- ONE 16384 x 16384 u8 frame ramp(4), level 8, High, Crossed: the only config whose single
+        launch exceeds the 256 MiB Infinity Cache.  Timed in the bench step's own pattern (encode, then decode of what
+        was just written), per launch with events on the codec's stream, after the frame stacks of the headline workload
+        have been released.  A deep pyramid: each direction is a short chain of launches (lattice plane first, then the
+        seeded tile launch; profiles/r03_c4_summary.md has the rocprofv3 rows)."""
+        import hashlib
+        torch, H, _ffi = self.torch, self.H, self._ffi
+        L = _ffi.lib()
+        W = 16384
+        n = W * W
+        res = {"workload": "C4: 1 x 16384x16384 u8 ramp(4), level=8 High, Crossed; encode then decode, HBM-resident"}
+        try:
+            err = np.zeros(1, np.uint8)
+            lut = np.zeros(256, np.uint8)
+            _ffi.check(L.hgi_linear_lut(3, lut.ctypes.data, err.ctypes.data))
+            img = torch.empty((W, W), dtype=torch.uint8, device=self.dev)
+            grid, out = torch.empty_like(img), torch.empty_like(img)
+            _ffi.check(L.hgi_synth_u8_dev(self.ctx.handle, _ffi.SYNTH_RAMP, SEED0 + 4, 0, W, W, img.data_ptr(), 1, n))
+            self.ctx.reserve(W, W, 8, 1)
+
+            def enc():
+                _ffi.check(L.hgi_encode_u8_dev(self.ctx.handle, img.data_ptr(), W, W, 8, 1, lut.ctypes.data, grid.data_ptr(), 1, n))
+
+            def dec():
+                _ffi.check(L.hgi_decode_u8_dev(self.ctx.handle, grid.data_ptr(), W, W, 8, 1, out.data_ptr(), 1, n))
+
+            reps, warm = 30, 60
+            ev = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(reps)]
+            for i in range(warm + reps):
+                e = ev[max(i - warm, 0)]
+                e[0].record()
+                enc()
+                e[1].record()
+                dec()
+                e[2].record()
+            torch.cuda.synchronize(self.dev)
+            e_us = float(np.mean([e[0].elapsed_time(e[1]) for e in ev])) * 1e3
+            d_us = float(np.mean([e[1].elapsed_time(e[2]) for e in ev])) * 1e3
+            c_us = self._timed(lambda: _ffi.check(L.hgi_copy_u8_dev(self.ctx.handle, img.data_ptr(), out.data_ptr(), n)), 20, warm=5) * 1e3
+            dec()
+            torch.cuda.synchronize(self.dev)
+            max_err = int((img[:4096].to(torch.int16) - out[:4096].to(torch.int16)).abs().max())
+            sha = hashlib.sha256(grid.cpu().numpy().tobytes()).hexdigest()
+            want = None
+            try:
+                with open(os.path.join(ROOT, "tests", "golden", "golden.json")) as f:
+                    want = json.load(f)["ramp4_16384/L8/q3/i1"]["sha_grid"]
+            except (OSError, KeyError, ValueError):
+                pass
+            alg = 2.0 * n
+
+            def rate(us):
+                return {"us": round(us, 2), "achieved": round(alg / us / 1e3, 1), "unit": "GB/s", "frac": round(alg / us / 1e3 / HBM_PEAK_GBS, 4)}
+
+            res.update({"algorithmic_bytes_per_call": alg, "peak": HBM_PEAK_GBS, "encode": rate(e_us), "decode": rate(d_us),
+                        "copy_same_run": rate(c_us), "max_abs_err": max_err, "grid_sha256": sha[:16],
+                        "grid_matches_golden": (sha == want) if want else None,
+                        "note": "per CALL (a deep pyramid is a chain of launches: lattice plane, then the seeded tile launch); "
+                                "decode reads the grid the encode before it has just written, as in the bench step"})
+            del img, grid, out
+        except Exception as e:      # an extra: never let it cost the line
+            res["error"] = "%s: %s" % (type(e).__name__, e)
+        self._restore()
+        return res
 
     def xgmi(self, dist, world, rank, fence, steps):
         """optional, separately labelled: every frame starts and ends on GPU 0.  Bound by the

@@ -180,11 +180,11 @@ bool use_lattice_kernel(const SubGeom &g, size_t batch)
 }
 
 hipError_t launch_encode_fused(const uint8_t *img, uint8_t *grid, const Frames &f, uint32_t k, int interp,
-                               const Lut256 &lut, bool ident, const Seeds *seeds, hipStream_t s, uint32_t row_limit = 0)
+                               const Lut256 &lut, bool ident, const Seeds *seeds, hipStream_t s, uint32_t row_limit = 0, uint8_t *rec_out = nullptr)
 {
     const uint32_t rows = row_limit && row_limit < f.height ? row_limit : f.height;   // what this launch really covers
-    return use_small_tiles(f.width, rows, k, f.batch) ? launch_encode_fused_32(img, grid, f, k, interp, lut, ident, seeds, s, row_limit)
-                                                      : launch_encode_fused_64(img, grid, f, k, interp, lut, ident, seeds, s, row_limit);
+    return use_small_tiles(f.width, rows, k, f.batch) ? launch_encode_fused_32(img, grid, f, k, interp, lut, ident, seeds, s, row_limit, rec_out)
+                                                      : launch_encode_fused_64(img, grid, f, k, interp, lut, ident, seeds, s, row_limit, rec_out);
 }
 
 hipError_t launch_decode_fused(const uint8_t *grid, uint8_t *img, const Frames &f, uint32_t k, int interp,
@@ -246,8 +246,20 @@ hgi_status encode_impl(hgi_ctx *c, const uint8_t *img, uint32_t w, uint32_t h, u
                                            g.sh, g.stride, c->stream));
         } else {
             HIP_TRY(launch_gather_lattice(img, f, k, sub_img, g.sw, g.sh, g.stride, c->stream));
-            HGI_TRY(encode_impl(c, sub_img, g.sw, g.sh, levels - k, interp, lut, sub_grid, batch, g.stride));
-            HGI_TRY(decode_impl(c, sub_grid, g.sw, g.sh, levels - k, interp, sub_rec, batch, g.stride));
+            // The plane's own pyramid in ONE launch when a tile holds it: the encoder writes its reconstruction beside the
+            // residuals (src/encoder.rs:63-64 has it in place anyway), so the plane need not be decoded again for the seeds.
+            static const bool no_rec = getenv("HGI_NO_ENC_REC") != nullptr;      // tests / experiments: the three-launch chain
+            hipError_t e = hipErrorNotSupported;
+            if (levels - k <= (uint32_t)kFusedMaxLevels && !no_rec) {
+                const Frames sf = {g.sw, g.sh, g.stride, (uint32_t)batch};
+                e = launch_encode_fused(sub_img, sub_grid, sf, levels - k, interp, l, is_identity(lut), nullptr, c->stream, 0, sub_rec);
+                if (e != hipSuccess && e != hipErrorNotSupported) HIP_TRY(e);
+            }
+            if (e != hipSuccess) {
+                (void)hipGetLastError();
+                HGI_TRY(encode_impl(c, sub_img, g.sw, g.sh, levels - k, interp, lut, sub_grid, batch, g.stride));
+                HGI_TRY(decode_impl(c, sub_grid, g.sw, g.sh, levels - k, interp, sub_rec, batch, g.stride));
+            }
         }
         Seeds sd = {sub_rec, sub_grid, g.sw, g.sh, g.stride};
         HIP_TRY(launch_encode_fused(img, grid, f, k, interp, l, is_identity(lut), &sd, c->stream));

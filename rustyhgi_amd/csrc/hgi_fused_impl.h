@@ -762,6 +762,7 @@ __device__ __forceinline__ void enc_level_coarse_fast(u8 *buf, u8 *rbuf, const u
 struct Buf {
     __amdgpu_buffer_rsrc_t rs;   // frame being read  (range check -> 0 beyond width*height)
     __amdgpu_buffer_rsrc_t rd;   // frame being written
+    __amdgpu_buffer_rsrc_t rr;   // encode with WREC: the reconstruction plane (src/encoder.rs:63-64 keeps it in place; here it is an output on request)
     u32 W, base;                 // base = Y0 * W + X0
 };
 
@@ -1085,7 +1086,9 @@ __device__ __forceinline__ void enc_level2_fast(u8 *buf, u8 *rbuf, const u8 *slu
     enc_halo_pass<INTERP, IDENT>(buf, rbuf, slut, 2, tl, W, H);
 }
 
-template <int INTERP, bool IDENT, int EDGE = 0>
+// WREC: the reconstruction of the tile goes out too (plane b.rr): lattice points from rbuf, new pixels as prediction +
+// residual -- what src/encoder.rs:63-64 writes back in place, and what the tile kernel of a deeper pyramid takes as seeds.
+template <int INTERP, bool IDENT, int EDGE = 0, bool WREC = false>
 __device__ __forceinline__ void enc_fine_fast(const u8 *buf, const u8 *rbuf, const u8 *slut, const Buf &b,
                                               const v4u (&odd)[NFINE], int rows = TH, int cols = TW)
 {
@@ -1155,6 +1158,21 @@ __device__ __forceinline__ void enc_fine_fast(const u8 *buf, const u8 *rbuf, con
             } else {
                 store_row_pair(o0, o1, b.rd, vo, Ws);
             }
+            if (WREC) {
+                const u32 oddm = 0xFF00FF00u;
+                const u32 q0 = __builtin_amdgcn_perm(P0, P0, 0x01010000u), q1 = __builtin_amdgcn_perm(P0, P0, 0x03030202u);
+                const u32 q2 = __builtin_amdgcn_perm(P1, P1, 0x01010000u), q3 = __builtin_amdgcn_perm(P1, P1, 0x03030202u);
+                // row y: even columns are lattice points (their reconstruction is rbuf's), odd columns prediction + residual
+                v4u r0 = {__builtin_amdgcn_perm(0u, c.x, 0x0c010c00u) | (add4(e0, q0) & oddm), __builtin_amdgcn_perm(0u, c.x, 0x0c030c02u) | (add4(e1, q1) & oddm),
+                          __builtin_amdgcn_perm(0u, c.y, 0x0c010c00u) | (add4(e2, q2) & oddm), __builtin_amdgcn_perm(0u, c.y, 0x0c030c02u) | (add4(e3, q3) & oddm)};
+                v4u r1 = {add4(g0, q0), add4(g1, q1), add4(g2, q2), add4(g3, q3)};
+                if (EDGE == 2) {
+                    const int y = 2 * (rp0 + (it + j) * (NL / CH));
+                    store_rows_edge(r0, r1, b.rr, vo, Ws, cols - 16 * (lane & (CH - 1)), y < rows, y + 1 < rows);
+                } else {
+                    store_row_pair(r0, r1, b.rr, vo, Ws);
+                }
+            }
         }
         r0 += PAIR * (NL / CH) * S;
         c0 += PAIR * (NL / CH) * S2;
@@ -1176,12 +1194,13 @@ __device__ __forceinline__ u8 *uniform_ptr(const u8 *p)
 // straddle the end of the frame, and the range check would drop it whole -- valid bytes included.  The host grants
 // the 3 bytes only when reading them is safe (fused_geom); what they hold lies right of the image and is masked.
 // Dwords that START at or beyond W * H are still out of range, so rows below the image keep reading as zero.
-__device__ __forceinline__ Buf make_buf(const u8 *fr, u8 *out, u32 W, u32 H, Tile tl, u32 tail)
+__device__ __forceinline__ Buf make_buf(const u8 *fr, u8 *out, u32 W, u32 H, Tile tl, u32 tail, u8 *rec = nullptr)
 {
     Buf b;
     const u32 bytes = W * H;   // the host only selects the fast path when this (plus the halo) fits 32 bits
     b.rs = __builtin_amdgcn_make_buffer_rsrc(uniform_ptr(fr), 0, bytes + tail, 0x00020000);
     b.rd = __builtin_amdgcn_make_buffer_rsrc(uniform_ptr(out), 0, bytes, 0x00020000);
+    b.rr = __builtin_amdgcn_make_buffer_rsrc(uniform_ptr(rec ? rec : out), 0, bytes, 0x00020000);
     b.W = W;
     b.base = __builtin_amdgcn_readfirstlane(tl.Y0 * W + tl.X0);
     return b;
@@ -1283,12 +1302,12 @@ struct TileCtx {
     Buf b;
 };
 
-__device__ __forceinline__ TileCtx fast_ctx(u32 t, const u8 *src, u8 *dst, const Frames &f, const TileGrid &g, u32 tail)
+__device__ __forceinline__ TileCtx fast_ctx(u32 t, const u8 *src, u8 *dst, const Frames &f, const TileGrid &g, u32 tail, u8 *rec = nullptr)
 {
     TileCtx c;
     c.tl = fast_tile(t, g);
     c.b = make_buf(src + (size_t)c.tl.frame * f.frame_stride, dst + (size_t)c.tl.frame * f.frame_stride, f.width,
-                   f.height, c.tl, tail);
+                   f.height, c.tl, tail, rec ? rec + (size_t)c.tl.frame * f.frame_stride : nullptr);
     return c;
 }
 
@@ -1487,7 +1506,7 @@ __device__ __forceinline__ void enc_seed_commit(u8 *buf, u8 *rbuf, const SeedReg
     LDS_ORDER();
 }
 
-template <int INTERP, bool IDENT, int EDGE>
+template <int INTERP, bool IDENT, int EDGE, bool WREC>
 __device__ __forceinline__ void enc_tile_edge(u8 *buf, u8 *rbuf, const u8 *slut, const TileCtx &cur,
                                               const v4u (&odd)[NFINE], u32 k, u32 W, u32 H)
 {
@@ -1500,10 +1519,10 @@ __device__ __forceinline__ void enc_tile_edge(u8 *buf, u8 *rbuf, const u8 *slut,
         }
         LDS_ORDER();
     }
-    enc_fine_fast<INTERP, IDENT, EDGE>(buf, rbuf, slut, cur.b, odd, (int)(H - cur.tl.Y0), (int)(W - cur.tl.X0));
+    enc_fine_fast<INTERP, IDENT, EDGE, WREC>(buf, rbuf, slut, cur.b, odd, (int)(H - cur.tl.Y0), (int)(W - cur.tl.X0));
 }
 
-template <int INTERP, bool IDENT>
+template <int INTERP, bool IDENT, bool WREC>
 __device__ __forceinline__ void enc_tile_fast(u8 *buf, u8 *rbuf, const u8 *slut, const TileCtx &cur,
                                               const v4u (&odd)[NFINE], u32 k, u32 W, u32 H)
 {
@@ -1527,7 +1546,7 @@ __device__ __forceinline__ void enc_tile_fast(u8 *buf, u8 *rbuf, const u8 *slut,
         LDS_ORDER();
     }
     HGI_MARK("fine");
-    enc_fine_fast<INTERP, IDENT>(buf, rbuf, slut, cur.b, odd);
+    enc_fine_fast<INTERP, IDENT, 0, WREC>(buf, rbuf, slut, cur.b, odd);
 }
 
 // Occupancy targets handed to the register allocator: encode fits 96 VGPRs (5 waves per SIMD, 20 per CU;
@@ -1535,9 +1554,11 @@ __device__ __forceinline__ void enc_tile_fast(u8 *buf, u8 *rbuf, const u8 *slut,
 #ifndef HGI_ENC_WAVES_PER_EU
 #define HGI_ENC_WAVES_PER_EU 5
 #endif
-template <int INTERP, bool IDENT, bool SEEDED, int TILE_ROWS>
+// WREC (never together with SEEDED): the launch also writes the reconstruction of every pixel to `rec` (same geometry as
+// dst) -- the top of a deeper pyramid's chain codes the lattice plane once and hands both planes on as seeds.
+template <int INTERP, bool IDENT, bool SEEDED, int TILE_ROWS, bool WREC = false>
 __global__ __launch_bounds__(NL) __attribute__((amdgpu_waves_per_eu(IDENT ? HGI_ENC_WAVES_PER_EU - 1 : HGI_ENC_WAVES_PER_EU))) void k_enc_tiles(const u8 *__restrict__ src, u8 *__restrict__ dst, Frames f, u32 k,
-                                                  Lut256 lut, Seeds sd, TileGrid g, u32 aligned)
+                                                  Lut256 lut, Seeds sd, TileGrid g, u32 aligned, u8 *__restrict__ rec)
 {
     HGI_TL_ENTRY();
     extern __shared__ __attribute__((aligned(16))) u8 smem[];
@@ -1562,7 +1583,7 @@ __global__ __launch_bounds__(NL) __attribute__((amdgpu_waves_per_eu(IDENT ? HGI_
     if (role.idle) return;
     if (!IDENT) reinterpret_cast<u32 *>(slut)[threadIdx.x] = lut.w[threadIdx.x];
     if (!role.edge) {
-        TileCtx cur = fast_ctx(role.index, src, dst, f, g, (aligned & 4u) ? 3u : 0u);
+        TileCtx cur = fast_ctx(role.index, src, dst, f, g, (aligned & 4u) ? 3u : 0u, WREC ? rec : nullptr);
         Stage st;
         SeedRegs seeds;
         HGI_MARK("stage_issue");
@@ -1574,7 +1595,7 @@ __global__ __launch_bounds__(NL) __attribute__((amdgpu_waves_per_eu(IDENT ? HGI_
         LDS_ORDER();
         HGI_TL_STAGED();
         enc_seed_commit<SEEDED>(buf, rbuf, seeds, k);
-        enc_tile_fast<INTERP, IDENT>(buf, rbuf, slut, cur, st.o, k, W, H);
+        enc_tile_fast<INTERP, IDENT, WREC>(buf, rbuf, slut, cur, st.o, k, W, H);
         HGI_MARK("end");
         HGI_TL_END();
         return;
@@ -1585,16 +1606,16 @@ __global__ __launch_bounds__(NL) __attribute__((amdgpu_waves_per_eu(IDENT ? HGI_
     SeedRegs seeds;
     if (SEEDED) seeds = seed_issue<true>(sd, tl, k);
     if (aligned & 2u) {   // 32-bit buffer offsets: buffer staging and the check-free levels with edge masks
-        TileCtx cur = {tl, make_buf(fr, out, W, H, tl, (aligned & 4u) ? 3u : 0u)};
+        TileCtx cur = {tl, make_buf(fr, out, W, H, tl, (aligned & 4u) ? 3u : 0u, WREC ? rec + (size_t)tl.frame * f.frame_stride : nullptr)};
         Stage st;
         stage_issue<true, true>(st, cur.b, tl, (int)k, nh);
         stage_commit<true>(buf, rbuf, st, nh);
         LDS_ORDER();
         enc_seed_commit<SEEDED>(buf, rbuf, seeds, k);
         if (tl.X0 + TW <= W && !(H & 1u))
-            enc_tile_edge<INTERP, IDENT, 1>(buf, rbuf, slut, cur, st.o, k, W, H);
+            enc_tile_edge<INTERP, IDENT, 1, WREC>(buf, rbuf, slut, cur, st.o, k, W, H);
         else
-            enc_tile_edge<INTERP, IDENT, 2>(buf, rbuf, slut, cur, st.o, k, W, H);
+            enc_tile_edge<INTERP, IDENT, 2, WREC>(buf, rbuf, slut, cur, st.o, k, W, H);
         return;
     }
     stage_tile_generic(buf, fr, W, H, tl, nh, (aligned & 1u) != 0);
@@ -1708,10 +1729,13 @@ hipError_t static_lds_is_empty(const void *kernel)
 }  // namespace
 
 hipError_t HGI_TILED(launch_encode_fused)(const uint8_t *img, uint8_t *grid, const Frames &f, uint32_t k, int interp,
-                                          const Lut256 &lut, bool ident, const Seeds *seeds, hipStream_t s, uint32_t row_limit)
+                                          const Lut256 &lut, bool ident, const Seeds *seeds, hipStream_t s, uint32_t row_limit, uint8_t *rec_out)
 {
     FusedGeom r = fused_geom(img, grid, f, row_limit);
     if (!r.ok || k < 1 || k > (u32)MAXK) return hipErrorInvalidValue;
+    // the reconstruction output exists on the check-free paths only (and never under seeds): the caller falls back to
+    // decoding the grid it just made
+    if (rec_out && (seeds || !(r.aligned & 2u))) return hipErrorNotSupported;
     const TileGrid &g = r.g;
     if (seeds && k < (uint32_t)kSeededMinLevels) return hipErrorInvalidValue;      // one lane per lattice point (seed_issue)
     Seeds sd = seeds ? *seeds : Seeds{nullptr, nullptr, 0, 0, 0};
@@ -1725,15 +1749,23 @@ hipError_t HGI_TILED(launch_encode_fused)(const uint8_t *img, uint8_t *grid, con
     do {                                                                                                          \
         static const hipError_t lds0 = static_lds_is_empty(reinterpret_cast<const void *>(&k_enc_tiles<I, ID, SE, TH>)); \
         if (lds0 != hipSuccess) return lds0;                                                                      \
-        hipLaunchKernelGGL((k_enc_tiles<I, ID, SE, TH>), blocks, b, lds, s, img, grid, f, k, lut, sd, g, r.aligned); \
+        hipLaunchKernelGGL((k_enc_tiles<I, ID, SE, TH>), blocks, b, lds, s, img, grid, f, k, lut, sd, g, r.aligned, (u8 *)nullptr); \
+    } while (0)
+#define HGI_ENC_REC(I, ID)                                                                                        \
+    do {                                                                                                          \
+        static const hipError_t lds0 = static_lds_is_empty(reinterpret_cast<const void *>(&k_enc_tiles<I, ID, false, TH, true>)); \
+        if (lds0 != hipSuccess) return lds0;                                                                      \
+        hipLaunchKernelGGL((k_enc_tiles<I, ID, false, TH, true>), blocks, b, lds, s, img, grid, f, k, lut, sd, g, r.aligned, rec_out); \
     } while (0)
 #define HGI_ENC_I(I)                                                          \
     do {                                                                      \
-        if (ident) { if (seeds) HGI_ENC(I, true, true); else HGI_ENC(I, true, false); } \
+        if (rec_out) { if (ident) HGI_ENC_REC(I, true); else HGI_ENC_REC(I, false); } \
+        else if (ident) { if (seeds) HGI_ENC(I, true, true); else HGI_ENC(I, true, false); } \
         else       { if (seeds) HGI_ENC(I, false, true); else HGI_ENC(I, false, false); } \
     } while (0)
     if (interp == kInterpCrossed) HGI_ENC_I(kInterpCrossed); else HGI_ENC_I(kInterpLeftTop);
 #undef HGI_ENC_I
+#undef HGI_ENC_REC
 #undef HGI_ENC
     return hipGetLastError();
 }

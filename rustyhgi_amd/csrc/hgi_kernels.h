@@ -55,13 +55,14 @@ hipError_t launch_encode_level(uint8_t *rec, uint8_t *grid, const Frames &f, uin
 
 // ---- fused path: the last k <= kFusedMaxLevels levels of every tile in one launch ------------
 // (_64 / _32 = tile rows; k <= kFusedMaxLevels resp. kFusedMaxLevelsSmall; row_limit: pixel rows (multiple of 64)
-// above which tile rows are launched, 0 = all -- bands of a frame that is still being uploaded)
+// above which tile rows are launched, 0 = all -- bands of a frame that is still being uploaded; rec_out: the encoder
+// also writes its reconstruction there (unseeded launches on the check-free paths only, else hipErrorNotSupported))
 #define HGI_DECLARE_FUSED(TH)                                                                                      \
     hipError_t launch_decode_fused_##TH(const uint8_t *grid, uint8_t *img, const Frames &f, uint32_t k, int interp, \
                                         const Seeds *seeds, hipStream_t s, uint32_t row_limit);                    \
     hipError_t launch_encode_fused_##TH(const uint8_t *img, uint8_t *grid, const Frames &f, uint32_t k, int interp, \
                                         const Lut256 &lut, bool lut_is_identity, const Seeds *seeds, hipStream_t s, \
-                                        uint32_t row_limit);
+                                        uint32_t row_limit, uint8_t *rec_out);
 HGI_DECLARE_FUSED(64)
 HGI_DECLARE_FUSED(32)
 #undef HGI_DECLARE_FUSED

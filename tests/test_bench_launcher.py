@@ -39,6 +39,12 @@ def test_plain_command_launches_two_ranks():
     assert d["config"]["levels"] == 4 and d["config"]["max_error"] == 20       # the broadcast reached rank 0's line
     for rank in (0, 1):
         assert "rank %d/2 joined (gloo)" % rank in r.stderr
+    # every rank's own record arrives in rank order (the real run sends plane-placement time, the separated flag and its
+    # launch times; the rehearsal sends numbers made from the rank), with min / max over the ranks beside it
+    pr = d["config"]["per_rank"]
+    assert pr["planes_alloc_s"] == [0.001, 0.002] and pr["planes_separated"] == [True, True]
+    assert pr["encode_ms"] == [0.5, 1.5] and pr["decode_ms"] == [0.25, 1.25] and pr["settle_steps"] == [8, 16]
+    assert pr["encode_ms_min_max"] == [0.5, 1.5] and pr["decode_ms_min_max"] == [0.25, 1.25]
 
 
 @pytest.mark.timeout(300)
