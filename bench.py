@@ -91,19 +91,6 @@ def cpu_baseline(args, lut, gpu_check):
             "one_thread_mpix_s": round(px / (r["enc_cpu_s"] + r["dec_cpu_s"]) / 1e6, 1)}
 
 
-def per_rank_record(batch, dist, values, device=None):
-    """All-gather of [plane-placement seconds, planes separated (0/1), encode ms, decode ms, settle steps] -> the
-    `per_rank` block of the line: every rank's numbers in rank order plus min / max of the two launch times."""
-    import torch
-    t = torch.tensor([float(v) for v in values], dtype=torch.float64, device=device or "cpu")
-    rows = batch.gather_stats(dist, t)
-    return {"planes_alloc_s": [round(float(r[0]), 4) for r in rows], "planes_separated": [bool(r[1] > 0.5) for r in rows],
-            "encode_ms": [round(float(r[2]), 4) for r in rows], "decode_ms": [round(float(r[3]), 4) for r in rows],
-            "settle_steps": [int(r[4]) for r in rows],
-            "encode_ms_min_max": [round(float(rows[:, 2].min()), 4), round(float(rows[:, 2].max()), 4)],
-            "decode_ms_min_max": [round(float(rows[:, 3].min()), 4), round(float(rows[:, 3].max()), 4)]}
-
-
 def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -353,6 +340,19 @@ def run_rank(args):
         dist.destroy_process_group()
     codec.close()
     return 0
+
+
+def per_rank_record(batch, dist, values, device=None):
+    """All-gather of [plane-placement seconds, planes separated (0/1), encode ms, decode ms, settle steps] -> the
+    `per_rank` block of the line: every rank's numbers in rank order plus min / max of the two launch times."""
+    import torch
+    t = torch.tensor([float(v) for v in values], dtype=torch.float64, device=device or "cpu")
+    rows = batch.gather_stats(dist, t)
+    return {"planes_alloc_s": [round(float(r[0]), 4) for r in rows], "planes_separated": [bool(r[1] > 0.5) for r in rows],
+            "encode_ms": [round(float(r[2]), 4) for r in rows], "decode_ms": [round(float(r[3]), 4) for r in rows],
+            "settle_steps": [int(r[4]) for r in rows],
+            "encode_ms_min_max": [round(float(rows[:, 2].min()), 4), round(float(rows[:, 2].max()), 4)],
+            "decode_ms_min_max": [round(float(rows[:, 3].min()), 4), round(float(rows[:, 3].max()), 4)]}
 
 
 class Codec:

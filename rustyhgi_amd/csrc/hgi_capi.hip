@@ -43,6 +43,10 @@ hgi_status fail(hgi_status st, const char *fmt, ...)
 
 inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
+#ifndef HGI_TILE16_MAX_DEFAULT
+#define HGI_TILE16_MAX_DEFAULT 0      // 32-row tiles of a call at or below which 16-row tiles run instead (0: never; set from measurement)
+#endif
+
 }  // namespace
 
 struct hgi_ctx {
@@ -156,19 +160,29 @@ size_t ws_need(const hgi_ctx *c, uint32_t w, uint32_t h, uint32_t levels, size_t
 // Tile geometry of a fused launch.  128 x 64 tiles are the throughput shape; a call whose 64-row tiles would not
 // fill the GPU (256 CUs x 20-32 resident waves) finishes sooner with 128 x 32 tiles -- four times the waves, half
 // the dependent chain per wave.  Measured crossover on MI355X at level 4 (tools/size_sweep.py): equal at ~2000
-// tiles; 32-row ahead by 15-35 % below ~1200, 64-row ahead by 12 % at 4000.  HGI_TILE_H=32|64 in the environment
-// forces one (experiments only).
-bool use_small_tiles(uint32_t w, uint32_t h, uint32_t k, size_t batch)
+// tiles; 32-row ahead by 15-35 % below ~1200, 64-row ahead by 12 % at 4000.  A single small frame (up to about two
+// waves per CU of 32-row tiles) ends when its slowest wave does, and that wave's chain is mostly its own VALU work:
+// 128 x 16 tiles halve the finest level's share of it (profiles/r03_sizes.txt).  HGI_TILE_H=16|32|64 in the
+// environment forces one where the pyramid fits (experiments, tests); HGI_TILE16_MAX moves the lower crossover.
+uint32_t use_tile_rows(uint32_t w, uint32_t h, uint32_t k, size_t batch)
 {
     static const int forced = [] {
         const char *e = getenv("HGI_TILE_H");
         return e ? atoi(e) : 0;
     }();
-    if (k > (uint32_t)kFusedMaxLevelsSmall) return false;
-    if (forced == 32) return true;
-    if (forced == 64) return false;
-    const uint64_t tiles64 = (uint64_t)((w + kTileW - 1) / kTileW) * ((h + 63) / 64) * batch;
-    return tiles64 < 1536;
+    static const uint64_t tiny_max = [] {
+        const char *e = getenv("HGI_TILE16_MAX");
+        return e ? (uint64_t)atoll(e) : (uint64_t)HGI_TILE16_MAX_DEFAULT;
+    }();
+    if (k > (uint32_t)kFusedMaxLevelsSmall) return 64;
+    const bool fits16 = k <= (uint32_t)kFusedMaxLevelsTiny;
+    if (forced == 16 && fits16) return 16;
+    if (forced == 32 || (forced == 16 && !fits16)) return 32;
+    if (forced == 64) return 64;
+    const uint64_t tx = (w + kTileW - 1) / kTileW;
+    const uint64_t tiles64 = tx * ((h + 63) / 64) * batch, tiles32 = tx * ((h + 31) / 32) * batch;
+    if (fits16 && tiles32 <= tiny_max) return 16;
+    return tiles64 < 1536 ? 32 : 64;
 }
 
 // Deep pyramids: the one-workgroup-per-frame kernel for the levels above the fused depth, when the lattice plane is
@@ -183,16 +197,22 @@ hipError_t launch_encode_fused(const uint8_t *img, uint8_t *grid, const Frames &
                                const Lut256 &lut, bool ident, const Seeds *seeds, hipStream_t s, uint32_t row_limit = 0, uint8_t *rec_out = nullptr)
 {
     const uint32_t rows = row_limit && row_limit < f.height ? row_limit : f.height;   // what this launch really covers
-    return use_small_tiles(f.width, rows, k, f.batch) ? launch_encode_fused_32(img, grid, f, k, interp, lut, ident, seeds, s, row_limit, rec_out)
-                                                      : launch_encode_fused_64(img, grid, f, k, interp, lut, ident, seeds, s, row_limit, rec_out);
+    switch (use_tile_rows(f.width, rows, k, f.batch)) {
+    case 16: return launch_encode_fused_16(img, grid, f, k, interp, lut, ident, seeds, s, row_limit, rec_out);
+    case 32: return launch_encode_fused_32(img, grid, f, k, interp, lut, ident, seeds, s, row_limit, rec_out);
+    default: return launch_encode_fused_64(img, grid, f, k, interp, lut, ident, seeds, s, row_limit, rec_out);
+    }
 }
 
 hipError_t launch_decode_fused(const uint8_t *grid, uint8_t *img, const Frames &f, uint32_t k, int interp,
                                const Seeds *seeds, hipStream_t s, uint32_t row_limit = 0)
 {
     const uint32_t rows = row_limit && row_limit < f.height ? row_limit : f.height;
-    return use_small_tiles(f.width, rows, k, f.batch) ? launch_decode_fused_32(grid, img, f, k, interp, seeds, s, row_limit)
-                                                      : launch_decode_fused_64(grid, img, f, k, interp, seeds, s, row_limit);
+    switch (use_tile_rows(f.width, rows, k, f.batch)) {
+    case 16: return launch_decode_fused_16(grid, img, f, k, interp, seeds, s, row_limit);
+    case 32: return launch_decode_fused_32(grid, img, f, k, interp, seeds, s, row_limit);
+    default: return launch_decode_fused_64(grid, img, f, k, interp, seeds, s, row_limit);
+    }
 }
 
 Lut256 pack_lut(const uint8_t lut[256])

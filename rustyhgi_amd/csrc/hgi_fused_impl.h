@@ -42,9 +42,21 @@ using namespace dev;
 #define HGI_CAT2(a, b) a##_##b
 #define HGI_CAT(a, b) HGI_CAT2(a, b)
 #define HGI_TILED(name) HGI_CAT(name, HGI_TILE_H)   // launch_decode_fused -> launch_decode_fused_64
+// Experiment build -DHGI_PAIR=1 (never shipped; tools/ab.py): a workgroup is TWO waves owning two x-adjacent
+// tiles.  The left wave takes its halo column from the right wave's LDS slice (one s_barrier after staging) instead of
+// loading it from memory, so the right tile's even-row lines are read by nobody else and can be loaded `nt`.
+#ifndef HGI_PAIR
+#define HGI_PAIR 0
+#endif
+#if HGI_PAIR
+#define HGI_LANE ((int)(threadIdx.x & 63u))
+#else
+#define HGI_LANE ((int)threadIdx.x)
+#endif
+constexpr int NWAVES = HGI_PAIR ? 2 : 1;
 constexpr int TW = kTileW;
 constexpr int TH = HGI_TILE_H;
-constexpr int MAXK = TH == 64 ? kFusedMaxLevels : kFusedMaxLevelsSmall;   // deepest pyramid one tile holds
+constexpr int MAXK = TH == 64 ? kFusedMaxLevels : TH == 32 ? kFusedMaxLevelsSmall : kFusedMaxLevelsTiny;   // deepest pyramid one tile holds
 constexpr int NL = kThreads;       // lanes
 constexpr int CH = TW / 16;        // 16-B chunks per tile row
 constexpr int LCH = 3;             // log2(CH)
@@ -76,7 +88,7 @@ constexpr int RCOL = -(HR * HP2);
 __host__ __device__ constexpr int buf_bytes(int nh) { return HR * HP + (TH / 2 + nh) * S; }
 __host__ __device__ constexpr int rbuf_bytes(int nh) { return HR * HP2 + (TH / 2 + nh) * S2; }
 
-static_assert(NL == 64 && CH == (1 << LCH) && (TH & (TH - 1)) == 0 && (TH == 64 || TH == 32) && (1 << MAXK) <= TH, "tile geometry");
+static_assert(NL == 64 && CH == (1 << LCH) && (TH & (TH - 1)) == 0 && (TH == 64 || TH == 32 || TH == 16) && (1 << MAXK) <= TH, "tile geometry");
 // 16-B accesses on the full-resolution rows, 8-B accesses on the half-resolution rows
 static_assert(S % 16 == 0 && (HR * HP) % 16 == 0 && S2 % 8 == 0 && (HR * HP2) % 16 == 0 && HP >= TH / 2 + HR &&
                   HP2 >= TH / 2 + HR && buf_bytes(1) % 16 == 0 && rbuf_bytes(1) % 8 == 0,
@@ -257,7 +269,7 @@ __device__ __forceinline__ int laddr2(int x, int y)
 // speed; tools/check_isa.py rejects any DPP in these kernels.
 __device__ __forceinline__ u32 from_next_lane(u32 v)
 {
-    return (u32)__builtin_amdgcn_ds_bpermute((int)((threadIdx.x + 1) << 2), (int)v);
+    return (u32)__builtin_amdgcn_ds_bpermute(((HGI_LANE + 1) << 2), (int)v);
 }
 
 struct Tile {
@@ -420,7 +432,7 @@ __device__ __forceinline__ void store16(u8 *__restrict__ fr, u32 W, u32 gx, u32 
 __device__ __noinline__ void stage_tile_generic(u8 *buf, const u8 *__restrict__ fr, u32 W, u32 H, Tile tl, int nh,
                                                 bool aligned)
 {
-    const int lane = threadIdx.x;
+    const int lane = HGI_LANE;
     for (int i = lane; i < (TH / 2 + nh) * CH; i += NL) {      // even rows and halo rows only
         int rr = i >> LCH, c = i & (CH - 1);
         int y = rr < TH / 2 ? 2 * rr : TH + hoff(rr - TH / 2);
@@ -455,7 +467,7 @@ __device__ __forceinline__ void dec_halo_cells(u8 *buf, int s, Tile tl, u32 W, u
     const bool deep = s >= 4;
     const int hs = hmap(s), h2 = hmap(step);
     u8 *hc = buf + HCOL;
-    const int lane = threadIdx.x;
+    const int lane = HGI_LANE;
     if (tl.X0 + TW < W && lane <= ncy) {           // column cells; lane == ncy is the corner cell (TW, TH)
         const int y0 = lane << lstep;
         if (tl.Y0 + y0 < H) {
@@ -494,7 +506,7 @@ __device__ __forceinline__ void dec_cells(u8 *buf, int s, Tile tl, u32 W, u32 H)
     const int ncx = TW >> lstep, ncy = TH >> lstep, lncx = 31 - __clz(ncx);
     // natural LDS coordinates: x0 + step <= TW maps to itself, image row y <= TH to LDS row y / 2
     const int hs = s >> 1;
-    for (int i = threadIdx.x; i < ncx * ncy; i += NL) {
+    for (int i = HGI_LANE; i < ncx * ncy; i += NL) {
         int x0 = (i & (ncx - 1)) << lstep, y0 = (i >> lncx) << lstep;
         if (CHECK && (tl.X0 + x0 >= W || tl.Y0 + y0 >= H)) continue;
         u8 *c = buf + (y0 >> 1) * S + x0;
@@ -517,7 +529,7 @@ __device__ __forceinline__ void enc_cells(u8 *buf, u8 *rbuf, const u8 *slut, int
 {
     const int step = 2 * s, hs = s >> 1, lstep = 31 - __clz(step);
     const int ncx = TW >> lstep, ncy = TH >> lstep, lncx = 31 - __clz(ncx);
-    for (int i = threadIdx.x; i < ncx * ncy; i += NL) {
+    for (int i = HGI_LANE; i < ncx * ncy; i += NL) {
         int x0 = (i & (ncx - 1)) << lstep, y0 = (i >> lncx) << lstep;
         if (CHECK && (tl.X0 + x0 >= W || tl.Y0 + y0 >= H)) continue;
         u8 *c = buf + (y0 >> 1) * S + x0;
@@ -549,7 +561,7 @@ template <int INTERP>
 __device__ __noinline__ void dec_fine_generic(const u8 *buf, const u8 *__restrict__ fr, u8 *__restrict__ out, Tile tl,
                                               u32 W, u32 H, bool aligned)
 {
-    for (int i = threadIdx.x; i < (TH / 2) * CH; i += NL) {
+    for (int i = HGI_LANE; i < (TH / 2) * CH; i += NL) {
         const int z = i >> LCH, y = 2 * z, x = 16 * (i & (CH - 1));
         const u32 gx = tl.X0 + x, gy = tl.Y0 + y;
         if (gx >= W || gy >= H) continue;
@@ -579,7 +591,7 @@ template <int INTERP, bool IDENT>
 __device__ __forceinline__ void enc_fine_generic(const u8 *buf, const u8 *rbuf, const u8 *slut, const u8 *__restrict__ fr,
                                               u8 *__restrict__ out, Tile tl, u32 W, u32 H, bool aligned)
 {
-    for (int i = threadIdx.x; i < (TH / 2) * CH; i += NL) {
+    for (int i = HGI_LANE; i < (TH / 2) * CH; i += NL) {
         const int y = 2 * (i >> LCH), x = 16 * (i & (CH - 1));
         const u32 gx = tl.X0 + x, gy = tl.Y0 + y;
         if (gx >= W || gy >= H) continue;
@@ -724,7 +736,7 @@ template <int INTERP, bool IDENT>
 __device__ __forceinline__ void enc_halo_pass(u8 *buf, u8 *rbuf, const u8 *slut, int s, Tile tl, u32 W, u32 H)
 {
     const int lstep = 31 - __clz(2 * s), nhalo = (TH >> lstep) + 1 + (TW >> lstep);
-    const CellAddr a = (int)threadIdx.x < nhalo ? enc_halo_cell(threadIdx.x, s, tl, W, H) : idle_cell();
+    const CellAddr a = HGI_LANE < nhalo ? enc_halo_cell(HGI_LANE, s, tl, W, H) : idle_cell();
     const CellVal v = cell_load(buf, rbuf, a);
     cell_finish<INTERP, IDENT>(buf, rbuf, slut, a, v);
 }
@@ -735,7 +747,7 @@ __device__ __forceinline__ void enc_halo_pass(u8 *buf, u8 *rbuf, const u8 *slut,
 template <int INTERP, bool IDENT>
 __device__ __forceinline__ void enc_level_coarse_fast(u8 *buf, u8 *rbuf, const u8 *slut, int s, Tile tl, u32 W, u32 H)
 {
-    const int lane = threadIdx.x;
+    const int lane = HGI_LANE;
     if (s == 4) {
         constexpr int ncells4 = (TW / 8) * (TH / 8);
         const CellAddr a0 = enc_body_cell(lane, 4, lane < ncells4), a1 = enc_body_cell(lane + NL, 4, lane + NL < ncells4);
@@ -769,7 +781,7 @@ struct Buf {
 // Row pair (image rows 2p, 2p + 1) a lane owns in iteration `it` of the finest level, p = fine_pair0 + 8 * it:
 // the octets of a half-wave take pairs 0,2,4,6 / 1,3,5,7, i.e. LDS rows two apart (bank skew).
 // The staging loads of the odd rows use the same map, which is what lets those rows stay in registers.
-__device__ __forceinline__ int fine_pair0() { return 2 * (((int)threadIdx.x >> LCH) & 3) + ((int)threadIdx.x >> 5); }
+__device__ __forceinline__ int fine_pair0() { return 2 * ((HGI_LANE >> LCH) & 3) + (HGI_LANE >> 5); }
 constexpr int NFINE = (TH / 2) * CH / NL;   // fine-level iterations = odd rows a lane holds
 
 // Everything a tile stages: all loads are issued before the first LDS write.
@@ -786,9 +798,12 @@ struct Stage {
 // RAGGED tiles that finish in the generic fine level fetch their odd rows there; bottom-ragged tiles
 // (ODD_CHECKED) keep the fast fine level and load them here, row offsets in voffset like the even rows.
 template <bool RAGGED, bool ODD_CHECKED = false>
-__device__ __forceinline__ void stage_issue(Stage &st, const Buf &b, Tile tl, int k, int nh)
+__device__ __forceinline__ void stage_issue(Stage &st, const Buf &b, Tile tl, int k, int nh, u32 wv = 0)
 {
-    const int lane = threadIdx.x, c = lane & (CH - 1), r = lane >> LCH;
+    // pair build, interior tiles: the right wave's lines have no other reader (nt); the left wave's halo column comes from
+    // the right wave's LDS slice, not from memory
+    const bool right_nt = HGI_PAIR && !RAGGED && wv == 1, skip_col = HGI_PAIR && !RAGGED && wv == 0;
+    const int lane = HGI_LANE, c = lane & (CH - 1), r = lane >> LCH;
     const u32 W = __builtin_amdgcn_readfirstlane(b.W);   // soffset operands must be provably uniform
     const u32 voff = b.base + 2 * r * W + 16 * c;                       // even rows 2 * (r + 8 j)
     const u32 vodd = b.base + (2 * fine_pair0() + 1) * W + 16 * c;      // odd rows 2 * (pair0 + 8 it) + 1
@@ -809,6 +824,8 @@ __device__ __forceinline__ void stage_issue(Stage &st, const Buf &b, Tile tl, in
         if (RAGGED) {
             if (cin) st.e[j] = __builtin_amdgcn_raw_buffer_load_b128(b.rs, voff + j * 16 * W, 0, 0);
             if (narrow) st.e[j] &= cm;
+        } else if (right_nt) {
+            st.e[j] = __builtin_amdgcn_raw_buffer_load_b128(b.rs, voff, j * 16 * W, 2);
         } else {
             st.e[j] = __builtin_amdgcn_raw_buffer_load_b128(b.rs, voff, j * 16 * W, HGI_LOAD_AUX);
         }
@@ -830,7 +847,7 @@ __device__ __forceinline__ void stage_issue(Stage &st, const Buf &b, Tile tl, in
     const u32 xr = tl.X0 + TW;              // first column right of the tile
     st.x0 = v3u{0, 0, 0};
     st.d16 = st.d32 = st.d64 = 0;
-    if (!(HGI_ABL & 16) && lane < TH / 2 + nh) {
+    if (!(HGI_ABL & 16) && !skip_col && lane < TH / 2 + nh) {
         if (xr < W) st.x0 = __builtin_amdgcn_raw_buffer_load_b96(b.rs, xo, 0, 0);
         if (xr + 4 >= W) st.x0.y = 0;    // offsets 4 / 8 can lie beyond the image when the width is not a multiple of 16
         if (xr + 8 >= W) st.x0.z = 0;
@@ -864,9 +881,9 @@ __device__ __forceinline__ v2u even_bytes(v4u a)
 // same registers.  Points of finer lattices hold originals until their level codes them; nothing reads
 // them earlier.
 template <bool LATTICE>
-__device__ __forceinline__ void stage_commit(u8 *buf, u8 *rbuf, const Stage &st, int nh)
+__device__ __forceinline__ void stage_commit(u8 *buf, u8 *rbuf, const Stage &st, int nh, bool skip_col = false)
 {
-    const int lane = threadIdx.x, c = lane & (CH - 1), r = lane >> LCH;
+    const int lane = HGI_LANE, c = lane & (CH - 1), r = lane >> LCH;
 #pragma unroll
     for (int j = 0; j < TH / 16; ++j) {
         *reinterpret_cast<v4u *>(buf + (r + 8 * j) * S + 16 * c) = st.e[j];
@@ -876,7 +893,7 @@ __device__ __forceinline__ void stage_commit(u8 *buf, u8 *rbuf, const Stage &st,
         *reinterpret_cast<v4u *>(buf + (TH / 2 + r) * S + 16 * c) = st.hv;
         if (LATTICE) *reinterpret_cast<v2u *>(rbuf + (TH / 2 + r) * S2 + 8 * c) = even_bytes(st.hv);
     }
-    if (lane < TH / 2 + nh) {
+    if (!skip_col && lane < TH / 2 + nh) {
         // transposed halo columns: slot {0..5} <- offsets {0, 4, 8, 16, 32, 64}, one byte per LDS row
         const u32 v[HR] = {st.x0.x, st.x0.y, st.x0.z, st.d16, st.d32, st.d64};
         u8 *h = buf + HCOL + lane, *h2 = rbuf + RCOL + lane;
@@ -888,14 +905,34 @@ __device__ __forceinline__ void stage_commit(u8 *buf, u8 *rbuf, const Stage &st,
     }
 }
 
+// pair build: the right wave hands the left wave its halo column -- bytes 0 / 4 / 8 / 16 / 32 / 64 of each of its staged
+// rows (halo rows included) -- by writing them into the left wave's transposed column slots; one workgroup barrier
+// follows.  Nothing of the right tile has been coded yet: these are the staged values, what the left wave would have
+// loaded from memory.
+template <bool LATTICE>
+__device__ __forceinline__ void pair_push_column(const u8 *mine, u8 *left_buf, u8 *left_rbuf, int nh)
+{
+    const int lane = HGI_LANE;
+    if (lane < TH / 2 + nh) {
+        const u8 *row = mine + lane * S;
+        const u32 lo = *reinterpret_cast<const u32 *>(row), m4 = *reinterpret_cast<const u32 *>(row + 4), m8 = *reinterpret_cast<const u32 *>(row + 8);
+        const u32 v[HR] = {lo, m4, m8, row[16], row[32], row[64]};
+#pragma unroll
+        for (int i = 0; i < HR; ++i) {
+            left_buf[HCOL + i * HP + lane] = (u8)v[i];
+            if (LATTICE) left_rbuf[RCOL + i * HP2 + lane] = (u8)v[i];
+        }
+    }
+}
+
 // the same initialisation out of LDS, for tiles staged by stage_tile_generic
 __device__ __forceinline__ void lattice_from_buf(const u8 *buf, u8 *rbuf, int nh)
 {
-    for (int i = threadIdx.x; i < (TH / 2 + nh) * CH; i += NL) {
+    for (int i = HGI_LANE; i < (TH / 2 + nh) * CH; i += NL) {
         const int rr = i >> LCH, c = i & (CH - 1);
         *reinterpret_cast<v2u *>(rbuf + rr * S2 + 8 * c) = even_bytes(*reinterpret_cast<const v4u *>(buf + rr * S + 16 * c));
     }
-    for (int i = threadIdx.x; i < HR * (TH / 2 + nh); i += NL) {
+    for (int i = HGI_LANE; i < HR * (TH / 2 + nh); i += NL) {
         const int hc = i / (TH / 2 + nh), rr = i - hc * (TH / 2 + nh);
         rbuf[RCOL + hc * HP2 + rr] = buf[HCOL + hc * HP + rr];
     }
@@ -916,9 +953,13 @@ __device__ __forceinline__ u32 gather_b0(v4u a)
 template <int INTERP, int EDGE = 0>
 __device__ __forceinline__ void dec_level2_fast(u8 *buf, int rows = TH, int cols = TW)
 {
+    // (TH / 4) * CH lane tasks: whole iterations of the wave for 32- and 64-row tiles, half a wave for 16-row tiles (the
+    // idle lanes compute on task 0 and do not store)
+    constexpr int N2 = (TH / 4) * CH;
 #pragma unroll
-    for (int it = 0; it < (TH / 4) * CH / NL; ++it) {
-        const int i = threadIdx.x + it * NL;
+    for (int it = 0; it < (N2 + NL - 1) / NL; ++it) {
+        const bool on = N2 % NL == 0 || HGI_LANE + it * NL < N2;
+        const int i = on ? HGI_LANE + it * NL : 0;
         u8 *r0 = buf + 2 * (i >> LCH) * S + 16 * (i & (CH - 1));      // image rows y0, y0 + 2, y0 + 4 = LDS rows z0 ..
         v4u A = *reinterpret_cast<const v4u *>(r0);
         v4u B = *reinterpret_cast<const v4u *>(r0 + S);
@@ -944,8 +985,8 @@ __device__ __forceinline__ void dec_level2_fast(u8 *buf, int rows = TH, int cols
             An &= m;
             Bn &= m;
         }
-        if (!EDGE || 2 * z0 < rows) *reinterpret_cast<v4u *>(r0) = An;
-        if (!EDGE || 2 * z0 + 2 < rows) *reinterpret_cast<v4u *>(r0 + S) = Bn;
+        if (on && (!EDGE || 2 * z0 < rows)) *reinterpret_cast<v4u *>(r0) = An;
+        if (on && (!EDGE || 2 * z0 + 2 < rows)) *reinterpret_cast<v4u *>(r0 + S) = Bn;
     }
 }
 
@@ -955,7 +996,7 @@ __device__ __forceinline__ void dec_level2_fast(u8 *buf, int rows = TH, int cols
 template <int INTERP, int EDGE = 0>
 __device__ __forceinline__ void dec_fine_fast(const u8 *buf, const Buf &b, const v4u (&odd)[NFINE], int rows = TH, int cols = TW)
 {
-    const int lane = threadIdx.x;
+    const int lane = HGI_LANE;
     const int rp0 = fine_pair0();
     const bool last = (lane & (CH - 1)) == CH - 1;
     const u8 *r0 = buf + rp0 * S + 16 * (lane & (CH - 1));
@@ -1007,10 +1048,11 @@ __device__ __forceinline__ void enc_level2_fast(u8 *buf, u8 *rbuf, const u8 *slu
     // halo cells in a pass of their own afterwards: with the odd rows parked in registers the level is
     // the kernel's register high-water mark, and 96 VGPRs (5 waves per SIMD) beat the longer chains that
     // batching both iterations and the halo cells into one bought at 12 waves per CU.
-    constexpr int NIT = (TH / 4) * CH / NL;
+    constexpr int N2 = (TH / 4) * CH, NIT = (N2 + NL - 1) / NL;      // see dec_level2_fast
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
-        const int i = threadIdx.x + it * NL;
+        const bool on = N2 % NL == 0 || HGI_LANE + it * NL < N2;
+        const int i = on ? HGI_LANE + it * NL : 0;
         const int g = i >> LCH, c = i & (CH - 1);
         u8 *r0 = buf + 2 * g * S + 16 * c;
         u8 *q0 = rbuf + 2 * g * S2 + 8 * c;
@@ -1071,11 +1113,11 @@ __device__ __forceinline__ void enc_level2_fast(u8 *buf, u8 *rbuf, const u8 *slu
             n0 &= m2;
             n1 &= m2;
         }
-        if (!EDGE || 4 * g < rows) {
+        if (on && (!EDGE || 4 * g < rows)) {
             *reinterpret_cast<v4u *>(r0) = An;
             *reinterpret_cast<v2u *>(q0) = n0;
         }
-        if (!EDGE || 4 * g + 2 < rows) {
+        if (on && (!EDGE || 4 * g + 2 < rows)) {
             *reinterpret_cast<v4u *>(r0 + S) = Bn;
             *reinterpret_cast<v2u *>(q0 + S2) = n1;
         }
@@ -1092,7 +1134,7 @@ template <int INTERP, bool IDENT, int EDGE = 0, bool WREC = false>
 __device__ __forceinline__ void enc_fine_fast(const u8 *buf, const u8 *rbuf, const u8 *slut, const Buf &b,
                                               const v4u (&odd)[NFINE], int rows = TH, int cols = TW)
 {
-    const int lane = threadIdx.x;
+    const int lane = HGI_LANE;
     const int rp0 = fine_pair0();
     const bool last = (lane & (CH - 1)) == CH - 1;
     const u8 *r0 = buf + rp0 * S + 16 * (lane & (CH - 1));
@@ -1103,7 +1145,7 @@ __device__ __forceinline__ void enc_fine_fast(const u8 *buf, const u8 *rbuf, con
 #ifndef HGI_FINE_BATCH
 #define HGI_FINE_BATCH 2
 #endif
-    constexpr int NIT = NFINE, PAIR = HGI_FINE_BATCH;   // row-pair groups per LDS dependency chain
+    constexpr int NIT = NFINE, PAIR = NFINE >= HGI_FINE_BATCH ? HGI_FINE_BATCH : 1;   // row-pair groups per LDS dependency chain
     static_assert(NIT % PAIR == 0, "fine level iterations come in pairs");
 #pragma unroll
     for (int it = 0; it < NIT; it += PAIR) {
@@ -1221,8 +1263,15 @@ struct TileGrid {
 #endif
 };
 
-__device__ __forceinline__ Tile fast_tile(u32 t, const TileGrid &g)
+__device__ __forceinline__ Tile fast_tile(u32 t, const TileGrid &gg, u32 wv = 0)
 {
+    // pair build: t counts PAIRS of x-adjacent tiles; the tile walk runs on a grid half as wide and wave `wv` takes the
+    // left (0) or right (1) tile of the pair
+    TileGrid g = gg;
+    if (HGI_PAIR) {
+        g.full_x >>= 1;
+        g.nfast >>= 1;
+    }
     t = __builtin_amdgcn_readfirstlane(g.reverse ? g.nfast - 1u - t : t);
     const u32 tpf = g.full_x * g.full_y;
     Tile tl;
@@ -1271,7 +1320,7 @@ __device__ __forceinline__ Tile fast_tile(u32 t, const TileGrid &g)
 #endif
     }
 #endif
-    tl.X0 = tx * TW;
+    tl.X0 = (HGI_PAIR ? 2 * tx + wv : tx) * TW;
     tl.Y0 = ty * TH;
     return tl;
 }
@@ -1302,10 +1351,10 @@ struct TileCtx {
     Buf b;
 };
 
-__device__ __forceinline__ TileCtx fast_ctx(u32 t, const u8 *src, u8 *dst, const Frames &f, const TileGrid &g, u32 tail, u8 *rec = nullptr)
+__device__ __forceinline__ TileCtx fast_ctx(u32 t, const u8 *src, u8 *dst, const Frames &f, const TileGrid &g, u32 tail, u8 *rec = nullptr, u32 wv = 0)
 {
     TileCtx c;
-    c.tl = fast_tile(t, g);
+    c.tl = fast_tile(t, g, wv);
     c.b = make_buf(src + (size_t)c.tl.frame * f.frame_stride, dst + (size_t)c.tl.frame * f.frame_stride, f.width,
                    f.height, c.tl, tail, rec ? rec + (size_t)c.tl.frame * f.frame_stride : nullptr);
     return c;
@@ -1327,7 +1376,7 @@ __device__ __forceinline__ SeedRegs seed_issue(const Seeds &sd, Tile tl, u32 k)
 {
     const int ext = k >= 2 ? 2 : 1;   // offset 2^k beyond the tile is only ever read for k >= 2
     const int nbx = (TW >> k) + ext, nby = (TH >> k) + ext;
-    const int i = threadIdx.x;
+    const int i = HGI_LANE;
     SeedRegs r;
     r.by = i / nbx;
     r.bx = i - r.by * nbx;
@@ -1362,7 +1411,7 @@ __device__ __forceinline__ void dec_tile_fast(u8 *buf, const TileCtx &cur, const
         LDS_ORDER();                                                                           \
     }
     if (MAXK >= 6) HGI_DEC_COARSE(32)
-    HGI_DEC_COARSE(16)
+    if (MAXK >= 5) HGI_DEC_COARSE(16)
     HGI_DEC_COARSE(8)
     HGI_DEC_COARSE(4)
 #undef HGI_DEC_COARSE
@@ -1388,12 +1437,23 @@ template <int INTERP, int EDGE>
 __device__ __forceinline__ void dec_tile_edge(u8 *buf, const TileCtx &cur, const v4u (&odd)[NFINE], u32 k, u32 W, u32 H)
 {
     const int rows = (int)(H - cur.tl.Y0), cols = (int)(W - cur.tl.X0);
-    for (int s = 1 << (k - 1); s >= 2; s >>= 1) {
-        if (s == 2)
-            dec_level2_fast<INTERP, EDGE>(buf, rows, cols);
-        else
-            dec_cells<INTERP, true>(buf, s, cur.tl, W, H);
-        dec_halo_cells<INTERP>(buf, s, cur.tl, W, H);
+    // the levels as a straight-line chain with the level a compile-time constant in each link, like the interior path: a
+    // lone frame's launch ends when its ragged tiles do, and their address arithmetic with a run-time step was the
+    // longest chain in it (1920 x 1080: tools/size_sweep.py)
+#define HGI_DEC_EDGE_COARSE(SUB)                                   \
+    if (k > HGI_LOG2(SUB)) {                                       \
+        dec_cells<INTERP, true>(buf, SUB, cur.tl, W, H);           \
+        dec_halo_cells<INTERP>(buf, SUB, cur.tl, W, H);            \
+        LDS_ORDER();                                               \
+    }
+    if (MAXK >= 6) HGI_DEC_EDGE_COARSE(32)
+    if (MAXK >= 5) HGI_DEC_EDGE_COARSE(16)
+    HGI_DEC_EDGE_COARSE(8)
+    HGI_DEC_EDGE_COARSE(4)
+#undef HGI_DEC_EDGE_COARSE
+    if (k >= 2) {
+        dec_level2_fast<INTERP, EDGE>(buf, rows, cols);
+        dec_halo_cells<INTERP>(buf, 2, cur.tl, W, H);
         LDS_ORDER();
     }
     dec_fine_fast<INTERP, EDGE>(buf, cur.b, odd, rows, cols);
@@ -1417,7 +1477,7 @@ __device__ __forceinline__ BlockRole block_role(const TileGrid &g)
     r.edge = b < ne8;
     r.idle = r.edge && b >= g.nedge;
     const u32 fb = b - ne8;
-    r.index = r.edge ? b : range_first(g.nfast, fb & 7u) + (fb >> 3);
+    r.index = r.edge ? b : range_first(HGI_PAIR ? g.nfast >> 1 : g.nfast, fb & 7u) + (fb >> 3);
     return r;
 }
 
@@ -1425,16 +1485,17 @@ __device__ __forceinline__ BlockRole block_role(const TileGrid &g)
 #define HGI_DEC_WAVES_PER_EU 8
 #endif
 template <int INTERP, bool SEEDED, int TILE_ROWS>   // TILE_ROWS == TH: only there to name the build in profiles
-__global__ __launch_bounds__(NL) __attribute__((amdgpu_waves_per_eu(HGI_DEC_WAVES_PER_EU))) void k_dec_tiles(const u8 *__restrict__ src, u8 *__restrict__ dst, Frames f, u32 k,
+__global__ __launch_bounds__(NL * NWAVES) __attribute__((amdgpu_waves_per_eu(HGI_DEC_WAVES_PER_EU))) void k_dec_tiles(const u8 *__restrict__ src, u8 *__restrict__ dst, Frames f, u32 k,
                                                   Seeds sd, TileGrid g, u32 aligned)
 {
     HGI_TL_ENTRY();
     extern __shared__ __attribute__((aligned(16))) u8 smem[];
-    u8 *buf = smem - HCOL;
 #ifdef HGI_ANALYZE_K
     k = HGI_ANALYZE_K;
 #endif
     const int nh = k >= 2 ? (int)k : 1;
+    const u32 wv = HGI_PAIR ? __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) : 0u;      // which tile of the pair
+    u8 *buf = smem + wv * buf_bytes(nh) - HCOL;
     const u32 W = f.width, H = f.height;
 #ifdef HGI_ANALYZE_K
     BlockRole role = block_role(g);
@@ -1442,18 +1503,22 @@ __global__ __launch_bounds__(NL) __attribute__((amdgpu_waves_per_eu(HGI_DEC_WAVE
 #else
     const BlockRole role = block_role(g);
 #endif
-    if (role.idle) return;
+    if (role.idle || (HGI_PAIR && role.edge && wv)) return;
     if (!role.edge) {
-        TileCtx cur = fast_ctx(role.index, src, dst, f, g, (aligned & 4u) ? 3u : 0u);
+        TileCtx cur = fast_ctx(role.index, src, dst, f, g, (aligned & 4u) ? 3u : 0u, nullptr, wv);
         Stage st;
         SeedRegs seeds;
         HGI_MARK("stage_issue");
         HGI_TL_START();
-        stage_issue<false>(st, cur.b, cur.tl, (int)k, nh);
+        stage_issue<false>(st, cur.b, cur.tl, (int)k, nh, wv);
         if (SEEDED) seeds = seed_issue<false>(sd, cur.tl, k);
         HGI_MARK("stage_commit");
-        stage_commit<false>(buf, nullptr, st, nh);
+        stage_commit<false>(buf, nullptr, st, nh, HGI_PAIR && wv == 0);
         LDS_ORDER();
+        if (HGI_PAIR) {
+            if (wv) pair_push_column<false>(buf, smem - HCOL, nullptr, nh);
+            __syncthreads();
+        }
         HGI_TL_STAGED();
         if (SEEDED) dec_seed_commit(buf, seeds, k);
         dec_tile_fast<INTERP>(buf, cur, st.o, k, W, H);
@@ -1510,13 +1575,19 @@ template <int INTERP, bool IDENT, int EDGE, bool WREC>
 __device__ __forceinline__ void enc_tile_edge(u8 *buf, u8 *rbuf, const u8 *slut, const TileCtx &cur,
                                               const v4u (&odd)[NFINE], u32 k, u32 W, u32 H)
 {
-    for (int s = 1 << (k - 1); s >= 2; s >>= 1) {
-        if (s == 2) {
-            enc_level2_fast<INTERP, IDENT, EDGE>(buf, rbuf, slut, cur.tl, W, H);
-        } else {
-            enc_cells<INTERP, IDENT, true>(buf, rbuf, slut, s, cur.tl, W, H);
-            enc_halo_pass<INTERP, IDENT>(buf, rbuf, slut, s, cur.tl, W, H);
-        }
+#define HGI_ENC_EDGE_COARSE(SUB)                                                   \
+    if (k > HGI_LOG2(SUB)) {                                                       \
+        enc_cells<INTERP, IDENT, true>(buf, rbuf, slut, SUB, cur.tl, W, H);        \
+        enc_halo_pass<INTERP, IDENT>(buf, rbuf, slut, SUB, cur.tl, W, H);          \
+        LDS_ORDER();                                                               \
+    }
+    if (MAXK >= 6) HGI_ENC_EDGE_COARSE(32)
+    if (MAXK >= 5) HGI_ENC_EDGE_COARSE(16)
+    HGI_ENC_EDGE_COARSE(8)
+    HGI_ENC_EDGE_COARSE(4)
+#undef HGI_ENC_EDGE_COARSE
+    if (k >= 2) {
+        enc_level2_fast<INTERP, IDENT, EDGE>(buf, rbuf, slut, cur.tl, W, H);
         LDS_ORDER();
     }
     enc_fine_fast<INTERP, IDENT, EDGE, WREC>(buf, rbuf, slut, cur.b, odd, (int)(H - cur.tl.Y0), (int)(W - cur.tl.X0));
@@ -1536,7 +1607,7 @@ __device__ __forceinline__ void enc_tile_fast(u8 *buf, u8 *rbuf, const u8 *slut,
         LDS_ORDER();                                                                           \
     }
     if (MAXK >= 6) HGI_ENC_COARSE(32)
-    HGI_ENC_COARSE(16)
+    if (MAXK >= 5) HGI_ENC_COARSE(16)
     HGI_ENC_COARSE(8)
     HGI_ENC_COARSE(4)
 #undef HGI_ENC_COARSE
@@ -1557,7 +1628,7 @@ __device__ __forceinline__ void enc_tile_fast(u8 *buf, u8 *rbuf, const u8 *slut,
 // WREC (never together with SEEDED): the launch also writes the reconstruction of every pixel to `rec` (same geometry as
 // dst) -- the top of a deeper pyramid's chain codes the lattice plane once and hands both planes on as seeds.
 template <int INTERP, bool IDENT, bool SEEDED, int TILE_ROWS, bool WREC = false>
-__global__ __launch_bounds__(NL) __attribute__((amdgpu_waves_per_eu(IDENT ? HGI_ENC_WAVES_PER_EU - 1 : HGI_ENC_WAVES_PER_EU))) void k_enc_tiles(const u8 *__restrict__ src, u8 *__restrict__ dst, Frames f, u32 k,
+__global__ __launch_bounds__(NL * NWAVES) __attribute__((amdgpu_waves_per_eu(IDENT ? HGI_ENC_WAVES_PER_EU - 1 : HGI_ENC_WAVES_PER_EU))) void k_enc_tiles(const u8 *__restrict__ src, u8 *__restrict__ dst, Frames f, u32 k,
                                                   Lut256 lut, Seeds sd, TileGrid g, u32 aligned, u8 *__restrict__ rec)
 {
     HGI_TL_ENTRY();
@@ -1570,9 +1641,11 @@ __global__ __launch_bounds__(NL) __attribute__((amdgpu_waves_per_eu(IDENT ? HGI_
     // planes behind it have a size that depends on k).  Dynamic LDS starts at 0 because the kernel has no static LDS:
     // launch_encode_fused verifies that on the host (hipFuncGetAttributes) before the first launch of each
     // instantiation and refuses to launch otherwise -- nothing on the device can abort.
+    const u32 wv = HGI_PAIR ? __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) : 0u;      // which tile of the pair
+    const u32 slice = buf_bytes(nh) + ((rbuf_bytes(nh) + 15) & ~15);                       // one wave's planes
     u8 *slut = smem;
-    u8 *buf = smem + 256 - HCOL;
-    u8 *rbuf = smem + 256 + buf_bytes(nh) - RCOL;
+    u8 *buf = smem + 256 + wv * slice - HCOL;
+    u8 *rbuf = smem + 256 + wv * slice + buf_bytes(nh) - RCOL;
     const u32 W = f.width, H = f.height;
 #ifdef HGI_ANALYZE_K
     BlockRole role = block_role(g);
@@ -1580,19 +1653,23 @@ __global__ __launch_bounds__(NL) __attribute__((amdgpu_waves_per_eu(IDENT ? HGI_
 #else
     const BlockRole role = block_role(g);
 #endif
-    if (role.idle) return;
-    if (!IDENT) reinterpret_cast<u32 *>(slut)[threadIdx.x] = lut.w[threadIdx.x];
+    if (role.idle || (HGI_PAIR && role.edge && wv)) return;
+    if (!IDENT) reinterpret_cast<u32 *>(slut)[HGI_LANE] = lut.w[HGI_LANE];      // (pair build: both waves write the same table)
     if (!role.edge) {
-        TileCtx cur = fast_ctx(role.index, src, dst, f, g, (aligned & 4u) ? 3u : 0u, WREC ? rec : nullptr);
+        TileCtx cur = fast_ctx(role.index, src, dst, f, g, (aligned & 4u) ? 3u : 0u, WREC ? rec : nullptr, wv);
         Stage st;
         SeedRegs seeds;
         HGI_MARK("stage_issue");
         HGI_TL_START();
-        stage_issue<false>(st, cur.b, cur.tl, (int)k, nh);
+        stage_issue<false>(st, cur.b, cur.tl, (int)k, nh, wv);
         if (SEEDED) seeds = seed_issue<true>(sd, cur.tl, k);
         HGI_MARK("stage_commit");
-        stage_commit<true>(buf, rbuf, st, nh);
+        stage_commit<true>(buf, rbuf, st, nh, HGI_PAIR && wv == 0);
         LDS_ORDER();
+        if (HGI_PAIR) {
+            if (wv) pair_push_column<true>(buf, smem + 256 - HCOL, smem + 256 + buf_bytes(nh) - RCOL, nh);
+            __syncthreads();
+        }
         HGI_TL_STAGED();
         enc_seed_commit<SEEDED>(buf, rbuf, seeds, k);
         enc_tile_fast<INTERP, IDENT, WREC>(buf, rbuf, slut, cur, st.o, k, W, H);
@@ -1701,10 +1778,11 @@ hipError_t HGI_TILED(launch_decode_fused)(const uint8_t *grid, uint8_t *img, con
     const TileGrid &g = r.g;
     if (seeds && k < (uint32_t)kSeededMinLevels) return hipErrorInvalidValue;      // one lane per lattice point (seed_issue)
     Seeds sd = seeds ? *seeds : Seeds{nullptr, nullptr, 0, 0, 0};
-    const dim3 b(NL);
+    const dim3 b(NL * NWAVES);
     const int nh = k >= 2 ? (int)k : 1;
-    const size_t lds = (size_t)buf_bytes(nh);
-    const dim3 blocks(((g.nedge + 7u) & ~7u) + g.nfast);
+    const size_t lds = (size_t)buf_bytes(nh) * NWAVES;
+    if (HGI_PAIR && (g.full_x & 1u)) return hipErrorInvalidValue;      // the experiment build pairs x-adjacent interior tiles
+    const dim3 blocks(((g.nedge + 7u) & ~7u) + g.nfast / NWAVES);
 #define HGI_DEC(I, SE) hipLaunchKernelGGL((k_dec_tiles<I, SE, TH>), blocks, b, lds, s, grid, img, f, k, sd, g, r.aligned)
     if (interp == kInterpCrossed) {
         if (seeds) HGI_DEC(kInterpCrossed, true); else HGI_DEC(kInterpCrossed, false);
@@ -1739,10 +1817,11 @@ hipError_t HGI_TILED(launch_encode_fused)(const uint8_t *img, uint8_t *grid, con
     const TileGrid &g = r.g;
     if (seeds && k < (uint32_t)kSeededMinLevels) return hipErrorInvalidValue;      // one lane per lattice point (seed_issue)
     Seeds sd = seeds ? *seeds : Seeds{nullptr, nullptr, 0, 0, 0};
-    const dim3 b(NL);
+    const dim3 b(NL * NWAVES);
     const int nh = k >= 2 ? (int)k : 1;
-    const size_t lds = (size_t)buf_bytes(nh) + rbuf_bytes(nh) + 256;
-    const dim3 blocks(((g.nedge + 7u) & ~7u) + g.nfast);
+    const size_t lds = ((size_t)buf_bytes(nh) + ((rbuf_bytes(nh) + 15) & ~15)) * NWAVES + 256;
+    if (HGI_PAIR && (g.full_x & 1u)) return hipErrorInvalidValue;      // the experiment build pairs x-adjacent interior tiles
+    const dim3 blocks(((g.nedge + 7u) & ~7u) + g.nfast / NWAVES);
     // lut_at() addresses the table from LDS offset 0: only valid while the kernel has no static LDS in front of its
     // dynamic segment.  Checked once per instantiation on the host; a build that breaks it fails here, not on the device.
 #define HGI_ENC(I, ID, SE)                                                                                        \

@@ -11,12 +11,14 @@ namespace hgi {
 constexpr int kInterpLeftTop = 0;
 constexpr int kInterpCrossed = 1;
 
-// Fused tile geometry (see DESIGN.md "Kernels").  Two builds of the same source live in the library:
-// 128 x 64 tiles (throughput: batches, large frames) and 128 x 32 tiles (latency: four times the waves and
-// half the chain per wave when a call has too few tiles to fill the GPU).  hgi_capi.hip picks per call.
+// Fused tile geometry (see DESIGN.md "Kernels").  Three builds of the same source live in the library:
+// 128 x 64 tiles (throughput: batches, large frames), 128 x 32 tiles (latency: four times the waves and
+// half the chain per wave when a call has too few tiles to fill the GPU) and 128 x 16 tiles (single small frames:
+// the launch ends when its slowest wave does).  hgi_capi.hip picks per call.
 constexpr int kTileW = 128;   // pixels per tile row: 8 lanes x 16 B = one 128-B line
 constexpr int kFusedMaxLevels = 6;        // 2^k <= 64: deepest pyramid a 64-row tile can hold
-constexpr int kFusedMaxLevelsSmall = 5;   // ... and a 32-row tile
+constexpr int kFusedMaxLevelsSmall = 5;   // ... a 32-row tile
+constexpr int kFusedMaxLevelsTiny = 4;    // ... and a 16-row tile
 constexpr int kSeededMinLevels = 4;       // a seeded launch gives each lattice point of a tile's halo frame a lane: (128 >> k) + 2 by (64 >> k) + 2 <= 64
 constexpr int kThreads = 64;  // ONE wave owns a tile: no workgroup barriers anywhere
 
@@ -65,6 +67,7 @@ hipError_t launch_encode_level(uint8_t *rec, uint8_t *grid, const Frames &f, uin
                                         uint32_t row_limit, uint8_t *rec_out);
 HGI_DECLARE_FUSED(64)
 HGI_DECLARE_FUSED(32)
+HGI_DECLARE_FUSED(16)
 #undef HGI_DECLARE_FUSED
 
 // dst[f][j][i] = src[f][j << k][i << k]  (the stride-2^k lattice as a dense plane)

@@ -583,14 +583,14 @@ def test_hip_graph_capture_and_replay(H, ctxs, oracle):
     ctx.close()
 
 
-@pytest.mark.parametrize("mode", ["HGI_FORCE_CHECKED=1", "HGI_TILE_H=64", "HGI_TILE_H=32", "HGI_NO_LATTICE_KERNEL=1",
+@pytest.mark.parametrize("mode", ["HGI_FORCE_CHECKED=1", "HGI_TILE_H=64", "HGI_TILE_H=32", "HGI_TILE_H=16", "HGI_NO_LATTICE_KERNEL=1",
                                   "HGI_NO_LATTICE_KERNEL=1,HGI_NO_ENC_REC=1", "HGI_DEC_REVERSE=1",
                                   "HGI_DEEP_K_ENC=4,HGI_DEEP_K_DEC=4", "HGI_DEEP_K_ENC=5,HGI_DEEP_K_DEC=5"])
 def test_forced_code_paths_in_a_child_process(mode):
-    """The library picks tile geometry and code path per launch: 128x32 or 128x64 tiles, and the fully checked path only
+    """The library picks tile geometry and code path per launch: 128x16, 128x32 or 128x64 tiles, and the fully checked path only
     for widths that are not multiples of 4 or frames beyond 32-bit offsets.  Each switch is read once per process, so a
     child process re-runs the shape-heavy parity cases with one of them forced: aligned shapes through the checked
-    path, small shapes through 64-row tiles, large ones through 32-row tiles, deep pyramids through the host recursion
+    path, small shapes through 64-row tiles, large ones through 32-row and (pyramids up to four levels) 16-row tiles, deep pyramids through the host recursion
     instead of the one-workgroup lattice kernel -- with the lattice plane's encoder writing its reconstruction itself
     (one launch) and with the older encode-then-decode chain (HGI_NO_ENC_REC) --, the decoder walking its tile list
     backwards, and deep pyramids split at four or five levels instead of six (what a lone 16384^2 encode does by itself;

@@ -40,7 +40,11 @@ print("planes separated:", bool(sep.value), " %d x %dx%d levels %d quant %d" % (
 lut = np.zeros(256, np.uint8); err = np.zeros(1, np.uint8)
 assert L0.hgi_linear_lut(QUANT, lut.ctypes.data, err.ctypes.data) == 0
 assert L0.hgi_synth_u8_dev(h0, _ffi.SYNTH_RAMP, 0x48474930 + 3, 0, W, Hh, img, NF, W * Hh) == 0
+class _Arr:
+    def __init__(self, ptr, nbytes):
+        self.__cuda_array_interface__ = {"shape": (int(nbytes),), "typestr": "|u1", "data": (int(ptr), False), "version": 2, "strides": None}
 res = {v: ([], []) for v in variants}
+ref_sum = None      # every build must produce the first build's bytes (cheap fingerprint: strided samples of grid and output)
 for rnd in range(rounds):
     for v in variants:
         L, h = libs[v]
@@ -53,6 +57,11 @@ for rnd in range(rounds):
             assert L.hgi_decode_u8_dev(h, grid, W, Hh, LEVELS, 1, out, NF, W * Hh) == 0
             e[2].record()
         torch.cuda.synchronize()
+        if rnd == 0:
+            gt = torch.as_tensor(_Arr(grid, n), device="cuda"); ot = torch.as_tensor(_Arr(out, n), device="cuda")
+            fp = (int(gt[::257].to(torch.int64).sum()), int(ot[::263].to(torch.int64).sum()), int(gt[-4096:].to(torch.int64).sum()))
+            if ref_sum is None: ref_sum = fp
+            print("variant[%-6s] fingerprint %s %s" % (v, fp, "(same bytes)" if fp == ref_sum else "*** DIFFERENT BYTES ***"))
         res[v][0].append(float(np.mean([e[0].elapsed_time(e[1]) for e in ev])))
         res[v][1].append(float(np.mean([e[1].elapsed_time(e[2]) for e in ev])))
 base = None
