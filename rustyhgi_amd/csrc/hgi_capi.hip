@@ -44,7 +44,7 @@ hgi_status fail(hgi_status st, const char *fmt, ...)
 inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 #ifndef HGI_TILE16_MAX_DEFAULT
-#define HGI_TILE16_MAX_DEFAULT 0      // 32-row tiles of a call at or below which 16-row tiles run instead (0: never; set from measurement)
+#define HGI_TILE16_MAX_DEFAULT 600    // an ENCODE of at most this many 32-row tiles runs on 16-row tiles instead (profiles/r03_sizes.txt: 1920 x 1080 is 510)
 #endif
 
 }  // namespace
@@ -164,7 +164,7 @@ size_t ws_need(const hgi_ctx *c, uint32_t w, uint32_t h, uint32_t levels, size_t
 // waves per CU of 32-row tiles) ends when its slowest wave does, and that wave's chain is mostly its own VALU work:
 // 128 x 16 tiles halve the finest level's share of it (profiles/r03_sizes.txt).  HGI_TILE_H=16|32|64 in the
 // environment forces one where the pyramid fits (experiments, tests); HGI_TILE16_MAX moves the lower crossover.
-uint32_t use_tile_rows(uint32_t w, uint32_t h, uint32_t k, size_t batch)
+uint32_t use_tile_rows(uint32_t w, uint32_t h, uint32_t k, size_t batch, bool encode)
 {
     static const int forced = [] {
         const char *e = getenv("HGI_TILE_H");
@@ -181,7 +181,7 @@ uint32_t use_tile_rows(uint32_t w, uint32_t h, uint32_t k, size_t batch)
     if (forced == 64) return 64;
     const uint64_t tx = (w + kTileW - 1) / kTileW;
     const uint64_t tiles64 = tx * ((h + 63) / 64) * batch, tiles32 = tx * ((h + 31) / 32) * batch;
-    if (fits16 && tiles32 <= tiny_max) return 16;
+    if (encode && fits16 && tiles32 <= tiny_max) return 16;      // (decode sits on the launch floor with 32-row tiles already)
     return tiles64 < 1536 ? 32 : 64;
 }
 
@@ -197,7 +197,7 @@ hipError_t launch_encode_fused(const uint8_t *img, uint8_t *grid, const Frames &
                                const Lut256 &lut, bool ident, const Seeds *seeds, hipStream_t s, uint32_t row_limit = 0, uint8_t *rec_out = nullptr)
 {
     const uint32_t rows = row_limit && row_limit < f.height ? row_limit : f.height;   // what this launch really covers
-    switch (use_tile_rows(f.width, rows, k, f.batch)) {
+    switch (use_tile_rows(f.width, rows, k, f.batch, true)) {
     case 16: return launch_encode_fused_16(img, grid, f, k, interp, lut, ident, seeds, s, row_limit, rec_out);
     case 32: return launch_encode_fused_32(img, grid, f, k, interp, lut, ident, seeds, s, row_limit, rec_out);
     default: return launch_encode_fused_64(img, grid, f, k, interp, lut, ident, seeds, s, row_limit, rec_out);
@@ -208,7 +208,7 @@ hipError_t launch_decode_fused(const uint8_t *grid, uint8_t *img, const Frames &
                                const Seeds *seeds, hipStream_t s, uint32_t row_limit = 0)
 {
     const uint32_t rows = row_limit && row_limit < f.height ? row_limit : f.height;
-    switch (use_tile_rows(f.width, rows, k, f.batch)) {
+    switch (use_tile_rows(f.width, rows, k, f.batch, false)) {
     case 16: return launch_decode_fused_16(grid, img, f, k, interp, seeds, s, row_limit);
     case 32: return launch_decode_fused_32(grid, img, f, k, interp, seeds, s, row_limit);
     default: return launch_decode_fused_64(grid, img, f, k, interp, seeds, s, row_limit);

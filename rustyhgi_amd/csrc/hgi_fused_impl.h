@@ -791,6 +791,7 @@ struct Stage {
     v4u hv;             // halo rows TH + {0,4,8,..}: full lines
     v3u x0;             // halo columns: one lane per (even) row; this 12-B load holds offsets 0/4/8
     u32 d16, d32, d64;  // ... and single dwords supply offsets 16/32/64
+    bool zero4, zero8;  // wave-uniform: column offsets 4 / 8 lie beyond the image (their bytes of x0 are cleared at commit)
 };
 
 // Rows below the image return 0 from the buffer range check; columns right of the image are masked
@@ -847,10 +848,13 @@ __device__ __forceinline__ void stage_issue(Stage &st, const Buf &b, Tile tl, in
     const u32 xr = tl.X0 + TW;              // first column right of the tile
     st.x0 = v3u{0, 0, 0};
     st.d16 = st.d32 = st.d64 = 0;
+    st.zero4 = st.zero8 = false;
     if (!(HGI_ABL & 16) && !skip_col && lane < TH / 2 + nh) {
         if (xr < W) st.x0 = __builtin_amdgcn_raw_buffer_load_b96(b.rs, xo, 0, 0);
-        if (xr + 4 >= W) st.x0.y = 0;    // offsets 4 / 8 can lie beyond the image when the width is not a multiple of 16
-        if (xr + 8 >= W) st.x0.z = 0;
+        // offsets 4 / 8 can lie beyond the image when the width is not a multiple of 16: cleared when the column is
+        // committed (stage_commit), not here -- touching the loaded registers now would wait for every load issued so far
+        st.zero4 = xr + 4 >= W;
+        st.zero8 = xr + 8 >= W;
         // Column offset `off` is only ever touched on rows = 0 (mod off): level off / 2 reads it as a corner of the
         // halo cells (rows = 0 mod step = off), level off codes it (rows = 0 mod s = off).  The other lanes do not
         // fetch that line at all.
@@ -895,7 +899,7 @@ __device__ __forceinline__ void stage_commit(u8 *buf, u8 *rbuf, const Stage &st,
     }
     if (!skip_col && lane < TH / 2 + nh) {
         // transposed halo columns: slot {0..5} <- offsets {0, 4, 8, 16, 32, 64}, one byte per LDS row
-        const u32 v[HR] = {st.x0.x, st.x0.y, st.x0.z, st.d16, st.d32, st.d64};
+        const u32 v[HR] = {st.x0.x, st.zero4 ? 0u : st.x0.y, st.zero8 ? 0u : st.x0.z, st.d16, st.d32, st.d64};
         u8 *h = buf + HCOL + lane, *h2 = rbuf + RCOL + lane;
 #pragma unroll
         for (int i = 0; i < HR; ++i) {
@@ -1258,6 +1262,7 @@ struct TileGrid {
     u32 full_x, full_y;     // tiles whose body is inside the image (0 x 0 when the fast path is off)
     u32 nfast, nedge;       // totals over the batch
     u32 reverse;            // walk the interior tile list backwards (speed only: see launch_decode_fused)
+    u32 band;               // tile rows per band of the column-major walk (fast_tile)
 #ifdef HGI_TIMELINE
     u64 *timeline;          // experiment builds (tools/timeline.py): eight u64 per block -- start, staged, end, hardware id, entry
 #endif
@@ -1294,7 +1299,7 @@ __device__ __forceinline__ Tile fast_tile(u32 t, const TileGrid &gg, u32 wv = 0)
     // Bands of HGI_TILE_BAND tile rows, column-major inside a band: x-neighbours are dispatched `rows` tiles apart,
     // y-neighbours next to each other.  The last band of a frame takes the rows that are left.
     {
-        constexpr u32 R = HGI_TILE_BAND;
+        const u32 R = g.band;      // tile rows per band (host policy: band_rows())
         const u32 per = R * g.full_x, nfull = (g.full_y / R) * per;
         u32 rows = R, row0, r;
         if (tt < nfull) {
@@ -1654,7 +1659,11 @@ __global__ __launch_bounds__(NL * NWAVES) __attribute__((amdgpu_waves_per_eu(IDE
     const BlockRole role = block_role(g);
 #endif
     if (role.idle || (HGI_PAIR && role.edge && wv)) return;
-    if (!IDENT) reinterpret_cast<u32 *>(slut)[HGI_LANE] = lut.w[HGI_LANE];      // (pair build: both waves write the same table)
+    // The table entry of this lane is a VECTOR load from the kernel-argument segment (the index is the lane): a trip to L2
+    // or beyond.  Done first, the whole prologue stalled on it (the timeline build showed 1.4-1.8 us of prologue per
+    // encode tile against 0.5-0.7 for decode: tools/timeline.py).  It is issued BEHIND the tile's staging loads instead
+    // and lands with them -- the table is first needed after staging has been committed to LDS anyway.
+    u32 lutv = 0;
     if (!role.edge) {
         TileCtx cur = fast_ctx(role.index, src, dst, f, g, (aligned & 4u) ? 3u : 0u, WREC ? rec : nullptr, wv);
         Stage st;
@@ -1663,8 +1672,10 @@ __global__ __launch_bounds__(NL * NWAVES) __attribute__((amdgpu_waves_per_eu(IDE
         HGI_TL_START();
         stage_issue<false>(st, cur.b, cur.tl, (int)k, nh, wv);
         if (SEEDED) seeds = seed_issue<true>(sd, cur.tl, k);
+        if (!IDENT) lutv = lut.w[HGI_LANE];      // (pair build: both waves write the same table)
         HGI_MARK("stage_commit");
         stage_commit<true>(buf, rbuf, st, nh, HGI_PAIR && wv == 0);
+        if (!IDENT) reinterpret_cast<u32 *>(slut)[HGI_LANE] = lutv;
         LDS_ORDER();
         if (HGI_PAIR) {
             if (wv) pair_push_column<true>(buf, smem + 256 - HCOL, smem + 256 + buf_bytes(nh) - RCOL, nh);
@@ -1686,7 +1697,9 @@ __global__ __launch_bounds__(NL * NWAVES) __attribute__((amdgpu_waves_per_eu(IDE
         TileCtx cur = {tl, make_buf(fr, out, W, H, tl, (aligned & 4u) ? 3u : 0u, WREC ? rec + (size_t)tl.frame * f.frame_stride : nullptr)};
         Stage st;
         stage_issue<true, true>(st, cur.b, tl, (int)k, nh);
+        if (!IDENT) lutv = lut.w[HGI_LANE];
         stage_commit<true>(buf, rbuf, st, nh);
+        if (!IDENT) reinterpret_cast<u32 *>(slut)[HGI_LANE] = lutv;
         LDS_ORDER();
         enc_seed_commit<SEEDED>(buf, rbuf, seeds, k);
         if (tl.X0 + TW <= W && !(H & 1u))
@@ -1695,6 +1708,7 @@ __global__ __launch_bounds__(NL * NWAVES) __attribute__((amdgpu_waves_per_eu(IDE
             enc_tile_edge<INTERP, IDENT, 2, WREC>(buf, rbuf, slut, cur, st.o, k, W, H);
         return;
     }
+    if (!IDENT) reinterpret_cast<u32 *>(slut)[HGI_LANE] = lut.w[HGI_LANE];
     stage_tile_generic(buf, fr, W, H, tl, nh, (aligned & 1u) != 0);
     LDS_ORDER();
     lattice_from_buf(buf, rbuf, nh);
@@ -1749,6 +1763,7 @@ FusedGeom fused_geom(const void *a, const void *b, const Frames &f, u32 row_limi
     g.nfast = (u32)nfast;
     g.nedge = (u32)(all - nfast);
     g.reverse = 0;
+    g.band = HGI_TILE_BAND;
     // bit 0: 16-B aligned rows and pointers (vector accesses of the byte-checked path); bit 1: check-free paths allowed
     // (32-bit buffer offsets); bit 2: read descriptors carry 3 extra records (rows not a multiple of 4 bytes)
     r.aligned = (aligned ? 1u : 0u) | (fast ? 2u : 0u) | (fast && !dword_rows ? 4u : 0u);
@@ -1756,6 +1771,21 @@ FusedGeom fused_geom(const void *a, const void *b, const Frames &f, u32 row_limi
     g.timeline = g_timeline;
 #endif
     return r;
+}
+
+// Tile rows per band of the interior walk.  A band is walked column-major, so the tiles in flight at one moment span
+// `rows * TH` image rows of a few tile columns: rows * TH * W bytes of address space.  Measured (tools/ab.py,
+// profiles/r03_ab_c4_order.txt, r03_band_sweep.txt): on 4096-wide frames the decoder is indifferent between 4 and 16 and
+// the encoder wants 4; on a 16384-wide frame a decode in 8-row bands is 15 % slower than in 4-row bands (135 -> 114 us
+// for 16384^2 -- what round 2 took for a read-after-write penalty), so bands are capped at 4 MiB of address space.
+// HGI_ENC_BAND / HGI_DEC_BAND in the environment force a height (experiments).
+inline u32 band_rows(const Frames &f, bool encode)
+{
+    static const int forced[2] = {getenv("HGI_DEC_BAND") ? atoi(getenv("HGI_DEC_BAND")) : 0, getenv("HGI_ENC_BAND") ? atoi(getenv("HGI_ENC_BAND")) : 0};
+    if (forced[encode ? 1 : 0] > 0) return (u32)forced[encode ? 1 : 0];
+    u32 rows = HGI_TILE_BAND;
+    while (rows > 1 && (u64)rows * TH * f.width > (4u << 20)) rows >>= 1;
+    return rows;
 }
 
 }  // namespace
@@ -1775,6 +1805,7 @@ hipError_t HGI_TILED(launch_decode_fused)(const uint8_t *grid, uint8_t *img, con
         return e ? atoi(e) : HGI_DEC_REVERSE_DEFAULT;
     }();
     r.g.reverse = dec_reverse ? 1u : 0u;
+    r.g.band = band_rows(f, false);
     const TileGrid &g = r.g;
     if (seeds && k < (uint32_t)kSeededMinLevels) return hipErrorInvalidValue;      // one lane per lattice point (seed_issue)
     Seeds sd = seeds ? *seeds : Seeds{nullptr, nullptr, 0, 0, 0};
@@ -1814,6 +1845,7 @@ hipError_t HGI_TILED(launch_encode_fused)(const uint8_t *img, uint8_t *grid, con
     // the reconstruction output exists on the check-free paths only (and never under seeds): the caller falls back to
     // decoding the grid it just made
     if (rec_out && (seeds || !(r.aligned & 2u))) return hipErrorNotSupported;
+    r.g.band = band_rows(f, true);
     const TileGrid &g = r.g;
     if (seeds && k < (uint32_t)kSeededMinLevels) return hipErrorInvalidValue;      // one lane per lattice point (seed_issue)
     Seeds sd = seeds ? *seeds : Seeds{nullptr, nullptr, 0, 0, 0};
