@@ -307,6 +307,14 @@ hgi_status decode_impl(hgi_ctx *c, const uint8_t *grid, uint32_t w, uint32_t h, 
     const uint32_t k = fused_depth(w, h, levels, false);
     if (levels > k) {
         SubGeom g = sub_geom(w, h, k);
+        // one or two levels above a 64-row tile's six: the tile kernel rebuilds its seeds from the grid itself -- no plane,
+        // no launch in front of it (hgi_fused_impl.h, inline_seed_*).  HGI_NO_INLINE_SEEDS keeps the planes (tests).
+        static const bool no_inline = getenv("HGI_NO_INLINE_SEEDS") != nullptr;
+        if (k == (uint32_t)kFusedMaxLevels && levels - k <= 2 && !no_inline) {
+            Seeds sd = {nullptr, nullptr, g.sw, g.sh, (uint64_t)(levels - k)};
+            HIP_TRY(launch_decode_fused(grid, img, f, k, interp, &sd, c->stream));
+            return HGI_OK;
+        }
         uint8_t *sub_grid = ws_take(c, batch * g.stride);
         uint8_t *sub_rec = ws_take(c, batch * g.stride);
         if (!sub_grid || !sub_rec) return fail(HGI_ENOMEM, "scratch exhausted (lattice planes)");

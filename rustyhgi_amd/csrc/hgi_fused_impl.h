@@ -115,6 +115,9 @@ static_assert(TH != 64 || 18 * (buf_bytes(4) + rbuf_bytes(4) + 256) <= 160 * 102
 #define HGI_ABL 0   // timing experiments: 1 no coarse levels, 2 no fine arithmetic, 4 no halo cells, 8 no sub==2 level,
                     // 16 no halo-column loads, 32 no halo-row loads
 #endif
+#ifndef HGI_XCD_MODE
+#define HGI_XCD_MODE 0
+#endif
 #ifndef HGI_DEC_REVERSE_DEFAULT
 #define HGI_DEC_REVERSE_DEFAULT 0
 #endif
@@ -1402,6 +1405,68 @@ __device__ __forceinline__ void dec_seed_commit(u8 *buf, const SeedRegs &r, u32 
     LDS_ORDER();
 }
 
+// ---- decode, seeds computed in the tile kernel itself (k = 6, at most two levels above it) -------------------------
+// A pyramid of 7 or 8 levels has one or two levels above a 64-row tile's six.  Their pixels are the stride-64 lattice, a
+// sw x sh plane with `up` = levels - 6 levels of its own, and a tile needs the reconstruction of 4 x 3 of its points.
+// Instead of coding that plane in launches of its own first (gather, decode: 9 us in front of a 16384^2 decode), every
+// wave rebuilds the few points it needs from the grid: the 5 x 5 patch of even/even plane points around its seeds (base
+// samples and, for up = 2, the level with step 4), then the seeds themselves.  Corners travel between lanes through the
+// LDS crossbar (ds_bpermute); nothing is exchanged between tiles -- neighbouring tiles recompute the same values, which
+// are pure functions of the grid (src/decoder.rs:30-44).  The loads go out with the tile's own staging loads.
+struct InlineSeeds {
+    u32 gv, gs;      // grid bytes: this lane's patch point / this lane's seed point
+};
+
+__device__ __forceinline__ u32 grid_at(const u8 *__restrict__ fr, u32 W, u32 H, u32 px, u32 py)
+{
+    const u64 x = (u64)px << 6, y = (u64)py << 6;       // plane point (px, py) is image pixel (64 px, 64 py)
+    return (x < W && y < H) ? fr[y * W + x] : 0u;
+}
+
+__device__ __forceinline__ InlineSeeds inline_seed_issue(const u8 *__restrict__ fr, u32 W, u32 H, Tile tl, u32 up)
+{
+    const u32 lane = HGI_LANE, bm = (1u << up) - 1u;
+    const u32 px0 = tl.X0 >> 6, py0 = tl.Y0 >> 6, ax = px0 & ~bm, ay = py0 & ~bm;
+    InlineSeeds s;
+    s.gv = lane < 25u ? grid_at(fr, W, H, ax + 2u * (lane % 5u), ay + 2u * (lane / 5u)) : 0u;
+    s.gs = lane < 12u ? grid_at(fr, W, H, px0 + (lane & 3u), py0 + (lane >> 2)) : 0u;
+    return s;
+}
+
+__device__ __forceinline__ u32 lane_value(u32 v, u32 from) { return (u32)__builtin_amdgcn_ds_bpermute((int)(from << 2), (int)v); }
+
+template <int INTERP>
+__device__ __forceinline__ SeedRegs inline_seed_finish(const InlineSeeds &s, Tile tl, u32 up, u32 sw, u32 sh)
+{
+    const u32 lane = HGI_LANE, bm = (1u << up) - 1u;
+    const u32 px0 = tl.X0 >> 6, py0 = tl.Y0 >> 6, ax = px0 & ~bm, ay = py0 & ~bm;
+    // the patch: lane l < 25 holds plane point (ax + 2 (l % 5), ay + 2 (l / 5)); points outside the plane read 0
+    const u32 ix = lane % 5u, iy = lane / 5u, mx = ax + 2u * ix, my = ay + 2u * iy;
+    const bool in_patch = lane < 25u && mx < sw && my < sh;
+    u32 rec0 = in_patch ? s.gv : 0u;
+    if (up == 2) {      // level with step 4 (sub 2): points even/even, not both = 0 mod 4; corners = base points of the patch
+        const u32 cx = (mx & ~3u) - ax, cy = (my & ~3u) - ay;                    // cell origin relative to the patch: 0 or 4 (or 8)
+        const u32 jx = cx >> 1, jy = cy >> 1, j0 = jy * 5u + jx;                  // its patch index; the far corners are 2 further
+        const u32 lt = lane_value(rec0, j0), rt = lane_value(rec0, j0 + 10u), lb = lane_value(rec0, j0 + 2u), rb = lane_value(rec0, j0 + 12u);
+        const u32 p = pred1<INTERP>(lt, rt, lb, rb);
+        const bool base = !((mx | my) & 3u);
+        rec0 = in_patch ? (base ? s.gv : ((p + s.gv) & 255u)) : 0u;
+    }
+    // the seeds: lane i < 12 is plane point (px0 + i % 4, py0 + i / 4) -- seed_issue()'s layout at k = 6
+    SeedRegs r;
+    r.bx = (int)(lane & 3u);
+    r.by = (int)(lane >> 2);
+    r.on = lane < 12u;
+    r.q = 0;
+    const u32 sx = px0 + (lane & 3u), sy = py0 + (lane >> 2);
+    const u32 ox = ((sx & ~1u) - ax) >> 1, oy = ((sy & ~1u) - ay) >> 1, o0 = (oy * 5u + ox) & 63u;
+    const u32 lt = lane_value(rec0, o0), rt = lane_value(rec0, (o0 + 5u) & 63u), lb = lane_value(rec0, (o0 + 1u) & 63u), rb = lane_value(rec0, (o0 + 6u) & 63u);
+    const u32 p = pred1<INTERP>(lt, rt, lb, rb);
+    const bool even = !((sx | sy) & 1u), inside = sx < sw && sy < sh;
+    r.rec = (r.on && inside) ? (even ? lt : ((p + s.gs) & 255u)) : 0u;
+    return r;
+}
+
 // One tile of the fast path, out of LDS: levels sub = 2^(k-1) .. 2 in place, then the finest level to HBM.
 template <int INTERP>
 __device__ __forceinline__ void dec_tile_fast(u8 *buf, const TileCtx &cur, const v4u (&odd)[NFINE], u32 k, u32 W, u32 H)
@@ -1483,13 +1548,28 @@ __device__ __forceinline__ BlockRole block_role(const TileGrid &g)
     r.idle = r.edge && b >= g.nedge;
     const u32 fb = b - ne8;
     r.index = r.edge ? b : range_first(HGI_PAIR ? g.nfast >> 1 : g.nfast, fb & 7u) + (fb >> 3);
+#if HGI_XCD_MODE
+    // Experiments (tile order): which tiles the eight XCDs work on at one time.  0 (shipped): each XCD walks
+    // its own contiguous eighth of the band-ordered list -- eight places of the frame an eighth of it apart.  1: bands dealt
+    // round-robin -- eight CONSECUTIVE bands.  2: every band cut into eight column strips -- ONE band at a time.
+    if (!r.edge && !HGI_PAIR && g.full_y % g.band == 0) {
+        const u32 P = g.band * g.full_x, nb = g.nfast / P, x = fb & 7u, sq = fb >> 3;
+        if (HGI_XCD_MODE == 1 && nb % 8u == 0) r.index = ((sq / P) * 8u + x) * P + sq % P;
+        if (HGI_XCD_MODE == 2 && g.full_x % 8u == 0) {
+            const u32 cw = g.full_x / 8u, per = g.band * cw, band = sq / per, rem = sq - band * per;
+            r.index = band * P + (x * cw) * g.band + rem;
+        }
+    }
+#endif
     return r;
 }
 
 #ifndef HGI_DEC_WAVES_PER_EU
 #define HGI_DEC_WAVES_PER_EU 8
 #endif
-template <int INTERP, bool SEEDED, int TILE_ROWS>   // TILE_ROWS == TH: only there to name the build in profiles
+// SEEDED: 0 = the pyramid fits the tile; 1 = seeds from planes coded by earlier launches; 2 = seeds rebuilt in the kernel
+// (k == 6 and at most two levels above: sd.sw x sd.sh is the stride-64 plane, sd.stride carries `up`)
+template <int INTERP, int SEEDED, int TILE_ROWS>   // TILE_ROWS == TH: only there to name the build in profiles
 __global__ __launch_bounds__(NL * NWAVES) __attribute__((amdgpu_waves_per_eu(HGI_DEC_WAVES_PER_EU))) void k_dec_tiles(const u8 *__restrict__ src, u8 *__restrict__ dst, Frames f, u32 k,
                                                   Seeds sd, TileGrid g, u32 aligned)
 {
@@ -1516,9 +1596,12 @@ __global__ __launch_bounds__(NL * NWAVES) __attribute__((amdgpu_waves_per_eu(HGI
         HGI_MARK("stage_issue");
         HGI_TL_START();
         stage_issue<false>(st, cur.b, cur.tl, (int)k, nh, wv);
-        if (SEEDED) seeds = seed_issue<false>(sd, cur.tl, k);
+        InlineSeeds il = {0, 0};
+        if (SEEDED == 1) seeds = seed_issue<false>(sd, cur.tl, k);
+        if (SEEDED == 2) il = inline_seed_issue(src + (size_t)cur.tl.frame * f.frame_stride, W, H, cur.tl, (u32)sd.stride);
         HGI_MARK("stage_commit");
         stage_commit<false>(buf, nullptr, st, nh, HGI_PAIR && wv == 0);
+        if (SEEDED == 2) seeds = inline_seed_finish<INTERP>(il, cur.tl, (u32)sd.stride, sd.sw, sd.sh);
         LDS_ORDER();
         if (HGI_PAIR) {
             if (wv) pair_push_column<false>(buf, smem - HCOL, nullptr, nh);
@@ -1536,7 +1619,8 @@ __global__ __launch_bounds__(NL * NWAVES) __attribute__((amdgpu_waves_per_eu(HGI
     const u8 *fr = src + (size_t)tl.frame * f.frame_stride;
     u8 *out = dst + (size_t)tl.frame * f.frame_stride;
     SeedRegs seeds;
-    if (SEEDED) seeds = seed_issue<false>(sd, tl, k);
+    if (SEEDED == 1) seeds = seed_issue<false>(sd, tl, k);
+    if (SEEDED == 2) seeds = inline_seed_finish<INTERP>(inline_seed_issue(fr, W, H, tl, (u32)sd.stride), tl, (u32)sd.stride, sd.sw, sd.sh);
     if (aligned & 2u) {   // 32-bit buffer offsets: buffer staging and the check-free levels with edge masks
         TileCtx cur = {tl, make_buf(fr, out, W, H, tl, (aligned & 4u) ? 3u : 0u)};
         Stage st;
@@ -1809,17 +1893,23 @@ hipError_t HGI_TILED(launch_decode_fused)(const uint8_t *grid, uint8_t *img, con
     const TileGrid &g = r.g;
     if (seeds && k < (uint32_t)kSeededMinLevels) return hipErrorInvalidValue;      // one lane per lattice point (seed_issue)
     Seeds sd = seeds ? *seeds : Seeds{nullptr, nullptr, 0, 0, 0};
+    // seeds without planes: the kernel rebuilds them from the grid (inline_seed_*): six fused levels, one or two above them
+    const bool inline_seeds = seeds && !seeds->rec;
+    if (inline_seeds && (TH != 64 || k != 6 || sd.stride < 1 || sd.stride > 2)) return hipErrorInvalidValue;
     const dim3 b(NL * NWAVES);
     const int nh = k >= 2 ? (int)k : 1;
     const size_t lds = (size_t)buf_bytes(nh) * NWAVES;
     if (HGI_PAIR && (g.full_x & 1u)) return hipErrorInvalidValue;      // the experiment build pairs x-adjacent interior tiles
     const dim3 blocks(((g.nedge + 7u) & ~7u) + g.nfast / NWAVES);
 #define HGI_DEC(I, SE) hipLaunchKernelGGL((k_dec_tiles<I, SE, TH>), blocks, b, lds, s, grid, img, f, k, sd, g, r.aligned)
-    if (interp == kInterpCrossed) {
-        if (seeds) HGI_DEC(kInterpCrossed, true); else HGI_DEC(kInterpCrossed, false);
-    } else {
-        if (seeds) HGI_DEC(kInterpLeftTop, true); else HGI_DEC(kInterpLeftTop, false);
-    }
+#define HGI_DEC_I(I)                                                     \
+    do {                                                                 \
+        if (!seeds) HGI_DEC(I, 0);                                       \
+        else if (!inline_seeds) HGI_DEC(I, 1);                           \
+        else if (TH == 64) HGI_DEC(I, (TH == 64 ? 2 : 1));               \
+    } while (0)
+    if (interp == kInterpCrossed) HGI_DEC_I(kInterpCrossed); else HGI_DEC_I(kInterpLeftTop);
+#undef HGI_DEC_I
 #undef HGI_DEC
     return hipGetLastError();
 }

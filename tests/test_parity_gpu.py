@@ -584,7 +584,8 @@ def test_hip_graph_capture_and_replay(H, ctxs, oracle):
 
 
 @pytest.mark.parametrize("mode", ["HGI_FORCE_CHECKED=1", "HGI_TILE_H=64", "HGI_TILE_H=32", "HGI_TILE_H=16", "HGI_NO_LATTICE_KERNEL=1",
-                                  "HGI_NO_LATTICE_KERNEL=1,HGI_NO_ENC_REC=1", "HGI_DEC_REVERSE=1",
+                                  "HGI_NO_LATTICE_KERNEL=1,HGI_NO_ENC_REC=1", "HGI_DEC_REVERSE=1", "HGI_NO_INLINE_SEEDS=1",
+                                  "HGI_NO_INLINE_SEEDS=1,HGI_NO_LATTICE_KERNEL=1",
                                   "HGI_DEEP_K_ENC=4,HGI_DEEP_K_DEC=4", "HGI_DEEP_K_ENC=5,HGI_DEEP_K_DEC=5"])
 def test_forced_code_paths_in_a_child_process(mode):
     """The library picks tile geometry and code path per launch: 128x16, 128x32 or 128x64 tiles, and the fully checked path only
@@ -593,7 +594,8 @@ def test_forced_code_paths_in_a_child_process(mode):
     path, small shapes through 64-row tiles, large ones through 32-row and (pyramids up to four levels) 16-row tiles, deep pyramids through the host recursion
     instead of the one-workgroup lattice kernel -- with the lattice plane's encoder writing its reconstruction itself
     (one launch) and with the older encode-then-decode chain (HGI_NO_ENC_REC) --, the decoder walking its tile list
-    backwards, and deep pyramids split at four or five levels instead of six (what a lone 16384^2 encode does by itself;
+    backwards, seven- and eight-level decodes through seed planes instead of seeds rebuilt inside the tile kernel, and deep
+    pyramids split at four or five levels instead of six (what a lone 16384^2 encode does by itself;
     the bytes must not depend on the split)."""
     import os
     import subprocess
@@ -972,6 +974,32 @@ def test_device_entropy_stage_batch(H, oracle, lena):
 def _ffi_error():
     from rustyhgi_amd import _ffi
     return _ffi.HgiError
+
+
+def test_archive_auto_entropy_rule(H, oracle, lena, tmp_path):
+    """device_entropy="auto": the device stream unless an LZ77 probe of the grid predicts a much smaller one.  The criterion
+    harness's exactly periodic `(x*y) as u8` frame (benches/bench.rs:26-28) is 19x smaller under LZ77 and must go to zlib;
+    a photograph's residuals keep the device stream.  Either archive reads back to the same grid."""
+    import io
+    import torch
+    from rustyhgi_amd.archive import Archive, Metadata
+    from rustyhgi_amd.grid import Grid
+    for name, img, want in (("xy", oracle.synth(oracle.SYNTH_XY, 0, 0, 1920, 1080), "zlib"), ("lena", lena, "device")):
+        h, w = img.shape
+        grid = oracle.encode(img, 4, oracle.linear_lut(0 if name == "xy" else 2)[0])
+        d = torch.from_numpy(grid).cuda()
+        a = Archive(Metadata(0 if name == "xy" else 2, 0, w, h, 4), Grid(d, w))
+        buf = io.BytesIO()
+        assert a.serialize_to_writer(buf, device_entropy="auto") == want, name
+        auto_bytes = buf.getvalue()
+        back = Archive.deserialize_from_reader(io.BytesIO(auto_bytes))
+        assert (np.asarray(back.grid.buffer).reshape(h, w) == grid).all(), name
+        dev = io.BytesIO()
+        assert a.serialize_to_writer(dev, device_entropy=True) == "device"
+        if want == "zlib":
+            assert len(auto_bytes) * 10 < len(dev.getvalue())        # 87 kB against 1.6 MB
+        else:
+            assert auto_bytes == dev.getvalue()
 
 
 def _run_structured(rng, n, max_run, nvalues):
