@@ -37,6 +37,11 @@ extern "C" {
                                lut: *const u8, grids_out: *mut u8, batch: usize, frame_stride: usize) -> c_int;
     pub fn hgi_decode_u8_batch(ctx: *mut HgiCtx, grids: *const u8, width: u32, height: u32, levels: u32, interp: c_int,
                                imgs_out: *mut u8, batch: usize, frame_stride: usize) -> c_int;
+    /// include/hgi.h: the entropy stage over a batch of device-resident grids, streams packed back to back into `out`
+    /// (stream f = out[offsets[f] .. offsets[f] + sizes[f]], offsets multiples of 64): one download per group of frames
+    pub fn hgi_deflate_grids_packed_dev(ctx: *mut HgiCtx, d_grids: *const c_void, width: u32, height: u32, batch: usize,
+                                        frame_stride: usize, out: *mut u8, cap: usize, offsets: *mut usize,
+                                        sizes: *mut usize) -> c_int;
     /// include/hgi.h: per-frame byte histogram of a grid batch on the device (d_hist: 256 * batch u64)
     pub fn hgi_histogram_u8_dev(ctx: *mut HgiCtx, d_grid: *const c_void, width: u32, height: u32, batch: usize,
                                 frame_stride: usize, d_hist: *mut c_void) -> c_int;

@@ -116,7 +116,7 @@ static_assert(TH != 64 || 18 * (buf_bytes(4) + rbuf_bytes(4) + 256) <= 160 * 102
                     // 16 no halo-column loads, 32 no halo-row loads
 #endif
 #ifndef HGI_XCD_MODE
-#define HGI_XCD_MODE 0
+#define HGI_XCD_MODE 1      // default of the XCD dealing policy (block_role); HGI_XCD_MODE in the environment overrides it
 #endif
 #ifndef HGI_DEC_REVERSE_DEFAULT
 #define HGI_DEC_REVERSE_DEFAULT 0
@@ -1266,6 +1266,7 @@ struct TileGrid {
     u32 nfast, nedge;       // totals over the batch
     u32 reverse;            // walk the interior tile list backwards (speed only: see launch_decode_fused)
     u32 band;               // tile rows per band of the column-major walk (fast_tile)
+    u32 xmode;              // how the band-ordered tile list is dealt to the XCDs (block_role)
 #ifdef HGI_TIMELINE
     u64 *timeline;          // experiment builds (tools/timeline.py): eight u64 per block -- start, staged, end, hardware id, entry
 #endif
@@ -1414,7 +1415,7 @@ __device__ __forceinline__ void dec_seed_commit(u8 *buf, const SeedRegs &r, u32 
 // LDS crossbar (ds_bpermute); nothing is exchanged between tiles -- neighbouring tiles recompute the same values, which
 // are pure functions of the grid (src/decoder.rs:30-44).  The loads go out with the tile's own staging loads.
 struct InlineSeeds {
-    u32 gv, gs;      // grid bytes: this lane's patch point / this lane's seed point
+    u32 gv;          // grid byte of this lane's patch point (the seeds' own residuals are in the staged tile already)
 };
 
 __device__ __forceinline__ u32 grid_at(const u8 *__restrict__ fr, u32 W, u32 H, u32 px, u32 py)
@@ -1429,14 +1430,15 @@ __device__ __forceinline__ InlineSeeds inline_seed_issue(const u8 *__restrict__ 
     const u32 px0 = tl.X0 >> 6, py0 = tl.Y0 >> 6, ax = px0 & ~bm, ay = py0 & ~bm;
     InlineSeeds s;
     s.gv = lane < 25u ? grid_at(fr, W, H, ax + 2u * (lane % 5u), ay + 2u * (lane / 5u)) : 0u;
-    s.gs = lane < 12u ? grid_at(fr, W, H, px0 + (lane & 3u), py0 + (lane >> 2)) : 0u;
     return s;
 }
 
 __device__ __forceinline__ u32 lane_value(u32 v, u32 from) { return (u32)__builtin_amdgcn_ds_bpermute((int)(from << 2), (int)v); }
 
+// `buf`: the staged tile (after stage_commit): the residual of seed (bx, by) sits at its lattice position in the tile's
+// halo frame -- the byte dec_seed_commit() is about to replace by the reconstruction.
 template <int INTERP>
-__device__ __forceinline__ SeedRegs inline_seed_finish(const InlineSeeds &s, Tile tl, u32 up, u32 sw, u32 sh)
+__device__ __forceinline__ SeedRegs inline_seed_finish(const InlineSeeds &s, const u8 *buf, Tile tl, u32 up, u32 sw, u32 sh)
 {
     const u32 lane = HGI_LANE, bm = (1u << up) - 1u;
     const u32 px0 = tl.X0 >> 6, py0 = tl.Y0 >> 6, ax = px0 & ~bm, ay = py0 & ~bm;
@@ -1463,7 +1465,8 @@ __device__ __forceinline__ SeedRegs inline_seed_finish(const InlineSeeds &s, Til
     const u32 lt = lane_value(rec0, o0), rt = lane_value(rec0, (o0 + 5u) & 63u), lb = lane_value(rec0, (o0 + 1u) & 63u), rb = lane_value(rec0, (o0 + 6u) & 63u);
     const u32 p = pred1<INTERP>(lt, rt, lb, rb);
     const bool even = !((sx | sy) & 1u), inside = sx < sw && sy < sh;
-    r.rec = (r.on && inside) ? (even ? lt : ((p + s.gs) & 255u)) : 0u;
+    const u32 gs = r.on ? buf[laddr(r.bx << 6, r.by << 6)] : 0u;
+    r.rec = (r.on && inside) ? (even ? lt : ((p + gs) & 255u)) : 0u;
     return r;
 }
 
@@ -1548,19 +1551,24 @@ __device__ __forceinline__ BlockRole block_role(const TileGrid &g)
     r.idle = r.edge && b >= g.nedge;
     const u32 fb = b - ne8;
     r.index = r.edge ? b : range_first(HGI_PAIR ? g.nfast >> 1 : g.nfast, fb & 7u) + (fb >> 3);
-#if HGI_XCD_MODE
-    // Experiments (tile order): which tiles the eight XCDs work on at one time.  0 (shipped): each XCD walks
-    // its own contiguous eighth of the band-ordered list -- eight places of the frame an eighth of it apart.  1: bands dealt
-    // round-robin -- eight CONSECUTIVE bands.  2: every band cut into eight column strips -- ONE band at a time.
-    if (!r.edge && !HGI_PAIR && g.full_y % g.band == 0) {
+    // Which tiles the eight XCDs work on at one time (speed only; g.xmode, host policy xcd_mode()).  0: each XCD walks its
+    // own contiguous eighth of the band-ordered list -- eight places an eighth of the batch apart, a power-of-two distance
+    // on power-of-two frames.  1: whole bands dealt round-robin, so the XCDs work on eight CONSECUTIVE bands (16384^2:
+    // -10 % encode, -9 % decode; 64 x 4096^2: -1.5 ... -1.8 %; profiles/r03_ab_xcd.txt); what is left after the last
+    // multiple of eight bands is split contiguously as in mode 0.  2 (experiment): every band cut into eight column strips.
+    if (!r.edge && !HGI_PAIR && g.xmode && g.full_y % g.band == 0) {
         const u32 P = g.band * g.full_x, nb = g.nfast / P, x = fb & 7u, sq = fb >> 3;
-        if (HGI_XCD_MODE == 1 && nb % 8u == 0) r.index = ((sq / P) * 8u + x) * P + sq % P;
-        if (HGI_XCD_MODE == 2 && g.full_x % 8u == 0) {
+        if (g.xmode == 1) {
+            const u32 nb8 = nb & ~7u, own = (nb8 >> 3) * P;          // blocks of this XCD that belong to whole rounds of bands
+            if (sq < own)
+                r.index = ((sq / P) * 8u + x) * P + sq % P;
+            else
+                r.index = nb8 * P + range_first(g.nfast - nb8 * P, x) + (sq - own);
+        } else if (g.full_x % 8u == 0) {
             const u32 cw = g.full_x / 8u, per = g.band * cw, band = sq / per, rem = sq - band * per;
             r.index = band * P + (x * cw) * g.band + rem;
         }
     }
-#endif
     return r;
 }
 
@@ -1596,12 +1604,13 @@ __global__ __launch_bounds__(NL * NWAVES) __attribute__((amdgpu_waves_per_eu(HGI
         HGI_MARK("stage_issue");
         HGI_TL_START();
         stage_issue<false>(st, cur.b, cur.tl, (int)k, nh, wv);
-        InlineSeeds il = {0, 0};
+        InlineSeeds il = {0};
         if (SEEDED == 1) seeds = seed_issue<false>(sd, cur.tl, k);
         if (SEEDED == 2) il = inline_seed_issue(src + (size_t)cur.tl.frame * f.frame_stride, W, H, cur.tl, (u32)sd.stride);
         HGI_MARK("stage_commit");
         stage_commit<false>(buf, nullptr, st, nh, HGI_PAIR && wv == 0);
-        if (SEEDED == 2) seeds = inline_seed_finish<INTERP>(il, cur.tl, (u32)sd.stride, sd.sw, sd.sh);
+        LDS_ORDER();
+        if (SEEDED == 2) seeds = inline_seed_finish<INTERP>(il, buf, cur.tl, (u32)sd.stride, sd.sw, sd.sh);
         LDS_ORDER();
         if (HGI_PAIR) {
             if (wv) pair_push_column<false>(buf, smem - HCOL, nullptr, nh);
@@ -1619,14 +1628,16 @@ __global__ __launch_bounds__(NL * NWAVES) __attribute__((amdgpu_waves_per_eu(HGI
     const u8 *fr = src + (size_t)tl.frame * f.frame_stride;
     u8 *out = dst + (size_t)tl.frame * f.frame_stride;
     SeedRegs seeds;
+    InlineSeeds il = {0};
     if (SEEDED == 1) seeds = seed_issue<false>(sd, tl, k);
-    if (SEEDED == 2) seeds = inline_seed_finish<INTERP>(inline_seed_issue(fr, W, H, tl, (u32)sd.stride), tl, (u32)sd.stride, sd.sw, sd.sh);
+    if (SEEDED == 2) il = inline_seed_issue(fr, W, H, tl, (u32)sd.stride);
     if (aligned & 2u) {   // 32-bit buffer offsets: buffer staging and the check-free levels with edge masks
         TileCtx cur = {tl, make_buf(fr, out, W, H, tl, (aligned & 4u) ? 3u : 0u)};
         Stage st;
         stage_issue<true, true>(st, cur.b, tl, (int)k, nh);
         stage_commit<false>(buf, nullptr, st, nh);
         LDS_ORDER();
+        if (SEEDED == 2) seeds = inline_seed_finish<INTERP>(il, buf, tl, (u32)sd.stride, sd.sw, sd.sh);
         if (SEEDED) dec_seed_commit(buf, seeds, k);
         if (tl.X0 + TW <= W && !(H & 1u))
             dec_tile_edge<INTERP, 1>(buf, cur, st.o, k, W, H);
@@ -1637,6 +1648,7 @@ __global__ __launch_bounds__(NL * NWAVES) __attribute__((amdgpu_waves_per_eu(HGI
     // frames whose byte offsets do not fit 32 bits: every access checked, 64-bit addressing
     stage_tile_generic(buf, fr, W, H, tl, nh, (aligned & 1u) != 0);
     LDS_ORDER();
+    if (SEEDED == 2) seeds = inline_seed_finish<INTERP>(il, buf, tl, (u32)sd.stride, sd.sw, sd.sh);
     if (SEEDED) dec_seed_commit(buf, seeds, k);
     for (int s = 1 << (k - 1); s >= 2; s >>= 1) {
         dec_cells<INTERP, true>(buf, s, tl, W, H);
@@ -1848,6 +1860,7 @@ FusedGeom fused_geom(const void *a, const void *b, const Frames &f, u32 row_limi
     g.nedge = (u32)(all - nfast);
     g.reverse = 0;
     g.band = HGI_TILE_BAND;
+    g.xmode = 0;
     // bit 0: 16-B aligned rows and pointers (vector accesses of the byte-checked path); bit 1: check-free paths allowed
     // (32-bit buffer offsets); bit 2: read descriptors carry 3 extra records (rows not a multiple of 4 bytes)
     r.aligned = (aligned ? 1u : 0u) | (fast ? 2u : 0u) | (fast && !dword_rows ? 4u : 0u);
@@ -1872,6 +1885,12 @@ inline u32 band_rows(const Frames &f, bool encode)
     return rows;
 }
 
+inline u32 xcd_mode()
+{
+    static const int forced = getenv("HGI_XCD_MODE") ? atoi(getenv("HGI_XCD_MODE")) : -1;      // experiments
+    return forced >= 0 ? (u32)forced : (u32)HGI_XCD_MODE;
+}
+
 }  // namespace
 
 #ifdef HGI_FUSED_DECODE
@@ -1890,6 +1909,7 @@ hipError_t HGI_TILED(launch_decode_fused)(const uint8_t *grid, uint8_t *img, con
     }();
     r.g.reverse = dec_reverse ? 1u : 0u;
     r.g.band = band_rows(f, false);
+    r.g.xmode = xcd_mode();
     const TileGrid &g = r.g;
     if (seeds && k < (uint32_t)kSeededMinLevels) return hipErrorInvalidValue;      // one lane per lattice point (seed_issue)
     Seeds sd = seeds ? *seeds : Seeds{nullptr, nullptr, 0, 0, 0};
@@ -1936,6 +1956,7 @@ hipError_t HGI_TILED(launch_encode_fused)(const uint8_t *img, uint8_t *grid, con
     // decoding the grid it just made
     if (rec_out && (seeds || !(r.aligned & 2u))) return hipErrorNotSupported;
     r.g.band = band_rows(f, true);
+    r.g.xmode = xcd_mode();
     const TileGrid &g = r.g;
     if (seeds && k < (uint32_t)kSeededMinLevels) return hipErrorInvalidValue;      // one lane per lattice point (seed_issue)
     Seeds sd = seeds ? *seeds : Seeds{nullptr, nullptr, 0, 0, 0};
