@@ -66,7 +66,9 @@ static void bench_encode(const char *name, Q quantizator, const GrayImage &image
                                        table.data(), out.data()));
                }), size);
     }
-    const int reps = 20;
+    // `device`: calls queued back to back, one synchronisation per sample; 200 of them so that the wait at the end (10-20 us
+    // of host latency) does not show in the per-call figure (round 2 used 20: +0.5 ... 1 us per call)
+    const int reps = 200;
     double sec = median_seconds(25, [&] {
         for (int r = 0; r < reps; ++r)
             check(hgi_encode_u8_dev(ctx.get(), d_in, image.width, image.height, (uint32_t)levels, I::kernel_id,
@@ -91,7 +93,7 @@ int main()
         std::vector<uint8_t> v(size), mem(size);
         for (size_t i = 0; i < size; ++i) v[i] = (uint8_t)i;
         report("memory", "host", median_seconds(25, [&] { std::memcpy(mem.data(), v.data(), size); }), size);
-        const int reps = 50;
+        const int reps = 200;
         double sec = median_seconds(25, [&] {
             for (int r = 0; r < reps; ++r) check(hgi_copy_u8_dev(ctx.get(), d_a, d_b, size));
             check(hgi_sync(ctx.get()));
@@ -110,7 +112,7 @@ int main()
         Decoder<Crossed> decoder(Crossed{});
         report("decode", "host", median_seconds(25, [&] { (void)decoder.decode({width, height}, levels, grid); }), size);
         (void)hipMemcpy(d_a, grid.buffer.data(), size, hipMemcpyHostToDevice);
-        const int reps = 20;
+        const int reps = 200;
         double sec = median_seconds(25, [&] {
             for (int r = 0; r < reps; ++r)
                 check(hgi_decode_u8_dev(ctx.get(), d_a, width, height, (uint32_t)levels, HGI_INTERP_CROSSED, d_b, 1, size));
@@ -198,6 +200,8 @@ int main()
                        used_device = serialize_auto_into(buffer, metadata, g, ctx.get(), d_b);
                        auto_bytes = buffer.size();
                    }), size);
+            bool lz = false;
+            report("  (the rule's LZ77 probe alone)", "host", median_seconds(5, [&] { lz = archive_detail::lz77_would_win(g, archive_bytes - 28); }), size);
             std::printf("  archive: %zu bytes (%.2fx) -- the rule chose %s\n", auto_bytes, double(size) / auto_bytes,
                         used_device ? "the device stream" : "zlib level 9 (an LZ77 probe of the grid beat the device stream's exact size)");
         }

@@ -43,6 +43,9 @@ hgi_status fail(hgi_status st, const char *fmt, ...)
 
 inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
+#ifndef HGI_ENTROPY_GROUP_MIB_DEFAULT
+#define HGI_ENTROPY_GROUP_MIB_DEFAULT 256
+#endif
 #ifndef HGI_TILE16_MAX_DEFAULT
 #define HGI_TILE16_MAX_DEFAULT 600    // an ENCODE of at most this many 32-row tiles runs on 16-row tiles instead (profiles/r03_sizes.txt: 1920 x 1080 is 510)
 #endif
@@ -871,8 +874,15 @@ DeflateGeom deflate_geom(uint64_t n, size_t batch)
     g.n = n;
     g.nchunks = huffman_chunks(n);
     g.dev_cap = align_up((size_t)(n + n / 4) + 4096, 256);      // an optimal code averages < 9 bits per byte
-    // a group's stream buffers: 256 MiB (two groups are in flight: one being packed, one being downloaded)
-    size_t group = ((size_t)256 << 20) / g.dev_cap;
+    // a group's stream buffers: 256 MiB by default (two groups are in flight: one being packed, one being downloaded);
+    // HGI_ENTROPY_GROUP_MIB in the environment sets another size (tools/entropy_packed_time.py: smaller groups shorten
+    // the un-overlapped head and tail of the pipeline, more groups cost more synchronisations)
+    static const size_t group_mib = [] {
+        const char *e = getenv("HGI_ENTROPY_GROUP_MIB");
+        const long v = e ? atol(e) : 0;
+        return v > 0 ? (size_t)v : (size_t)HGI_ENTROPY_GROUP_MIB_DEFAULT;
+    }();
+    size_t group = (group_mib << 20) / g.dev_cap;
     if (group < 1) group = 1;
     if (group > batch) group = batch ? batch : 1;
     if (group > 256) group = 256;

@@ -11,11 +11,13 @@
 #endif
 // Interior tiles are walked in bands of HGI_TILE_BAND tile rows, column-major inside a band (fast_tile()): tiles that share
 // halo lines with their right neighbour are then dispatched a band height apart instead of back to back.  Measured in
-// one process on the same planes (tools/ab.py, profiles/r02_ab_tile_order*.txt): decode 8 rows -3.0 ... -4.0 %, 4 rows -2 ... -2.6 %, 16 rows -5.5 % on one box and 0 % on the next, 32 rows +3.5 %.
+// one process on the same planes (tools/ab.py, profiles/r02_ab_tile_order*.txt; bands dealt contiguously to the XCDs, round 2): decode 8 rows
+// -3.0 ... -4.0 %, 4 rows -2 ... -2.6 %.  Round 3 deals the bands round-robin (block_role, g.xmode) and there four rows win in both
+// directions (profiles/r03_order_sweep.txt); the height is capped by address span at run time (band_rows()).
 #ifndef HGI_TILE_ORDER
 #define HGI_TILE_ORDER 3
 #endif
 #ifndef HGI_TILE_BAND
-#define HGI_TILE_BAND 8
+#define HGI_TILE_BAND 4
 #endif
 #include "hgi_fused_impl.h"

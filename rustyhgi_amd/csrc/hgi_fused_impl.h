@@ -1871,17 +1871,20 @@ FusedGeom fused_geom(const void *a, const void *b, const Frames &f, u32 row_limi
 }
 
 // Tile rows per band of the interior walk.  A band is walked column-major, so the tiles in flight at one moment span
-// `rows * TH` image rows of a few tile columns: rows * TH * W bytes of address space.  Measured (tools/ab.py,
-// profiles/r03_ab_c4_order.txt, r03_band_sweep.txt): on 4096-wide frames the decoder is indifferent between 4 and 16 and
-// the encoder wants 4; on a 16384-wide frame a decode in 8-row bands is 15 % slower than in 4-row bands (135 -> 114 us
-// for 16384^2 -- what round 2 took for a read-after-write penalty), so bands are capped at 4 MiB of address space.
-// HGI_ENC_BAND / HGI_DEC_BAND in the environment force a height (experiments).
+// `rows * TH` image rows of a few tile columns: rows * TH * W bytes of address space.  Measured with the bands dealt
+// round-robin to the XCDs (tools/order_sweep.sh, profiles/r03_order_sweep.txt; tools/ab.py, profiles/r03_ab_c4_order.txt):
+// four rows are best in both directions on 4096-wide frames (64 x 4096^2: 354.6 / 347.3 us against 357.2 / 351.4 at
+// eight and 366.0 / 353.9 at two); on a 16384-wide frame the encoder still wants four (102 us; two: 109) and the decoder
+// two (98 us; four: 104) -- and with round 2's eight-row decoder bands and contiguous eighths that decode took 135 us,
+// which round 2 mistook for a read-after-write penalty.  Hence: four rows, capped at 4 MiB (encode) / 2 MiB (decode) of
+// address space.  HGI_ENC_BAND / HGI_DEC_BAND in the environment force a height (experiments).
 inline u32 band_rows(const Frames &f, bool encode)
 {
     static const int forced[2] = {getenv("HGI_DEC_BAND") ? atoi(getenv("HGI_DEC_BAND")) : 0, getenv("HGI_ENC_BAND") ? atoi(getenv("HGI_ENC_BAND")) : 0};
     if (forced[encode ? 1 : 0] > 0) return (u32)forced[encode ? 1 : 0];
+    const u64 cap = encode ? (4u << 20) : (2u << 20);
     u32 rows = HGI_TILE_BAND;
-    while (rows > 1 && (u64)rows * TH * f.width > (4u << 20)) rows >>= 1;
+    while (rows > 1 && (u64)rows * TH * f.width > cap) rows >>= 1;
     return rows;
 }
 
