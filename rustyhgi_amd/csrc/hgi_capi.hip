@@ -932,19 +932,12 @@ hgi_status deflate_frames(hgi_ctx *c, const uint8_t *d_grids, uint32_t w, uint32
         prefix[i] = (uint8_t)(n >> (8 * i));
         suffix[i] = (uint8_t)((uint64_t)w >> (8 * i));
     }
-    // Group boundaries.  The pipeline's un-overlapped head is the first group's own histogram + plan + pack (nothing is
-    // there to download yet), so the first groups are small and double up to the full size: 1/8, 1/4, 1/2 of a group, then
-    // whole groups (64 x 4096^2 grids: 4.0 -> 3.x ms, tools/entropy_packed_time.py).
+    // Group boundaries: equal groups.  (Small first groups that double up to the full size -- to shorten the pipeline's
+    // un-overlapped head, the first group's own histogram + plan + pack -- were tried: 9 groups instead of 6 for the C3
+    // shard cost more in synchronisations than the head gave back: packed / strided 0.92 against 0.90, profiles/r03_entropy_groups.txt.)
     std::vector<size_t> starts;
-    {
-        size_t at = 0, step = g.group >= 8 && batch > g.group ? g.group / 8 : g.group;
-        while (at < batch) {
-            starts.push_back(at);
-            at += step < batch - at ? step : batch - at;
-            if (step < g.group) step = step * 2 < g.group ? step * 2 : g.group;
-        }
-        starts.push_back(batch);
-    }
+    for (size_t at = 0; at < batch; at += g.group) starts.push_back(at);
+    starts.push_back(batch);
     const size_t ngroups = starts.size() - 1;
     const bool piped = ngroups > 1;
     if (!n) {

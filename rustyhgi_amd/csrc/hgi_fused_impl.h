@@ -29,6 +29,7 @@
 //
 // All arithmetic is u8/integer; there is no MFMA-shaped work on this path.
 #include "hgi_dev.h"
+#include "hgi_fastdiv.h"
 
 namespace hgi {
 namespace {
@@ -122,22 +123,13 @@ static_assert(TH != 64 || 18 * (buf_bytes(4) + rbuf_bytes(4) + 256) <= 160 * 102
 #define HGI_DEC_REVERSE_DEFAULT 0
 #endif
 #ifndef HGI_TILE_ORDER
-#define HGI_TILE_ORDER 0      // order of the interior tiles inside a frame: 0 row-major (shipped); 1..3 experiments
+#define HGI_TILE_ORDER 0      // order of the interior tiles inside a frame: 0 row-major (experiment), 3 column-major bands (shipped; set by the direction's unit)
 #endif
 #ifndef HGI_TILE_BAND
 #define HGI_TILE_BAND 8
 #endif
-#ifndef HGI_TILE_REVERSE_Y
-#define HGI_TILE_REVERSE_Y 0
-#endif
 #ifndef HGI_HALO_FIRST
 #define HGI_HALO_FIRST 0
-#endif
-#ifndef HGI_TILE_ORDER_Y
-#define HGI_TILE_ORDER_Y 0
-#endif
-#ifndef HGI_TILE_REVERSE_X
-#define HGI_TILE_REVERSE_X 0
 #endif
 #ifndef HGI_HALO_ALL_ROWS
 #define HGI_HALO_ALL_ROWS 0   // 1: fetch the halo-column offsets >= 16 on every even row (the round-1 behaviour)
@@ -1260,6 +1252,7 @@ __device__ __forceinline__ Buf make_buf(const u8 *fr, u8 *out, u32 W, u32 H, Til
 // ---------------------------------------------------------------------------------------------
 // Tile lists.  `full_x` x `full_y` tiles per frame lie entirely inside the image: the fast kernels walk
 // those; the checked path takes the rest (right column first, then the bottom rows).
+// (FastDiv / make_fastdiv / fdiv: hgi_fastdiv.h -- the block -> tile index math divides by launch-wide constants only)
 struct TileGrid {
     u32 tiles_x, tiles_y;   // all tiles of a frame
     u32 full_x, full_y;     // tiles whose body is inside the image (0 x 0 when the fast path is off)
@@ -1267,66 +1260,46 @@ struct TileGrid {
     u32 reverse;            // walk the interior tile list backwards (speed only: see launch_decode_fused)
     u32 band;               // tile rows per band of the column-major walk (fast_tile)
     u32 xmode;              // how the band-ordered tile list is dealt to the XCDs (block_role)
+    // derived by finish_grid() on the host, so that the kernels neither divide nor re-derive launch constants:
+    u32 ex, nf;             // interior tile columns / interior tiles the walk runs on (pair build: pairs)
+    u32 tpf, P, nfull, rem_rows;   // tiles per frame; per band; in a frame's whole bands; rows of its last, shorter band
+    u32 rr_own, rr_tail0;   // round-robin dealing: blocks per XCD that belong to whole rounds of eight bands; first tile behind them
+    FastDiv fd_tpf, fd_P, fd_band, fd_rem, fd_ex;
 #ifdef HGI_TIMELINE
     u64 *timeline;          // experiment builds (tools/timeline.py): eight u64 per block -- start, staged, end, hardware id, entry
 #endif
 };
 
-__device__ __forceinline__ Tile fast_tile(u32 t, const TileGrid &gg, u32 wv = 0)
+__device__ __forceinline__ Tile fast_tile(u32 t, const TileGrid &g, u32 wv = 0)
 {
-    // pair build: t counts PAIRS of x-adjacent tiles; the tile walk runs on a grid half as wide and wave `wv` takes the
-    // left (0) or right (1) tile of the pair
-    TileGrid g = gg;
-    if (HGI_PAIR) {
-        g.full_x >>= 1;
-        g.nfast >>= 1;
-    }
-    t = __builtin_amdgcn_readfirstlane(g.reverse ? g.nfast - 1u - t : t);
-    const u32 tpf = g.full_x * g.full_y;
+    // (pair build: t counts PAIRS of x-adjacent tiles; the walk runs on a grid half as wide -- g.ex, g.nf -- and wave `wv`
+    // takes the left (0) or right (1) tile of the pair)
+    t = __builtin_amdgcn_readfirstlane(g.reverse ? g.nf - 1u - t : t);
     Tile tl;
-    tl.frame = t / tpf;
-    const u32 tt = t - tl.frame * tpf;
-    u32 ty = tt / g.full_x, tx = tt - ty * g.full_x;
-#if HGI_TILE_ORDER == 1          // right to left within a tile row
-    tx = g.full_x - 1 - tx;
-#elif HGI_TILE_ORDER == 2
-    // bands of HGI_TILE_BAND tile rows, even tile columns of the band first, then the odd ones (experiment; frames whose
-    // interior does not divide keep row-major order)
-    constexpr u32 R = HGI_TILE_BAND;
-    if (g.full_y % R == 0 && g.full_x % 2 == 0) {
-        const u32 per = R * g.full_x, band = tt / per, r = tt - band * per;
-        const u32 half = g.full_x / 2, odd = r >= R * half, q = r - odd * R * half;
-        ty = band * R + q / half;
-        tx = 2 * (q % half) + odd;
-    }
-#elif HGI_TILE_ORDER == 3
-    // Bands of HGI_TILE_BAND tile rows, column-major inside a band: x-neighbours are dispatched `rows` tiles apart,
+    tl.frame = fdiv(t, g.fd_tpf);
+    const u32 tt = t - tl.frame * g.tpf;
+    u32 ty, tx;
+#if HGI_TILE_ORDER == 0          // row-major (experiment)
+    ty = fdiv(tt, g.fd_ex);
+    tx = tt - ty * g.ex;
+#else
+    // Bands of g.band tile rows, column-major inside a band: x-neighbours are dispatched `rows` tiles apart,
     // y-neighbours next to each other.  The last band of a frame takes the rows that are left.
     {
-        const u32 R = g.band;      // tile rows per band (host policy: band_rows())
-        const u32 per = R * g.full_x, nfull = (g.full_y / R) * per;
-        u32 rows = R, row0, r;
-        if (tt < nfull) {
-            const u32 band = tt / per;
-            r = tt - band * per;
-            row0 = band * R;
+        u32 rows, row0, r;
+        if (tt < g.nfull) {
+            const u32 band = fdiv(tt, g.fd_P);
+            r = tt - band * g.P;
+            row0 = band * g.band;
+            rows = g.band;
+            tx = fdiv(r, g.fd_band);
         } else {
-            rows = g.full_y % R;
-            r = tt - nfull;
+            rows = g.rem_rows;
+            r = tt - g.nfull;
             row0 = g.full_y - rows;
+            tx = fdiv(r, g.fd_rem);
         }
-        tx = r / rows;
-        u32 q = r - tx * rows;
-#if HGI_TILE_ORDER_Y == 1          // even rows of the band first, then the odd ones: y-neighbours rows / 2 apart as well
-        q = q < (rows + 1) / 2 ? 2 * q : 2 * (q - (rows + 1) / 2) + 1;
-#endif
-#if HGI_TILE_REVERSE_Y             // ... and bottom to top: the tile below (owner of the halo rows) is dispatched earlier too
-        q = rows - 1 - q;
-#endif
-        ty = row0 + q;
-#if HGI_TILE_REVERSE_X             // ... walking the band right to left: the right neighbour is dispatched EARLIER
-        tx = g.full_x - 1 - tx;
-#endif
+        ty = row0 + (r - tx * rows);
     }
 #endif
     tl.X0 = (HGI_PAIR ? 2 * tx + wv : tx) * TW;
@@ -1550,23 +1523,20 @@ __device__ __forceinline__ BlockRole block_role(const TileGrid &g)
     r.edge = b < ne8;
     r.idle = r.edge && b >= g.nedge;
     const u32 fb = b - ne8;
-    r.index = r.edge ? b : range_first(HGI_PAIR ? g.nfast >> 1 : g.nfast, fb & 7u) + (fb >> 3);
+    r.index = r.edge ? b : range_first(g.nf, fb & 7u) + (fb >> 3);
     // Which tiles the eight XCDs work on at one time (speed only; g.xmode, host policy xcd_mode()).  0: each XCD walks its
     // own contiguous eighth of the band-ordered list -- eight places an eighth of the batch apart, a power-of-two distance
     // on power-of-two frames.  1: whole bands dealt round-robin, so the XCDs work on eight CONSECUTIVE bands (16384^2:
     // -10 % encode, -9 % decode; 64 x 4096^2: -1.5 ... -1.8 %; profiles/r03_ab_xcd.txt); what is left after the last
-    // multiple of eight bands is split contiguously as in mode 0.  2 (experiment): every band cut into eight column strips.
-    if (!r.edge && !HGI_PAIR && g.xmode && g.full_y % g.band == 0) {
-        const u32 P = g.band * g.full_x, nb = g.nfast / P, x = fb & 7u, sq = fb >> 3;
-        if (g.xmode == 1) {
-            const u32 nb8 = nb & ~7u, own = (nb8 >> 3) * P;          // blocks of this XCD that belong to whole rounds of bands
-            if (sq < own)
-                r.index = ((sq / P) * 8u + x) * P + sq % P;
-            else
-                r.index = nb8 * P + range_first(g.nfast - nb8 * P, x) + (sq - own);
-        } else if (g.full_x % 8u == 0) {
-            const u32 cw = g.full_x / 8u, per = g.band * cw, band = sq / per, rem = sq - band * per;
-            r.index = band * P + (x * cw) * g.band + rem;
+    // multiple of eight bands is split contiguously as in mode 0.  (finish_grid() clears xmode when a frame's rows do not
+    // divide into whole bands.)
+    if (!r.edge && g.xmode == 1) {
+        const u32 x = fb & 7u, sq = fb >> 3;
+        if (sq < g.rr_own) {
+            const u32 round = fdiv(sq, g.fd_P);
+            r.index = (round * 8u + x) * g.P + (sq - round * g.P);
+        } else {
+            r.index = g.rr_tail0 + range_first(g.nf - g.rr_tail0, x) + (sq - g.rr_own);
         }
     }
     return r;
@@ -1888,6 +1858,31 @@ inline u32 band_rows(const Frames &f, bool encode)
     return rows;
 }
 
+// Everything the kernels would otherwise derive per block from the launch's constants (and the divisions by them).
+inline void finish_grid(TileGrid &g)
+{
+    g.ex = HGI_PAIR ? g.full_x >> 1 : g.full_x;
+    g.nf = HGI_PAIR ? g.nfast >> 1 : g.nfast;
+    if (g.band < 1) g.band = 1;
+    g.tpf = g.ex * g.full_y;
+    g.P = g.band * g.ex;
+    g.nfull = (g.full_y / g.band) * g.P;
+    g.rem_rows = g.full_y % g.band;
+    g.fd_tpf = make_fastdiv(g.tpf);
+    g.fd_P = make_fastdiv(g.P);
+    g.fd_band = make_fastdiv(g.band);
+    g.fd_rem = make_fastdiv(g.rem_rows);
+    g.fd_ex = make_fastdiv(g.ex);
+    g.rr_own = g.rr_tail0 = 0;
+    if (g.xmode != 1 || HGI_PAIR || g.rem_rows != 0 || g.P == 0 || g.nf == 0) {
+        g.xmode = 0;
+    } else {
+        const u32 nb8 = (g.nf / g.P) & ~7u;          // bands in whole rounds of eight
+        g.rr_own = (nb8 >> 3) * g.P;
+        g.rr_tail0 = nb8 * g.P;
+    }
+}
+
 inline u32 xcd_mode()
 {
     static const int forced = getenv("HGI_XCD_MODE") ? atoi(getenv("HGI_XCD_MODE")) : -1;      // experiments
@@ -1913,6 +1908,7 @@ hipError_t HGI_TILED(launch_decode_fused)(const uint8_t *grid, uint8_t *img, con
     r.g.reverse = dec_reverse ? 1u : 0u;
     r.g.band = band_rows(f, false);
     r.g.xmode = xcd_mode();
+    finish_grid(r.g);
     const TileGrid &g = r.g;
     if (seeds && k < (uint32_t)kSeededMinLevels) return hipErrorInvalidValue;      // one lane per lattice point (seed_issue)
     Seeds sd = seeds ? *seeds : Seeds{nullptr, nullptr, 0, 0, 0};
@@ -1960,6 +1956,7 @@ hipError_t HGI_TILED(launch_encode_fused)(const uint8_t *img, uint8_t *grid, con
     if (rec_out && (seeds || !(r.aligned & 2u))) return hipErrorNotSupported;
     r.g.band = band_rows(f, true);
     r.g.xmode = xcd_mode();
+    finish_grid(r.g);
     const TileGrid &g = r.g;
     if (seeds && k < (uint32_t)kSeededMinLevels) return hipErrorInvalidValue;      // one lane per lattice point (seed_issue)
     Seeds sd = seeds ? *seeds : Seeds{nullptr, nullptr, 0, 0, 0};
