@@ -197,13 +197,14 @@ bool use_lattice_kernel(const SubGeom &g, size_t batch)
 }
 
 hipError_t launch_encode_fused(const uint8_t *img, uint8_t *grid, const Frames &f, uint32_t k, int interp,
-                               const Lut256 &lut, bool ident, const Seeds *seeds, hipStream_t s, uint32_t row_limit = 0, uint8_t *rec_out = nullptr)
+                               const Lut256 &lut, bool ident, const Seeds *seeds, hipStream_t s, uint32_t row_limit = 0, uint8_t *rec_out = nullptr,
+                               const View *view = nullptr)
 {
     const uint32_t rows = row_limit && row_limit < f.height ? row_limit : f.height;   // what this launch really covers
     switch (use_tile_rows(f.width, rows, k, f.batch, true)) {
-    case 16: return launch_encode_fused_16(img, grid, f, k, interp, lut, ident, seeds, s, row_limit, rec_out);
-    case 32: return launch_encode_fused_32(img, grid, f, k, interp, lut, ident, seeds, s, row_limit, rec_out);
-    default: return launch_encode_fused_64(img, grid, f, k, interp, lut, ident, seeds, s, row_limit, rec_out);
+    case 16: return launch_encode_fused_16(img, grid, f, k, interp, lut, ident, seeds, s, row_limit, rec_out, view);
+    case 32: return launch_encode_fused_32(img, grid, f, k, interp, lut, ident, seeds, s, row_limit, rec_out, view);
+    default: return launch_encode_fused_64(img, grid, f, k, interp, lut, ident, seeds, s, row_limit, rec_out, view);
     }
 }
 
@@ -268,15 +269,26 @@ hgi_status encode_impl(hgi_ctx *c, const uint8_t *img, uint32_t w, uint32_t h, u
             HIP_TRY(launch_lattice_pyramid(img, f, k, levels - k, interp, l, is_identity(lut), true, sub_grid, sub_rec, g.sw,
                                            g.sh, g.stride, c->stream));
         } else {
-            HIP_TRY(launch_gather_lattice(img, f, k, sub_img, g.sw, g.sh, g.stride, c->stream));
             // The plane's own pyramid in ONE launch when a tile holds it: the encoder writes its reconstruction beside the
-            // residuals (src/encoder.rs:63-64 has it in place anyway), so the plane need not be decoded again for the seeds.
-            static const bool no_rec = getenv("HGI_NO_ENC_REC") != nullptr;      // tests / experiments: the three-launch chain
+            // residuals (src/encoder.rs:63-64 has it in place anyway), so the plane need not be decoded again for the seeds --
+            // and when the plane consists of whole tiles that launch stages them straight from the frame (a view), so the
+            // gather launch goes too.  HGI_NO_ENC_REC / HGI_NO_ENC_VIEW keep the older chains (tests, experiments).
+            static const bool no_rec = getenv("HGI_NO_ENC_REC") != nullptr, no_view = getenv("HGI_NO_ENC_VIEW") != nullptr;
+            const bool one_launch = levels - k <= (uint32_t)kFusedMaxLevels && !no_rec;
+            const Frames sf = {g.sw, g.sh, g.stride, (uint32_t)batch};
             hipError_t e = hipErrorNotSupported;
-            if (levels - k <= (uint32_t)kFusedMaxLevels && !no_rec) {
-                const Frames sf = {g.sw, g.sh, g.stride, (uint32_t)batch};
-                e = launch_encode_fused(sub_img, sub_grid, sf, levels - k, interp, l, is_identity(lut), nullptr, c->stream, 0, sub_rec);
+            if (one_launch && !no_view) {
+                const View vw = {k, w, h, (uint64_t)stride};
+                e = launch_encode_fused(img, sub_grid, sf, levels - k, interp, l, is_identity(lut), nullptr, c->stream, 0, sub_rec, &vw);
                 if (e != hipSuccess && e != hipErrorNotSupported) HIP_TRY(e);
+            }
+            if (e != hipSuccess) {
+                (void)hipGetLastError();
+                HIP_TRY(launch_gather_lattice(img, f, k, sub_img, g.sw, g.sh, g.stride, c->stream));
+                if (one_launch) {
+                    e = launch_encode_fused(sub_img, sub_grid, sf, levels - k, interp, l, is_identity(lut), nullptr, c->stream, 0, sub_rec);
+                    if (e != hipSuccess && e != hipErrorNotSupported) HIP_TRY(e);
+                }
             }
             if (e != hipSuccess) {
                 (void)hipGetLastError();

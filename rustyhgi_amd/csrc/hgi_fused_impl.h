@@ -771,6 +771,7 @@ struct Buf {
     __amdgpu_buffer_rsrc_t rd;   // frame being written
     __amdgpu_buffer_rsrc_t rr;   // encode with WREC: the reconstruction plane (src/encoder.rs:63-64 keeps it in place; here it is an output on request)
     u32 W, base;                 // base = Y0 * W + X0
+    u32 vshift, vrow, vbase;     // view staging (encoder's plane launch): pixel shift, parent bytes per plane row, parent offset of (X0, Y0)
 };
 
 // Row pair (image rows 2p, 2p + 1) a lane owns in iteration `it` of the finest level, p = fine_pair0 + 8 * it:
@@ -865,6 +866,51 @@ __device__ __forceinline__ void stage_issue(Stage &st, const Buf &b, Tile tl, in
     } else {
         issue_body();
         issue_halo();
+    }
+}
+
+// Interior tile of a lattice plane staged straight from the parent frame: every 16-pixel chunk is sixteen byte loads
+// 2^shift apart (the gather kernel that used to run in front of the plane launch did the same loads, and then the plane
+// was read again).  Same Stage registers, so everything behind staging is unchanged.
+__device__ __forceinline__ v4u load16_view(const Buf &b, u32 off)
+{
+    u32 w[4];
+#pragma unroll
+    for (int d = 0; d < 4; ++d) {
+        u32 v = 0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            v |= (u32)__builtin_amdgcn_raw_buffer_load_b8(b.rs, off + ((u32)(4 * d + i) << b.vshift), 0, 0) << (8 * i);
+        w[d] = v;
+    }
+    return v4u{w[0], w[1], w[2], w[3]};
+}
+
+__device__ __forceinline__ void stage_issue_view(Stage &st, const Buf &b, int k, int nh, bool has_right)
+{
+    const int lane = HGI_LANE, c = lane & (CH - 1), r = lane >> LCH;
+    const u32 rw = __builtin_amdgcn_readfirstlane(b.vrow), sh = b.vshift;
+    const u32 col = b.vbase + ((u32)(16 * c) << sh);
+#pragma unroll
+    for (int j = 0; j < TH / 16; ++j) st.e[j] = load16_view(b, col + (u32)(2 * (r + 8 * j)) * rw);
+#pragma unroll
+    for (int j = 0; j < NFINE; ++j) st.o[j] = load16_view(b, col + (u32)(2 * (fine_pair0() + 8 * j) + 1) * rw);
+    st.hv = v4u{0, 0, 0, 0};
+    if (lane < nh * CH) st.hv = load16_view(b, col + (u32)(TH + hoff(r)) * rw);
+    st.x0 = v3u{0, 0, 0};
+    st.d16 = st.d32 = st.d64 = 0;
+    st.zero4 = st.zero8 = false;
+    const int hy = lane < TH / 2 ? 2 * lane : TH + hoff(lane - TH / 2);
+    // the column right of the tile: the plane consists of whole tiles, so either the whole next tile exists or nothing does
+    // (the parent's range check does not help here: x << shift would run on into the parent's next row)
+    if (lane < TH / 2 + nh && has_right) {
+        const u32 xo = b.vbase + (u32)hy * rw + ((u32)TW << sh);
+        st.x0.x = __builtin_amdgcn_raw_buffer_load_b8(b.rs, xo, 0, 0);
+        st.x0.y = __builtin_amdgcn_raw_buffer_load_b8(b.rs, xo + (4u << sh), 0, 0);
+        st.x0.z = __builtin_amdgcn_raw_buffer_load_b8(b.rs, xo + (8u << sh), 0, 0);
+        if (k >= 4 && !(hy & 15)) st.d16 = __builtin_amdgcn_raw_buffer_load_b8(b.rs, xo + (16u << sh), 0, 0);
+        if (k >= 5 && !(hy & 31)) st.d32 = __builtin_amdgcn_raw_buffer_load_b8(b.rs, xo + (32u << sh), 0, 0);
+        if (k >= 6 && !(hy & 63)) st.d64 = __builtin_amdgcn_raw_buffer_load_b8(b.rs, xo + (64u << sh), 0, 0);
     }
 }
 
@@ -1244,7 +1290,18 @@ __device__ __forceinline__ Buf make_buf(const u8 *fr, u8 *out, u32 W, u32 H, Til
     b.rr = __builtin_amdgcn_make_buffer_rsrc(uniform_ptr(rec ? rec : out), 0, bytes, 0x00020000);
     b.W = W;
     b.base = __builtin_amdgcn_readfirstlane(tl.Y0 * W + tl.X0);
+    b.vshift = b.vrow = b.vbase = 0;
     return b;
+}
+
+// ... reading through a view: the read descriptor spans the PARENT frame; rows below the plane lie beyond it (range check
+// -> 0, as ever), columns right of it do not occur (the host launches views on planes of whole tiles only)
+__device__ __forceinline__ void make_buf_view(Buf &b, const u8 *parent, const View &vw, Tile tl)
+{
+    b.rs = __builtin_amdgcn_make_buffer_rsrc(uniform_ptr(parent), 0, vw.pitch * vw.height, 0x00020000);
+    b.vshift = vw.shift;
+    b.vrow = vw.pitch << vw.shift;
+    b.vbase = __builtin_amdgcn_readfirstlane(tl.Y0 * b.vrow + (tl.X0 << vw.shift));
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1697,10 +1754,12 @@ __device__ __forceinline__ void enc_tile_fast(u8 *buf, u8 *rbuf, const u8 *slut,
 #define HGI_ENC_WAVES_PER_EU 5
 #endif
 // WREC (never together with SEEDED): the launch also writes the reconstruction of every pixel to `rec` (same geometry as
-// dst) -- the top of a deeper pyramid's chain codes the lattice plane once and hands both planes on as seeds.
+// dst) -- the top of a deeper pyramid's chain codes the lattice plane once and hands both planes on as seeds.  These are
+// small, latency-bound launches (a lattice plane): their register budget is not held to the main kernels' occupancy
+// target -- the view staging keeps sixteen byte loads per chunk in flight.
 template <int INTERP, bool IDENT, bool SEEDED, int TILE_ROWS, bool WREC = false>
-__global__ __launch_bounds__(NL * NWAVES) __attribute__((amdgpu_waves_per_eu(IDENT ? HGI_ENC_WAVES_PER_EU - 1 : HGI_ENC_WAVES_PER_EU))) void k_enc_tiles(const u8 *__restrict__ src, u8 *__restrict__ dst, Frames f, u32 k,
-                                                  Lut256 lut, Seeds sd, TileGrid g, u32 aligned, u8 *__restrict__ rec)
+__global__ __launch_bounds__(NL * NWAVES) __attribute__((amdgpu_waves_per_eu(WREC ? 2 : IDENT ? HGI_ENC_WAVES_PER_EU - 1 : HGI_ENC_WAVES_PER_EU))) void k_enc_tiles(const u8 *__restrict__ src, u8 *__restrict__ dst, Frames f, u32 k,
+                                                  Lut256 lut, Seeds sd, TileGrid g, u32 aligned, u8 *__restrict__ rec, View vw)
 {
     HGI_TL_ENTRY();
     extern __shared__ __attribute__((aligned(16))) u8 smem[];
@@ -1736,7 +1795,12 @@ __global__ __launch_bounds__(NL * NWAVES) __attribute__((amdgpu_waves_per_eu(IDE
         SeedRegs seeds;
         HGI_MARK("stage_issue");
         HGI_TL_START();
-        stage_issue<false>(st, cur.b, cur.tl, (int)k, nh, wv);
+        if (WREC && vw.shift) {      // the lattice plane of a larger frame, staged straight from that frame (no gather launch)
+            make_buf_view(cur.b, src + (size_t)cur.tl.frame * vw.frame_stride, vw, cur.tl);
+            stage_issue_view(st, cur.b, (int)k, nh, cur.tl.X0 + TW < W);
+        } else {
+            stage_issue<false>(st, cur.b, cur.tl, (int)k, nh, wv);
+        }
         if (SEEDED) seeds = seed_issue<true>(sd, cur.tl, k);
         if (!IDENT) lutv = lut.w[HGI_LANE];      // (pair build: both waves write the same table)
         HGI_MARK("stage_commit");
@@ -1947,10 +2011,21 @@ hipError_t static_lds_is_empty(const void *kernel)
 }  // namespace
 
 hipError_t HGI_TILED(launch_encode_fused)(const uint8_t *img, uint8_t *grid, const Frames &f, uint32_t k, int interp,
-                                          const Lut256 &lut, bool ident, const Seeds *seeds, hipStream_t s, uint32_t row_limit, uint8_t *rec_out)
+                                          const Lut256 &lut, bool ident, const Seeds *seeds, hipStream_t s, uint32_t row_limit, uint8_t *rec_out,
+                                          const View *view)
 {
-    FusedGeom r = fused_geom(img, grid, f, row_limit);
+    // through a view `img` is the parent frame: the geometry checks below concern the plane (grid, rec_out); the parent only
+    // has to be addressable with 32-bit offsets
+    FusedGeom r = fused_geom(view ? grid : img, grid, f, row_limit);
     if (!r.ok || k < 1 || k > (u32)MAXK) return hipErrorInvalidValue;
+    View vw = {0, 0, 0, 0};
+    if (view) {
+        const u64 row = (u64)view->pitch << view->shift;
+        if (!rec_out || seeds || r.g.nedge != 0 || !(r.aligned & 2u) || view->shift < 1 || view->shift > 8 ||
+            (u64)view->pitch * view->height >= (1ull << 32) || ((u64)f.height + 2 * TH + 64) * row >= (1ull << 32))
+            return hipErrorNotSupported;
+        vw = *view;
+    }
     // the reconstruction output exists on the check-free paths only (and never under seeds): the caller falls back to
     // decoding the grid it just made
     if (rec_out && (seeds || !(r.aligned & 2u))) return hipErrorNotSupported;
@@ -1971,13 +2046,13 @@ hipError_t HGI_TILED(launch_encode_fused)(const uint8_t *img, uint8_t *grid, con
     do {                                                                                                          \
         static const hipError_t lds0 = static_lds_is_empty(reinterpret_cast<const void *>(&k_enc_tiles<I, ID, SE, TH>)); \
         if (lds0 != hipSuccess) return lds0;                                                                      \
-        hipLaunchKernelGGL((k_enc_tiles<I, ID, SE, TH>), blocks, b, lds, s, img, grid, f, k, lut, sd, g, r.aligned, (u8 *)nullptr); \
+        hipLaunchKernelGGL((k_enc_tiles<I, ID, SE, TH>), blocks, b, lds, s, img, grid, f, k, lut, sd, g, r.aligned, (u8 *)nullptr, vw); \
     } while (0)
 #define HGI_ENC_REC(I, ID)                                                                                        \
     do {                                                                                                          \
         static const hipError_t lds0 = static_lds_is_empty(reinterpret_cast<const void *>(&k_enc_tiles<I, ID, false, TH, true>)); \
         if (lds0 != hipSuccess) return lds0;                                                                      \
-        hipLaunchKernelGGL((k_enc_tiles<I, ID, false, TH, true>), blocks, b, lds, s, img, grid, f, k, lut, sd, g, r.aligned, rec_out); \
+        hipLaunchKernelGGL((k_enc_tiles<I, ID, false, TH, true>), blocks, b, lds, s, img, grid, f, k, lut, sd, g, r.aligned, rec_out, vw); \
     } while (0)
 #define HGI_ENC_I(I)                                                          \
     do {                                                                      \

@@ -585,7 +585,8 @@ def test_hip_graph_capture_and_replay(H, ctxs, oracle):
 
 @pytest.mark.parametrize("mode", ["HGI_FORCE_CHECKED=1", "HGI_TILE_H=64", "HGI_TILE_H=32", "HGI_TILE_H=16", "HGI_NO_LATTICE_KERNEL=1",
                                   "HGI_NO_LATTICE_KERNEL=1,HGI_NO_ENC_REC=1", "HGI_DEC_REVERSE=1", "HGI_NO_INLINE_SEEDS=1",
-                                  "HGI_NO_INLINE_SEEDS=1,HGI_NO_LATTICE_KERNEL=1",
+                                  "HGI_NO_INLINE_SEEDS=1,HGI_NO_LATTICE_KERNEL=1", "HGI_DEEP_K_ENC=4,HGI_DEEP_K_DEC=4,HGI_NO_LATTICE_KERNEL=1",
+                                  "HGI_DEEP_K_ENC=4,HGI_NO_LATTICE_KERNEL=1,HGI_NO_ENC_VIEW=1",
                                   "HGI_DEEP_K_ENC=4,HGI_DEEP_K_DEC=4", "HGI_DEEP_K_ENC=5,HGI_DEEP_K_DEC=5"])
 def test_forced_code_paths_in_a_child_process(mode):
     """The library picks tile geometry and code path per launch: 128x16, 128x32 or 128x64 tiles, and the fully checked path only
@@ -607,6 +608,34 @@ def test_forced_code_paths_in_a_child_process(mode):
                         "small_golden or lena_and_fullhd or random_shapes or smooth_images or batch_layouts or fuzz or extreme or deep_pyramid"],
                        env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, mode + "\n" + r.stdout[-3000:] + r.stderr[-1000:]
+
+
+@pytest.mark.parametrize("w,h,levels,batch", [(2048, 512, 7, 2), (4096, 1024, 8, 1), (2048, 2048, 9, 1), (4096, 512, 6, 3)])
+def test_deep_pyramid_plane_of_whole_tiles(H, oracle, w, h, levels, batch):
+    """Frames whose stride-16 lattice plane consists of whole tiles: with the pyramid split at four levels and the
+    one-workgroup lattice kernel off (the forced-path child processes do that) the encoder's plane launch stages its tiles
+    straight from the frame through a view -- no gather launch -- and writes residuals and reconstruction in one go; here,
+    with the default switches, the same shapes go through whatever the library picks.  Bytes must not depend on it."""
+    import torch
+    from rustyhgi_amd import _ffi
+    L = _ffi.lib()
+    ctx = H.Context(0)
+    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    for q in (2, 0):
+        lut = oracle.linear_lut(q)[0]
+        host = np.stack([oracle.synth(oracle.SYNTH_NOISE if q else oracle.SYNTH_RAMP, SEED0 + 21, f, w, h) for f in range(batch)])
+        src = torch.from_numpy(host).cuda()
+        grid = torch.empty_like(src)
+        out = torch.empty_like(src)
+        _ffi.check(L.hgi_encode_u8_dev(ctx.handle, src.data_ptr(), w, h, levels, 1, lut.ctypes.data, grid.data_ptr(), batch, w * h))
+        _ffi.check(L.hgi_decode_u8_dev(ctx.handle, grid.data_ptr(), w, h, levels, 1, out.data_ptr(), batch, w * h))
+        torch.cuda.synchronize()
+        assert_same(src.cpu().numpy(), host, "encode modified its input")
+        for f in range(batch):
+            want = oracle.encode(host[f], levels, lut)
+            assert_same(grid[f].cpu().numpy(), want, "encode %dx%d L%d q%d frame %d" % (w, h, levels, q, f))
+            assert_same(out[f].cpu().numpy(), oracle.decode(want, levels), "decode %dx%d L%d q%d frame %d" % (w, h, levels, q, f))
+    ctx.close()
 
 
 @pytest.mark.parametrize("w,h,levels,batch", [(1024, 1024, 31, 1), (704, 300, 13, 2), (4096, 256, 20, 1), (2048, 2048, 19, 1)])
