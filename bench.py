@@ -59,7 +59,7 @@ def pmc_traffic(kernel, frames, size, levels):
     """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (FETCH_SIZE with the
     gfx950 x2 correction + WRITE_SIZE; tools/profile.sh -> profiles/*_traffic.json), if that profile was
     taken on this exact workload; else None.  bench.py cannot run the profiler on itself."""
-    for name in ("r02_traffic.json", "r01_traffic.json"):      # newest committed profile of this workload
+    for name in ("r03_traffic.json", "r02_traffic.json", "r01_traffic.json"):      # newest committed profile of this workload
         try:
             with open(os.path.join(ROOT, "profiles", name)) as f:
                 prof = json.load(f)

@@ -424,6 +424,8 @@ def test_cli_hgi_test_report_and_archive_interop(H, oracle, lena, tmp_path):
     dec_m = oracle.decode(want, 4)
     assert arc.metadata == Metadata(1, 0, 256, 256, 3) and (arc.grid.as_image() == oracle.encode(dec_m, 3, oracle.linear_lut(1)[0])).all()
     # the same report with the archive's DEFLATE stream written by the device's entropy stage: smaller on this image
+    auto = subprocess.run([exe, "test", "LENA.TIF", "-s", "_a", "--entropy", "auto"], cwd=str(tmp_path), capture_output=True, text=True, timeout=120)
+    assert auto.returncode == 0 and "Compressed:   13 kb" in auto.stdout and "SD:           9.17" in auto.stdout, auto.stdout + auto.stderr   # the rule keeps the device stream on a photograph
     dev = subprocess.run([exe, "test", "LENA.TIF", "-s", "_d", "--entropy", "device"], cwd=str(tmp_path), capture_output=True, text=True, timeout=120)
     assert dev.returncode == 0, dev.stderr
     assert "Compressed:   13 kb" in dev.stdout and "SD:           9.17" in dev.stdout, dev.stdout      # 14 033 B (zlib-9: 16 067)
