@@ -869,48 +869,64 @@ __device__ __forceinline__ void stage_issue(Stage &st, const Buf &b, Tile tl, in
     }
 }
 
-// Interior tile of a lattice plane staged straight from the parent frame: every 16-pixel chunk is sixteen byte loads
-// 2^shift apart (the gather kernel that used to run in front of the plane launch did the same loads, and then the plane
-// was read again).  Same Stage registers, so everything behind staging is unchanged.
-__device__ __forceinline__ v4u load16_view(const Buf &b, u32 off)
+// Interior tile of a lattice plane staged straight from the parent frame (no gather launch in front of the plane launch).
+// Plane pixels are single bytes 2^shift apart, so this path loads BYTES, one plane pixel per lane: a wave instruction
+// covers 64 neighbouring pixels of one plane row = 64 << shift parent bytes (8 lines at shift 4; the first version gave
+// each lane a 16-pixel chunk like the ordinary staging does and touched 64 lines per instruction: the launch took
+// 10 us).  The bytes go straight to their places in LDS -- even rows and halo rows into `buf`, halo columns into the
+// transposed column slots, odd rows into a scratch area behind the planes (`oddbuf`, TH / 2 rows of TW bytes) from
+// which the finest level's lane map picks them up as 16-byte chunks; the half-resolution plane is derived from `buf`
+// afterwards (lattice_from_buf).  Everything behind staging is unchanged.
+__device__ __forceinline__ void stage_view_to_lds(u8 *buf, u8 *oddbuf, const Buf &b, int k, int nh, bool has_right)
 {
-    u32 w[4];
+    const u32 lane = HGI_LANE, sh = b.vshift;
+    const u32 rw = __builtin_amdgcn_readfirstlane(b.vrow);
+    const u32 col = b.vbase + (lane << sh), half = 64u << sh;
+    u32 ev[TH / 2][2], od[TH / 2][2], hr[HR][2];
 #pragma unroll
-    for (int d = 0; d < 4; ++d) {
-        u32 v = 0;
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-            v |= (u32)__builtin_amdgcn_raw_buffer_load_b8(b.rs, off + ((u32)(4 * d + i) << b.vshift), 0, 0) << (8 * i);
-        w[d] = v;
+    for (int z = 0; z < TH / 2; ++z) {
+        ev[z][0] = __builtin_amdgcn_raw_buffer_load_b8(b.rs, col + (u32)(2 * z) * rw, 0, 0);
+        ev[z][1] = __builtin_amdgcn_raw_buffer_load_b8(b.rs, col + (u32)(2 * z) * rw + half, 0, 0);
+        od[z][0] = __builtin_amdgcn_raw_buffer_load_b8(b.rs, col + (u32)(2 * z + 1) * rw, 0, 0);
+        od[z][1] = __builtin_amdgcn_raw_buffer_load_b8(b.rs, col + (u32)(2 * z + 1) * rw + half, 0, 0);
     }
-    return v4u{w[0], w[1], w[2], w[3]};
-}
-
-__device__ __forceinline__ void stage_issue_view(Stage &st, const Buf &b, int k, int nh, bool has_right)
-{
-    const int lane = HGI_LANE, c = lane & (CH - 1), r = lane >> LCH;
-    const u32 rw = __builtin_amdgcn_readfirstlane(b.vrow), sh = b.vshift;
-    const u32 col = b.vbase + ((u32)(16 * c) << sh);
 #pragma unroll
-    for (int j = 0; j < TH / 16; ++j) st.e[j] = load16_view(b, col + (u32)(2 * (r + 8 * j)) * rw);
-#pragma unroll
-    for (int j = 0; j < NFINE; ++j) st.o[j] = load16_view(b, col + (u32)(2 * (fine_pair0() + 8 * j) + 1) * rw);
-    st.hv = v4u{0, 0, 0, 0};
-    if (lane < nh * CH) st.hv = load16_view(b, col + (u32)(TH + hoff(r)) * rw);
-    st.x0 = v3u{0, 0, 0};
-    st.d16 = st.d32 = st.d64 = 0;
-    st.zero4 = st.zero8 = false;
-    const int hy = lane < TH / 2 ? 2 * lane : TH + hoff(lane - TH / 2);
+    for (int i = 0; i < HR; ++i) {
+        hr[i][0] = hr[i][1] = 0;
+        if (i < nh) {
+            hr[i][0] = __builtin_amdgcn_raw_buffer_load_b8(b.rs, col + (u32)(TH + hoff(i)) * rw, 0, 0);
+            hr[i][1] = __builtin_amdgcn_raw_buffer_load_b8(b.rs, col + (u32)(TH + hoff(i)) * rw + half, 0, 0);
+        }
+    }
     // the column right of the tile: the plane consists of whole tiles, so either the whole next tile exists or nothing does
     // (the parent's range check does not help here: x << shift would run on into the parent's next row)
-    if (lane < TH / 2 + nh && has_right) {
+    u32 hc[HR] = {0, 0, 0, 0, 0, 0};
+    const int hy = (int)lane < TH / 2 ? 2 * (int)lane : TH + hoff((int)lane - TH / 2);
+    if ((int)lane < TH / 2 + nh && has_right) {
         const u32 xo = b.vbase + (u32)hy * rw + ((u32)TW << sh);
-        st.x0.x = __builtin_amdgcn_raw_buffer_load_b8(b.rs, xo, 0, 0);
-        st.x0.y = __builtin_amdgcn_raw_buffer_load_b8(b.rs, xo + (4u << sh), 0, 0);
-        st.x0.z = __builtin_amdgcn_raw_buffer_load_b8(b.rs, xo + (8u << sh), 0, 0);
-        if (k >= 4 && !(hy & 15)) st.d16 = __builtin_amdgcn_raw_buffer_load_b8(b.rs, xo + (16u << sh), 0, 0);
-        if (k >= 5 && !(hy & 31)) st.d32 = __builtin_amdgcn_raw_buffer_load_b8(b.rs, xo + (32u << sh), 0, 0);
-        if (k >= 6 && !(hy & 63)) st.d64 = __builtin_amdgcn_raw_buffer_load_b8(b.rs, xo + (64u << sh), 0, 0);
+        hc[0] = __builtin_amdgcn_raw_buffer_load_b8(b.rs, xo, 0, 0);
+        hc[1] = __builtin_amdgcn_raw_buffer_load_b8(b.rs, xo + (4u << sh), 0, 0);
+        hc[2] = __builtin_amdgcn_raw_buffer_load_b8(b.rs, xo + (8u << sh), 0, 0);
+        if (k >= 4 && !(hy & 15)) hc[3] = __builtin_amdgcn_raw_buffer_load_b8(b.rs, xo + (16u << sh), 0, 0);
+        if (k >= 5 && !(hy & 31)) hc[4] = __builtin_amdgcn_raw_buffer_load_b8(b.rs, xo + (32u << sh), 0, 0);
+        if (k >= 6 && !(hy & 63)) hc[5] = __builtin_amdgcn_raw_buffer_load_b8(b.rs, xo + (64u << sh), 0, 0);
+    }
+#pragma unroll
+    for (int z = 0; z < TH / 2; ++z) {
+        buf[z * S + lane] = (u8)ev[z][0];
+        buf[z * S + 64 + lane] = (u8)ev[z][1];
+        oddbuf[z * TW + lane] = (u8)od[z][0];
+        oddbuf[z * TW + 64 + lane] = (u8)od[z][1];
+    }
+#pragma unroll
+    for (int i = 0; i < HR; ++i)
+        if (i < nh) {
+            buf[(TH / 2 + i) * S + lane] = (u8)hr[i][0];
+            buf[(TH / 2 + i) * S + 64 + lane] = (u8)hr[i][1];
+        }
+    if ((int)lane < TH / 2 + nh) {
+#pragma unroll
+        for (int i = 0; i < HR; ++i) buf[HCOL + i * HP + lane] = (u8)hc[i];
     }
 }
 
@@ -1795,16 +1811,24 @@ __global__ __launch_bounds__(NL * NWAVES) __attribute__((amdgpu_waves_per_eu(WRE
         SeedRegs seeds;
         HGI_MARK("stage_issue");
         HGI_TL_START();
-        if (WREC && vw.shift) {      // the lattice plane of a larger frame, staged straight from that frame (no gather launch)
+        const bool through_view = WREC && vw.shift != 0;
+        if (through_view) {      // the lattice plane of a larger frame, staged straight from that frame (no gather launch)
+            u8 *oddbuf = smem + 256 + slice;                  // scratch behind the planes (the launcher sized LDS for it)
             make_buf_view(cur.b, src + (size_t)cur.tl.frame * vw.frame_stride, vw, cur.tl);
-            stage_issue_view(st, cur.b, (int)k, nh, cur.tl.X0 + TW < W);
+            stage_view_to_lds(buf, oddbuf, cur.b, (int)k, nh, cur.tl.X0 + TW < W);
+            if (!IDENT) lutv = lut.w[HGI_LANE];
+            LDS_ORDER();
+            lattice_from_buf(buf, rbuf, nh);
+#pragma unroll
+            for (int j = 0; j < NFINE; ++j)
+                st.o[j] = *reinterpret_cast<const v4u *>(oddbuf + (fine_pair0() + 8 * j) * TW + 16 * (HGI_LANE & (CH - 1)));
         } else {
             stage_issue<false>(st, cur.b, cur.tl, (int)k, nh, wv);
+            if (SEEDED) seeds = seed_issue<true>(sd, cur.tl, k);
+            if (!IDENT) lutv = lut.w[HGI_LANE];      // (pair build: both waves write the same table)
+            HGI_MARK("stage_commit");
+            stage_commit<true>(buf, rbuf, st, nh, HGI_PAIR && wv == 0);
         }
-        if (SEEDED) seeds = seed_issue<true>(sd, cur.tl, k);
-        if (!IDENT) lutv = lut.w[HGI_LANE];      // (pair build: both waves write the same table)
-        HGI_MARK("stage_commit");
-        stage_commit<true>(buf, rbuf, st, nh, HGI_PAIR && wv == 0);
         if (!IDENT) reinterpret_cast<u32 *>(slut)[HGI_LANE] = lutv;
         LDS_ORDER();
         if (HGI_PAIR) {
@@ -2037,7 +2061,7 @@ hipError_t HGI_TILED(launch_encode_fused)(const uint8_t *img, uint8_t *grid, con
     Seeds sd = seeds ? *seeds : Seeds{nullptr, nullptr, 0, 0, 0};
     const dim3 b(NL * NWAVES);
     const int nh = k >= 2 ? (int)k : 1;
-    const size_t lds = ((size_t)buf_bytes(nh) + ((rbuf_bytes(nh) + 15) & ~15)) * NWAVES + 256;
+    const size_t lds = ((size_t)buf_bytes(nh) + ((rbuf_bytes(nh) + 15) & ~15)) * NWAVES + 256 + (view ? (size_t)(TH / 2) * TW : 0);
     if (HGI_PAIR && (g.full_x & 1u)) return hipErrorInvalidValue;      // the experiment build pairs x-adjacent interior tiles
     const dim3 blocks(((g.nedge + 7u) & ~7u) + g.nfast / NWAVES);
     // lut_at() addresses the table from LDS offset 0: only valid while the kernel has no static LDS in front of its
