@@ -1971,6 +1971,16 @@ inline void finish_grid(TileGrid &g)
     }
 }
 
+// Dynamic LDS of a launch padded so that at most `waves` blocks fit a CU (160 KiB of LDS): a launch only a few rounds of
+// resident tiles deep pays a tile LIFETIME for filling and draining the chip, and the lifetime is resident tiles / rate
+// (Little) -- fewer resident tiles at the same rate shorten it.  Experiments: HGI_DEC_WAVES / HGI_ENC_WAVES.
+inline size_t lds_for_waves(size_t lds, int waves)
+{
+    if (waves <= 0) return lds;
+    const size_t cap = ((size_t)160 * 1024 / (size_t)waves) & ~(size_t)255;
+    return cap > lds ? cap : lds;
+}
+
 inline u32 xcd_mode()
 {
     static const int forced = getenv("HGI_XCD_MODE") ? atoi(getenv("HGI_XCD_MODE")) : -1;      // experiments
@@ -2005,7 +2015,8 @@ hipError_t HGI_TILED(launch_decode_fused)(const uint8_t *grid, uint8_t *img, con
     if (inline_seeds && (TH != 64 || k != 6 || sd.stride < 1 || sd.stride > 2)) return hipErrorInvalidValue;
     const dim3 b(NL * NWAVES);
     const int nh = k >= 2 ? (int)k : 1;
-    const size_t lds = (size_t)buf_bytes(nh) * NWAVES;
+    static const int dec_waves = getenv("HGI_DEC_WAVES") ? atoi(getenv("HGI_DEC_WAVES")) : 0;
+    const size_t lds = lds_for_waves((size_t)buf_bytes(nh) * NWAVES, dec_waves);
     if (HGI_PAIR && (g.full_x & 1u)) return hipErrorInvalidValue;      // the experiment build pairs x-adjacent interior tiles
     const dim3 blocks(((g.nedge + 7u) & ~7u) + g.nfast / NWAVES);
 #define HGI_DEC(I, SE) hipLaunchKernelGGL((k_dec_tiles<I, SE, TH>), blocks, b, lds, s, grid, img, f, k, sd, g, r.aligned)
@@ -2061,7 +2072,8 @@ hipError_t HGI_TILED(launch_encode_fused)(const uint8_t *img, uint8_t *grid, con
     Seeds sd = seeds ? *seeds : Seeds{nullptr, nullptr, 0, 0, 0};
     const dim3 b(NL * NWAVES);
     const int nh = k >= 2 ? (int)k : 1;
-    const size_t lds = ((size_t)buf_bytes(nh) + ((rbuf_bytes(nh) + 15) & ~15)) * NWAVES + 256 + (view ? (size_t)(TH / 2) * TW : 0);
+    static const int enc_waves = getenv("HGI_ENC_WAVES") ? atoi(getenv("HGI_ENC_WAVES")) : 0;
+    const size_t lds = lds_for_waves(((size_t)buf_bytes(nh) + ((rbuf_bytes(nh) + 15) & ~15)) * NWAVES + 256 + (view ? (size_t)(TH / 2) * TW : 0), enc_waves);
     if (HGI_PAIR && (g.full_x & 1u)) return hipErrorInvalidValue;      // the experiment build pairs x-adjacent interior tiles
     const dim3 blocks(((g.nedge + 7u) & ~7u) + g.nfast / NWAVES);
     // lut_at() addresses the table from LDS offset 0: only valid while the kernel has no static LDS in front of its
