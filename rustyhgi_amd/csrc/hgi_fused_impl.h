@@ -2015,7 +2015,13 @@ hipError_t HGI_TILED(launch_decode_fused)(const uint8_t *grid, uint8_t *img, con
     if (inline_seeds && (TH != 64 || k != 6 || sd.stride < 1 || sd.stride > 2)) return hipErrorInvalidValue;
     const dim3 b(NL * NWAVES);
     const int nh = k >= 2 ? (int)k : 1;
-    static const int dec_waves = getenv("HGI_DEC_WAVES") ? atoi(getenv("HGI_DEC_WAVES")) : 0;
+    // A decode between one and eight rounds of resident tiles deep (8 192 ... 65 536 tiles: a lone 16384^2 frame has 32 768)
+    // runs with 20 tiles per CU instead of the 32 its LDS allows: the rate is the same down to 16 (round 1, and
+    // profiles/r03_waves_sweep.txt: 101.3 us at 32, 99.1 at 20, 98.5 at 16, 109.8 at 12), the tile lifetime -- what filling
+    // and draining the chip costs -- shorter.  (The encoder needs all 20 it can get: 98 us, 106 at 16.)
+    static const int dec_waves_forced = getenv("HGI_DEC_WAVES") ? atoi(getenv("HGI_DEC_WAVES")) : -1;
+    const u64 tiles = (u64)g.nfast + g.nedge;
+    const int dec_waves = dec_waves_forced >= 0 ? dec_waves_forced : (tiles >= 8192 && tiles < 65536 ? 20 : 0);
     const size_t lds = lds_for_waves((size_t)buf_bytes(nh) * NWAVES, dec_waves);
     if (HGI_PAIR && (g.full_x & 1u)) return hipErrorInvalidValue;      // the experiment build pairs x-adjacent interior tiles
     const dim3 blocks(((g.nedge + 7u) & ~7u) + g.nfast / NWAVES);
