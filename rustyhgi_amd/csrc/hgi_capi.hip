@@ -67,7 +67,7 @@ struct hgi_ctx {
     hipEvent_t ev_up[3], ev_free[3];
     hipEvent_t ev_band[16];   // banded single-frame calls: "band uploaded"
     bool have_pipe;
-    uint32_t *pool_ctr;       // 64 zeroed u32 of device memory: ticket / exit counters of the tile kernels' tail pool (self-resetting)
+    uint32_t *pool_ctr;       // 4 KiB of zeroed device memory: the tile kernels' tail-pool counters (TileGrid::pool; self-resetting)
     uint8_t *pin;             // pinned host memory (entropy stage: histograms and stream sizes come down without stalling the host)
     size_t pin_bytes;
 };
@@ -410,7 +410,7 @@ hgi_status hgi_ctx_create(int device, hgi_ctx **out)
     c->pin = nullptr;
     c->pin_bytes = 0;
     c->pool_ctr = nullptr;
-    if (hipMalloc(reinterpret_cast<void **>(&c->pool_ctr), 256) != hipSuccess || hipMemset(c->pool_ctr, 0, 256) != hipSuccess) {
+    if (hipMalloc(reinterpret_cast<void **>(&c->pool_ctr), 4096) != hipSuccess || hipMemset(c->pool_ctr, 0, 4096) != hipSuccess) {
         if (c->pool_ctr) (void)hipFree(c->pool_ctr);
         delete c;
         return fail(HGI_ENOMEM, "device allocation failed");

@@ -1340,14 +1340,18 @@ struct TileGrid {
     u32 ex, nf;             // interior tile columns / interior tiles the walk runs on (pair build: pairs)
     u32 tpf, P, nfull, rem_rows;   // tiles per frame; per band; in a frame's whole bands; rows of its last, shorter band
     u32 rr_own, rr_tail0;   // round-robin dealing: blocks per XCD that belong to whole rounds of eight bands; first tile behind them
-    // The tail pool.  Blocks are dealt to the XCDs by the hardware in equal numbers, the XCDs do not run equally fast
-    // (the per-block timeline shows their last stores 5-10 us apart on a 350 us launch, 4-6 on a 100 us one), and a
-    // block that owns exactly one tile cannot help: the last `pool_tiles` tiles of the list are therefore not owned by
-    // blocks.  `pool_blocks` extra blocks at the end of the grid take them by ticket (one agent-scope atomic per tile) and
-    // LOOP until the pool is empty -- the blocks of a fast XCD arrive earlier and take more.  pool[0] = tickets,
-    // pool[32] = blocks that have left; the last one to leave zeroes both, so every launch starts from zero (graph
-    // replays included).  ns = nf - pool_tiles tiles keep their static owners.
-    u32 ns, pool_tiles, pool_blocks;
+    // The tail pool.  Blocks are dealt to the XCDs by the hardware in equal numbers (block b runs on the XCD labelled
+    // b % 8), the XCDs do not run equally fast (the per-block timeline shows their last stores 5-10 us apart on a 350 us
+    // launch, 4-6 on a 100 us one), and blocks that own their tiles cannot help each other.  So the last 8 pool_q
+    // tiles of the list have no owners: they form eight queues (one per XCD label, pool_q tiles each, contiguous in the
+    // list), and the grid ends with pool_q + pool_extra blocks per label that take a tile by TICKET -- one agent-scope
+    // atomic on their own queue's counter, and when that queue is empty on the other queues' counters in turn (stealing).
+    // The blocks of a fast XCD come up earlier, empty their queue and steal; the last blocks of a slow XCD find nothing
+    // and leave.  Nothing loops (a block still codes at most one tile) and nothing waits.  Counters (u32, 32 words = one
+    // 128-byte line apart): pool[32 x] tickets of queue x, pool[32 (8 + x)] blocks of label x that have left,
+    // pool[32 * 16] labels that are done; the last block of the last label zeroes them all, so every launch finds zeros
+    // (graph replays included).  ns = nf - 8 pool_q tiles keep their static owners.
+    u32 ns, pool_q, pool_extra;
     u32 *pool;
     FastDiv fd_tpf, fd_P, fd_band, fd_rem, fd_ex;
 #ifdef HGI_TIMELINE
@@ -1596,24 +1600,34 @@ __device__ __forceinline__ void dec_tile_edge(u8 *buf, const TileCtx &cur, const
 // (A persistent variant -- resident waves pulling tiles from per-XCD atomic counters and prefetching
 // the next tile into registers -- was built and measured: not faster on MI355X, see DESIGN.md
 // "Scheduling".)
-// next tile of the tail pool for this (looping) block, or false when the pool is empty
-__device__ __forceinline__ bool pool_take(const TileGrid &g, u32 &index)
+// A pool block's tile: a ticket of its own queue (label x = its XCD), else of the other queues in turn; false: all empty.
+__device__ __forceinline__ bool pool_take(const TileGrid &g, u32 x, u32 &index)
 {
-    u32 t = 0;
-    if (HGI_LANE == 0) t = __hip_atomic_fetch_add(g.pool, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    t = __builtin_amdgcn_readfirstlane(t);
-    index = g.ns + t;
-    return t < g.pool_tiles;
+    bool got = false;
+    index = 0;
+    for (u32 i = 0; i < 8u && !got; ++i) {
+        const u32 q = (x + i) & 7u;
+        u32 t = 0;
+        if (HGI_LANE == 0) t = __hip_atomic_fetch_add(g.pool + 32u * q, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        t = __builtin_amdgcn_readfirstlane(t);
+        if (t < g.pool_q) {
+            index = g.ns + q * g.pool_q + t;
+            got = true;
+        }
+    }
+    return got;
 }
-// a pool block leaves: the last one zeroes the counters for the next launch (nobody touches them any more: every other
-// pool block has left its loop before it counted itself out)
+// A pool block leaves.  The last block of a label reports the label done; the last label to be done zeroes every counter
+// for the next launch (nobody touches them any more: each block takes its tickets before it counts itself out).
 __device__ __forceinline__ void pool_leave(const TileGrid &g)
 {
     if (HGI_LANE == 0) {
-        const u32 d = __hip_atomic_fetch_add(g.pool + 32, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (d == g.pool_blocks - 1u) {
-            __hip_atomic_store(g.pool, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(g.pool + 32, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const u32 x = blockIdx.x & 7u, per_label = g.pool_q + g.pool_extra;
+        const u32 d = __hip_atomic_fetch_add(g.pool + 32u * (8u + x), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (d == per_label - 1u) {
+            const u32 e = __hip_atomic_fetch_add(g.pool + 32u * 16u, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (e == 7u)
+                for (u32 i = 0; i <= 16u; ++i) __hip_atomic_store(g.pool + 32u * i, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
 }
@@ -1632,6 +1646,12 @@ __device__ __forceinline__ BlockRole block_role(const TileGrid &g)
     const u32 fb = b - ne8;
     r.pool = !r.edge && fb >= g.ns;
     r.index = r.edge ? b : range_first(g.ns, fb & 7u) + (fb >> 3);
+    if (r.pool) {      // no owner: a ticket (ns is a multiple of eight, so fb & 7 is still the XCD label)
+        u32 index;
+        r.idle = !pool_take(g, fb & 7u, index);
+        r.index = index;
+        return r;
+    }
     // Which tiles the eight XCDs work on at one time (speed only; g.xmode, host policy xcd_mode()).  0: each XCD walks its
     // own contiguous eighth of the band-ordered list -- eight places an eighth of the batch apart, a power-of-two distance
     // on power-of-two frames.  1: whole bands dealt round-robin, so the XCDs work on eight CONSECUTIVE bands (16384^2:
@@ -1674,11 +1694,12 @@ __global__ __launch_bounds__(NL * NWAVES) __attribute__((amdgpu_waves_per_eu(HGI
 #else
     const BlockRole role = block_role(g);
 #endif
-    if (role.idle || (HGI_PAIR && role.edge && wv)) return;
+    if (role.idle || (HGI_PAIR && role.edge && wv)) {
+        if (role.pool) pool_leave(g);
+        return;
+    }
     if (!role.edge) {
-      u32 index = role.index;
-      for (;;) {      // one pass for a block that owns its tile; pool blocks loop until the pool is empty
-        if (role.pool && !pool_take(g, index)) break;
+        const u32 index = role.index;
         TileCtx cur = fast_ctx(index, src, dst, f, g, (aligned & 4u) ? 3u : 0u, nullptr, wv);
         Stage st;
         SeedRegs seeds;
@@ -1702,11 +1723,8 @@ __global__ __launch_bounds__(NL * NWAVES) __attribute__((amdgpu_waves_per_eu(HGI
         dec_tile_fast<INTERP>(buf, cur, st.o, k, W, H);
         HGI_MARK("end");
         HGI_TL_END();
-        if (!role.pool) break;
-        LDS_ORDER();
-      }
-      if (role.pool) pool_leave(g);
-      return;
+        if (role.pool) pool_leave(g);
+        return;
     }
     // ragged tile (body crosses the image edge), unaligned rows, or offsets beyond 32 bits: every access checked
     const Tile tl = edge_tile(role.index, g);
@@ -1841,16 +1859,17 @@ __global__ __launch_bounds__(NL * NWAVES) __attribute__((amdgpu_waves_per_eu(WRE
 #else
     const BlockRole role = block_role(g);
 #endif
-    if (role.idle || (HGI_PAIR && role.edge && wv)) return;
+    if (role.idle || (HGI_PAIR && role.edge && wv)) {
+        if (role.pool) pool_leave(g);
+        return;
+    }
     // The table entry of this lane is a VECTOR load from the kernel-argument segment (the index is the lane): a trip to L2
     // or beyond.  Done first, the whole prologue stalled on it (the timeline build showed 1.4-1.8 us of prologue per
     // encode tile against 0.5-0.7 for decode: tools/timeline.py).  It is issued BEHIND the tile's staging loads instead
     // and lands with them -- the table is first needed after staging has been committed to LDS anyway.
     u32 lutv = 0;
     if (!role.edge) {
-      u32 index = role.index;
-      for (;;) {      // one pass for a block that owns its tile; pool blocks loop until the pool is empty
-        if (role.pool && !pool_take(g, index)) break;
+        const u32 index = role.index;
         TileCtx cur = fast_ctx(index, src, dst, f, g, (aligned & 4u) ? 3u : 0u, WREC ? rec : nullptr, wv);
         Stage st;
         SeedRegs seeds;
@@ -1885,11 +1904,8 @@ __global__ __launch_bounds__(NL * NWAVES) __attribute__((amdgpu_waves_per_eu(WRE
         enc_tile_fast<INTERP, IDENT, WREC>(buf, rbuf, slut, cur, st.o, k, W, H);
         HGI_MARK("end");
         HGI_TL_END();
-        if (!role.pool) break;
-        LDS_ORDER();
-      }
-      if (role.pool) pool_leave(g);
-      return;
+        if (role.pool) pool_leave(g);
+        return;
     }
     const Tile tl = edge_tile(role.index, g);
     const u8 *fr = src + (size_t)tl.frame * f.frame_stride;
@@ -2010,9 +2026,8 @@ inline void finish_grid(TileGrid &g)
     g.fd_band = make_fastdiv(g.band);
     g.fd_rem = make_fastdiv(g.rem_rows);
     g.fd_ex = make_fastdiv(g.ex);
-    if (g.pool == nullptr || HGI_PAIR || g.pool_tiles >= g.nf) g.pool_tiles = g.pool_blocks = 0;
-    if (g.pool_blocks == 0) g.pool_tiles = 0;
-    g.ns = g.nf - g.pool_tiles;
+    if (g.pool == nullptr || HGI_PAIR || (u64)8 * g.pool_q >= g.nf) g.pool_q = g.pool_extra = 0;
+    g.ns = g.nf - 8u * g.pool_q;
     g.rr_own = g.rr_tail0 = 0;
     if (g.xmode != 1 || HGI_PAIR || g.rem_rows != 0 || g.P == 0 || g.ns == 0) {
         g.xmode = 0;
@@ -2024,18 +2039,18 @@ inline void finish_grid(TileGrid &g)
 }
 
 // Tail pool of a launch (TileGrid::pool*): `waves` = tiles resident per CU.  Launches at least four rounds of resident
-// tiles deep get a pool of 1.5 rounds served by one round of looping blocks; HGI_POOL in the environment: 0 switches the
-// pool off, any other value is the pool's size in per cent of a round (experiments).
+// tiles deep get a pool of 1.5 rounds (HGI_POOL in the environment: its size in per cent of a round, 0 = no pool;
+// experiments) and, per XCD label, extra blocks worth 5 % of that label's share of the whole launch.
 inline void plan_pool(TileGrid &g, u32 *counters, int waves, bool allowed)
 {
     static const int pct = getenv("HGI_POOL") ? atoi(getenv("HGI_POOL")) : HGI_POOL_DEFAULT;
     g.pool = nullptr;
-    g.pool_tiles = g.pool_blocks = 0;
+    g.pool_q = g.pool_extra = 0;
     const u64 round = (u64)256 * (u64)(waves > 0 ? waves : 1);
-    if (!allowed || !counters || pct <= 0 || (u64)g.nfast < 4 * round) return;
+    if (!allowed || !counters || pct <= 0 || (u64)g.nfast < 4 * round || (g.nfast & 7u)) return;
     g.pool = counters;
-    g.pool_blocks = (u32)round;
-    g.pool_tiles = (u32)(round * (u64)pct / 100);
+    g.pool_q = (u32)(round * (u64)pct / 100 / 8);
+    g.pool_extra = g.nfast / 8 / 20 + 1;
 }
 
 // Dynamic LDS of a launch padded so that at most `waves` blocks fit a CU (160 KiB of LDS): a launch only a few rounds of
@@ -2092,7 +2107,7 @@ hipError_t HGI_TILED(launch_decode_fused)(const uint8_t *grid, uint8_t *img, con
     const int nh = k >= 2 ? (int)k : 1;
     const size_t lds = lds_for_waves((size_t)buf_bytes(nh) * NWAVES, dec_waves);
     if (HGI_PAIR && (g.full_x & 1u)) return hipErrorInvalidValue;      // the experiment build pairs x-adjacent interior tiles
-    const dim3 blocks(((g.nedge + 7u) & ~7u) + g.ns + g.pool_blocks);
+    const dim3 blocks(((g.nedge + 7u) & ~7u) + g.ns + 8u * (g.pool_q + g.pool_extra));
 #define HGI_DEC(I, SE) hipLaunchKernelGGL((k_dec_tiles<I, SE, TH>), blocks, b, lds, s, grid, img, f, k, sd, g, r.aligned)
 #define HGI_DEC_I(I)                                                     \
     do {                                                                 \
@@ -2150,7 +2165,7 @@ hipError_t HGI_TILED(launch_encode_fused)(const uint8_t *img, uint8_t *grid, con
     static const int enc_waves = getenv("HGI_ENC_WAVES") ? atoi(getenv("HGI_ENC_WAVES")) : 0;
     const size_t lds = lds_for_waves(((size_t)buf_bytes(nh) + ((rbuf_bytes(nh) + 15) & ~15)) * NWAVES + 256 + (view ? (size_t)(TH / 2) * TW : 0), enc_waves);
     if (HGI_PAIR && (g.full_x & 1u)) return hipErrorInvalidValue;      // the experiment build pairs x-adjacent interior tiles
-    const dim3 blocks(((g.nedge + 7u) & ~7u) + g.ns + g.pool_blocks);
+    const dim3 blocks(((g.nedge + 7u) & ~7u) + g.ns + 8u * (g.pool_q + g.pool_extra));
     // lut_at() addresses the table from LDS offset 0: only valid while the kernel has no static LDS in front of its
     // dynamic segment.  Checked once per instantiation on the host; a build that breaks it fails here, not on the device.
 #define HGI_ENC(I, ID, SE)                                                                                        \
