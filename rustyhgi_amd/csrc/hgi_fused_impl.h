@@ -1600,22 +1600,23 @@ __device__ __forceinline__ void dec_tile_edge(u8 *buf, const TileCtx &cur, const
 // (A persistent variant -- resident waves pulling tiles from per-XCD atomic counters and prefetching
 // the next tile into registers -- was built and measured: not faster on MI355X, see DESIGN.md
 // "Scheduling".)
-// A pool block's tile: a ticket of its own queue (label x = its XCD), else of the other queues in turn; false: all empty.
+// A pool block's tile: a ticket of its own queue (label x = its XCD); when that queue is empty, ONE ticket of another
+// queue picked from the block id (the first version tried all eight in turn: the surplus blocks' failed scans -- tens
+// of thousands of atomics on eight words -- took longer than the imbalance they were to cure).  false: nothing taken.
 __device__ __forceinline__ bool pool_take(const TileGrid &g, u32 x, u32 &index)
 {
-    bool got = false;
     index = 0;
-    for (u32 i = 0; i < 8u && !got; ++i) {
-        const u32 q = (x + i) & 7u;
-        u32 t = 0;
+    u32 q = x, t = 0;
+    if (HGI_LANE == 0) t = __hip_atomic_fetch_add(g.pool + 32u * q, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    t = __builtin_amdgcn_readfirstlane(t);
+    if (t >= g.pool_q) {
+        q = (x + 1u + ((blockIdx.x >> 3) % 7u)) & 7u;
         if (HGI_LANE == 0) t = __hip_atomic_fetch_add(g.pool + 32u * q, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         t = __builtin_amdgcn_readfirstlane(t);
-        if (t < g.pool_q) {
-            index = g.ns + q * g.pool_q + t;
-            got = true;
-        }
+        if (t >= g.pool_q) return false;
     }
-    return got;
+    index = g.ns + q * g.pool_q + t;
+    return true;
 }
 // A pool block leaves.  The last block of a label reports the label done; the last label to be done zeroes every counter
 // for the next launch (nobody touches them any more: each block takes its tickets before it counts itself out).
@@ -2040,7 +2041,7 @@ inline void finish_grid(TileGrid &g)
 
 // Tail pool of a launch (TileGrid::pool*): `waves` = tiles resident per CU.  Launches at least four rounds of resident
 // tiles deep get a pool of 1.5 rounds (HGI_POOL in the environment: its size in per cent of a round, 0 = no pool;
-// experiments) and, per XCD label, extra blocks worth 5 % of that label's share of the whole launch.
+// experiments) and, per XCD label, extra blocks worth 2 % of that label's share of the whole launch.
 inline void plan_pool(TileGrid &g, u32 *counters, int waves, bool allowed)
 {
     static const int pct = getenv("HGI_POOL") ? atoi(getenv("HGI_POOL")) : HGI_POOL_DEFAULT;
@@ -2050,7 +2051,7 @@ inline void plan_pool(TileGrid &g, u32 *counters, int waves, bool allowed)
     if (!allowed || !counters || pct <= 0 || (u64)g.nfast < 4 * round || (g.nfast & 7u)) return;
     g.pool = counters;
     g.pool_q = (u32)(round * (u64)pct / 100 / 8);
-    g.pool_extra = g.nfast / 8 / 20 + 1;
+    g.pool_extra = g.nfast / 8 / 50 + 1;
 }
 
 // Dynamic LDS of a launch padded so that at most `waves` blocks fit a CU (160 KiB of LDS): a launch only a few rounds of
