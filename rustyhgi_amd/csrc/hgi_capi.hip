@@ -67,7 +67,6 @@ struct hgi_ctx {
     hipEvent_t ev_up[3], ev_free[3];
     hipEvent_t ev_band[16];   // banded single-frame calls: "band uploaded"
     bool have_pipe;
-    uint32_t *pool_ctr;       // 4 KiB of zeroed device memory: the tile kernels' tail-pool counters (TileGrid::pool; self-resetting)
     uint8_t *pin;             // pinned host memory (entropy stage: histograms and stream sizes come down without stalling the host)
     size_t pin_bytes;
 };
@@ -199,24 +198,24 @@ bool use_lattice_kernel(const SubGeom &g, size_t batch)
 
 hipError_t launch_encode_fused(const uint8_t *img, uint8_t *grid, const Frames &f, uint32_t k, int interp,
                                const Lut256 &lut, bool ident, const Seeds *seeds, hipStream_t s, uint32_t row_limit = 0, uint8_t *rec_out = nullptr,
-                               const View *view = nullptr, uint32_t *pool = nullptr)
+                               const View *view = nullptr)
 {
     const uint32_t rows = row_limit && row_limit < f.height ? row_limit : f.height;   // what this launch really covers
     switch (use_tile_rows(f.width, rows, k, f.batch, true)) {
-    case 16: return launch_encode_fused_16(img, grid, f, k, interp, lut, ident, seeds, s, row_limit, rec_out, view, pool);
-    case 32: return launch_encode_fused_32(img, grid, f, k, interp, lut, ident, seeds, s, row_limit, rec_out, view, pool);
-    default: return launch_encode_fused_64(img, grid, f, k, interp, lut, ident, seeds, s, row_limit, rec_out, view, pool);
+    case 16: return launch_encode_fused_16(img, grid, f, k, interp, lut, ident, seeds, s, row_limit, rec_out, view);
+    case 32: return launch_encode_fused_32(img, grid, f, k, interp, lut, ident, seeds, s, row_limit, rec_out, view);
+    default: return launch_encode_fused_64(img, grid, f, k, interp, lut, ident, seeds, s, row_limit, rec_out, view);
     }
 }
 
 hipError_t launch_decode_fused(const uint8_t *grid, uint8_t *img, const Frames &f, uint32_t k, int interp,
-                               const Seeds *seeds, hipStream_t s, uint32_t row_limit = 0, uint32_t *pool = nullptr)
+                               const Seeds *seeds, hipStream_t s, uint32_t row_limit = 0)
 {
     const uint32_t rows = row_limit && row_limit < f.height ? row_limit : f.height;
     switch (use_tile_rows(f.width, rows, k, f.batch, false)) {
-    case 16: return launch_decode_fused_16(grid, img, f, k, interp, seeds, s, row_limit, pool);
-    case 32: return launch_decode_fused_32(grid, img, f, k, interp, seeds, s, row_limit, pool);
-    default: return launch_decode_fused_64(grid, img, f, k, interp, seeds, s, row_limit, pool);
+    case 16: return launch_decode_fused_16(grid, img, f, k, interp, seeds, s, row_limit);
+    case 32: return launch_decode_fused_32(grid, img, f, k, interp, seeds, s, row_limit);
+    default: return launch_decode_fused_64(grid, img, f, k, interp, seeds, s, row_limit);
     }
 }
 
@@ -298,9 +297,9 @@ hgi_status encode_impl(hgi_ctx *c, const uint8_t *img, uint32_t w, uint32_t h, u
             }
         }
         Seeds sd = {sub_rec, sub_grid, g.sw, g.sh, g.stride};
-        HIP_TRY(launch_encode_fused(img, grid, f, k, interp, l, is_identity(lut), &sd, c->stream, 0, nullptr, nullptr, c->pool_ctr));
+        HIP_TRY(launch_encode_fused(img, grid, f, k, interp, l, is_identity(lut), &sd, c->stream));
     } else {
-        HIP_TRY(launch_encode_fused(img, grid, f, k, interp, l, is_identity(lut), nullptr, c->stream, 0, nullptr, nullptr, c->pool_ctr));
+        HIP_TRY(launch_encode_fused(img, grid, f, k, interp, l, is_identity(lut), nullptr, c->stream));
     }
     return HGI_OK;
 }
@@ -328,7 +327,7 @@ hgi_status decode_impl(hgi_ctx *c, const uint8_t *grid, uint32_t w, uint32_t h, 
         static const bool no_inline = getenv("HGI_NO_INLINE_SEEDS") != nullptr;
         if (k == (uint32_t)kFusedMaxLevels && levels - k <= 2 && !no_inline) {
             Seeds sd = {nullptr, nullptr, g.sw, g.sh, (uint64_t)(levels - k)};
-            HIP_TRY(launch_decode_fused(grid, img, f, k, interp, &sd, c->stream, 0, c->pool_ctr));
+            HIP_TRY(launch_decode_fused(grid, img, f, k, interp, &sd, c->stream));
             return HGI_OK;
         }
         uint8_t *sub_grid = ws_take(c, batch * g.stride);
@@ -342,9 +341,9 @@ hgi_status decode_impl(hgi_ctx *c, const uint8_t *grid, uint32_t w, uint32_t h, 
             HGI_TRY(decode_impl(c, sub_grid, g.sw, g.sh, levels - k, interp, sub_rec, batch, g.stride));
         }
         Seeds sd = {sub_rec, nullptr, g.sw, g.sh, g.stride};
-        HIP_TRY(launch_decode_fused(grid, img, f, k, interp, &sd, c->stream, 0, c->pool_ctr));
+        HIP_TRY(launch_decode_fused(grid, img, f, k, interp, &sd, c->stream));
     } else {
-        HIP_TRY(launch_decode_fused(grid, img, f, k, interp, nullptr, c->stream, 0, c->pool_ctr));
+        HIP_TRY(launch_decode_fused(grid, img, f, k, interp, nullptr, c->stream));
     }
     return HGI_OK;
 }
@@ -409,12 +408,6 @@ hgi_status hgi_ctx_create(int device, hgi_ctx **out)
     c->have_pipe = false;
     c->pin = nullptr;
     c->pin_bytes = 0;
-    c->pool_ctr = nullptr;
-    if (hipMalloc(reinterpret_cast<void **>(&c->pool_ctr), 4096) != hipSuccess || hipMemset(c->pool_ctr, 0, 4096) != hipSuccess) {
-        if (c->pool_ctr) (void)hipFree(c->pool_ctr);
-        delete c;
-        return fail(HGI_ENOMEM, "device allocation failed");
-    }
     if (hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_hist[0], hipEventDisableTiming) != hipSuccess ||
@@ -434,7 +427,6 @@ void hgi_ctx_destroy(hgi_ctx *c)
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
     if (c->ws) (void)hipFree(c->ws);
-    if (c->pool_ctr) (void)hipFree(c->pool_ctr);
     if (c->pin) (void)hipHostFree(c->pin);
     (void)hipEventDestroy(c->ev0);
     (void)hipEventDestroy(c->ev1);

@@ -116,9 +116,6 @@ static_assert(TH != 64 || 18 * (buf_bytes(4) + rbuf_bytes(4) + 256) <= 160 * 102
 #define HGI_ABL 0   // timing experiments: 1 no coarse levels, 2 no fine arithmetic, 4 no halo cells, 8 no sub==2 level,
                     // 16 no halo-column loads, 32 no halo-row loads
 #endif
-#ifndef HGI_POOL_DEFAULT
-#define HGI_POOL_DEFAULT 150     // tail pool: per cent of a round of resident tiles (plan_pool)
-#endif
 #ifndef HGI_XCD_MODE
 #define HGI_XCD_MODE 1      // default of the XCD dealing policy (block_role); HGI_XCD_MODE in the environment overrides it
 #endif
@@ -298,19 +295,19 @@ __device__ __forceinline__ u64 tl_now(bool drain)
         asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
     return t;
 }
-__device__ __forceinline__ void tl_write(u64 *tl, u32 slot, u64 te, u64 t0, u64 t1)
+__device__ __forceinline__ void tl_write(u64 *tl, u64 te, u64 t0, u64 t1)
 {
     const u64 t2 = tl_now(true);
     const u32 hw = __builtin_amdgcn_s_getreg(4 | (31 << 11)), xcc = __builtin_amdgcn_s_getreg(20 | (31 << 11));
     if (tl && threadIdx.x == 0) {
-        u64 *r = tl + 8 * (size_t)slot;      // one row per tile (pool blocks code several)
+        u64 *r = tl + 8 * (size_t)blockIdx.x;
         r[0] = t0; r[1] = t1; r[2] = t2; r[3] = ((u64)xcc << 32) | hw; r[4] = te;
     }
 }
 #define HGI_TL_ENTRY() const u64 tl_te = tl_now(false)      /* first statement of the kernel: the wave is on its CU */
 #define HGI_TL_START() const u64 tl_t0 = tl_now(false)      /* prologue done (arguments, table, tile index): loads go out */
 #define HGI_TL_STAGED() const u64 tl_t1 = tl_now(true)
-#define HGI_TL_END() tl_write(g.timeline, ((g.nedge + 7u) & ~7u) + index, tl_te, tl_t0, tl_t1)
+#define HGI_TL_END() tl_write(g.timeline, tl_te, tl_t0, tl_t1)
 #else
 #define HGI_TL_ENTRY()
 #define HGI_TL_START()
@@ -1340,19 +1337,6 @@ struct TileGrid {
     u32 ex, nf;             // interior tile columns / interior tiles the walk runs on (pair build: pairs)
     u32 tpf, P, nfull, rem_rows;   // tiles per frame; per band; in a frame's whole bands; rows of its last, shorter band
     u32 rr_own, rr_tail0;   // round-robin dealing: blocks per XCD that belong to whole rounds of eight bands; first tile behind them
-    // The tail pool.  Blocks are dealt to the XCDs by the hardware in equal numbers (block b runs on the XCD labelled
-    // b % 8), the XCDs do not run equally fast (the per-block timeline shows their last stores 5-10 us apart on a 350 us
-    // launch, 4-6 on a 100 us one), and blocks that own their tiles cannot help each other.  So the last 8 pool_q
-    // tiles of the list have no owners: they form eight queues (one per XCD label, pool_q tiles each, contiguous in the
-    // list), and the grid ends with pool_q + pool_extra blocks per label that take a tile by TICKET -- one agent-scope
-    // atomic on their own queue's counter, and when that queue is empty on the other queues' counters in turn (stealing).
-    // The blocks of a fast XCD come up earlier, empty their queue and steal; the last blocks of a slow XCD find nothing
-    // and leave.  Nothing loops (a block still codes at most one tile) and nothing waits.  Counters (u32, 32 words = one
-    // 128-byte line apart): pool[32 x] tickets of queue x, pool[32 (8 + x)] blocks of label x that have left,
-    // pool[32 * 16] labels that are done; the last block of the last label zeroes them all, so every launch finds zeros
-    // (graph replays included).  ns = nf - 8 pool_q tiles keep their static owners.
-    u32 ns, pool_q, pool_extra;
-    u32 *pool;
     FastDiv fd_tpf, fd_P, fd_band, fd_rem, fd_ex;
 #ifdef HGI_TIMELINE
     u64 *timeline;          // experiment builds (tools/timeline.py): eight u64 per block -- start, staged, end, hardware id, entry
@@ -1600,41 +1584,8 @@ __device__ __forceinline__ void dec_tile_edge(u8 *buf, const TileCtx &cur, const
 // (A persistent variant -- resident waves pulling tiles from per-XCD atomic counters and prefetching
 // the next tile into registers -- was built and measured: not faster on MI355X, see DESIGN.md
 // "Scheduling".)
-// A pool block's tile: a ticket of its own queue (label x = its XCD); when that queue is empty, ONE ticket of another
-// queue picked from the block id (the first version tried all eight in turn: the surplus blocks' failed scans -- tens
-// of thousands of atomics on eight words -- took longer than the imbalance they were to cure).  false: nothing taken.
-__device__ __forceinline__ bool pool_take(const TileGrid &g, u32 x, u32 &index)
-{
-    index = 0;
-    u32 q = x, t = 0;
-    if (HGI_LANE == 0) t = __hip_atomic_fetch_add(g.pool + 32u * q, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    t = __builtin_amdgcn_readfirstlane(t);
-    if (t >= g.pool_q) {
-        q = (x + 1u + ((blockIdx.x >> 3) % 7u)) & 7u;
-        if (HGI_LANE == 0) t = __hip_atomic_fetch_add(g.pool + 32u * q, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        t = __builtin_amdgcn_readfirstlane(t);
-        if (t >= g.pool_q) return false;
-    }
-    index = g.ns + q * g.pool_q + t;
-    return true;
-}
-// A pool block leaves.  The last block of a label reports the label done; the last label to be done zeroes every counter
-// for the next launch (nobody touches them any more: each block takes its tickets before it counts itself out).
-__device__ __forceinline__ void pool_leave(const TileGrid &g)
-{
-    if (HGI_LANE == 0) {
-        const u32 x = blockIdx.x & 7u, per_label = g.pool_q + g.pool_extra;
-        const u32 d = __hip_atomic_fetch_add(g.pool + 32u * (8u + x), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (d == per_label - 1u) {
-            const u32 e = __hip_atomic_fetch_add(g.pool + 32u * 16u, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (e == 7u)
-                for (u32 i = 0; i <= 16u; ++i) __hip_atomic_store(g.pool + 32u * i, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-    }
-}
-
 struct BlockRole {
-    bool edge, idle, pool;   // pool: one of the looping blocks at the end of the grid that serve the tail pool by ticket
+    bool edge, idle;
     u32 index;       // edge tile index, or position of the interior tile in the XCD-contiguous order
 };
 
@@ -1645,27 +1596,20 @@ __device__ __forceinline__ BlockRole block_role(const TileGrid &g)
     r.edge = b < ne8;
     r.idle = r.edge && b >= g.nedge;
     const u32 fb = b - ne8;
-    r.pool = !r.edge && fb >= g.ns;
-    r.index = r.edge ? b : range_first(g.ns, fb & 7u) + (fb >> 3);
-    if (r.pool) {      // no owner: a ticket (ns is a multiple of eight, so fb & 7 is still the XCD label)
-        u32 index;
-        r.idle = !pool_take(g, fb & 7u, index);
-        r.index = index;
-        return r;
-    }
+    r.index = r.edge ? b : range_first(g.nf, fb & 7u) + (fb >> 3);
     // Which tiles the eight XCDs work on at one time (speed only; g.xmode, host policy xcd_mode()).  0: each XCD walks its
     // own contiguous eighth of the band-ordered list -- eight places an eighth of the batch apart, a power-of-two distance
     // on power-of-two frames.  1: whole bands dealt round-robin, so the XCDs work on eight CONSECUTIVE bands (16384^2:
     // -10 % encode, -9 % decode; 64 x 4096^2: -1.5 ... -1.8 %; profiles/r03_ab_xcd.txt); what is left after the last
     // multiple of eight bands is split contiguously as in mode 0.  (finish_grid() clears xmode when a frame's rows do not
     // divide into whole bands.)
-    if (!r.edge && !r.pool && g.xmode == 1) {
+    if (!r.edge && g.xmode == 1) {
         const u32 x = fb & 7u, sq = fb >> 3;
         if (sq < g.rr_own) {
             const u32 round = fdiv(sq, g.fd_P);
             r.index = (round * 8u + x) * g.P + (sq - round * g.P);
         } else {
-            r.index = g.rr_tail0 + range_first(g.ns - g.rr_tail0, x) + (sq - g.rr_own);
+            r.index = g.rr_tail0 + range_first(g.nf - g.rr_tail0, x) + (sq - g.rr_own);
         }
     }
     return r;
@@ -1695,13 +1639,9 @@ __global__ __launch_bounds__(NL * NWAVES) __attribute__((amdgpu_waves_per_eu(HGI
 #else
     const BlockRole role = block_role(g);
 #endif
-    if (role.idle || (HGI_PAIR && role.edge && wv)) {
-        if (role.pool) pool_leave(g);
-        return;
-    }
+    if (role.idle || (HGI_PAIR && role.edge && wv)) return;
     if (!role.edge) {
-        const u32 index = role.index;
-        TileCtx cur = fast_ctx(index, src, dst, f, g, (aligned & 4u) ? 3u : 0u, nullptr, wv);
+        TileCtx cur = fast_ctx(role.index, src, dst, f, g, (aligned & 4u) ? 3u : 0u, nullptr, wv);
         Stage st;
         SeedRegs seeds;
         HGI_MARK("stage_issue");
@@ -1724,7 +1664,6 @@ __global__ __launch_bounds__(NL * NWAVES) __attribute__((amdgpu_waves_per_eu(HGI
         dec_tile_fast<INTERP>(buf, cur, st.o, k, W, H);
         HGI_MARK("end");
         HGI_TL_END();
-        if (role.pool) pool_leave(g);
         return;
     }
     // ragged tile (body crosses the image edge), unaligned rows, or offsets beyond 32 bits: every access checked
@@ -1860,18 +1799,14 @@ __global__ __launch_bounds__(NL * NWAVES) __attribute__((amdgpu_waves_per_eu(WRE
 #else
     const BlockRole role = block_role(g);
 #endif
-    if (role.idle || (HGI_PAIR && role.edge && wv)) {
-        if (role.pool) pool_leave(g);
-        return;
-    }
+    if (role.idle || (HGI_PAIR && role.edge && wv)) return;
     // The table entry of this lane is a VECTOR load from the kernel-argument segment (the index is the lane): a trip to L2
     // or beyond.  Done first, the whole prologue stalled on it (the timeline build showed 1.4-1.8 us of prologue per
     // encode tile against 0.5-0.7 for decode: tools/timeline.py).  It is issued BEHIND the tile's staging loads instead
     // and lands with them -- the table is first needed after staging has been committed to LDS anyway.
     u32 lutv = 0;
     if (!role.edge) {
-        const u32 index = role.index;
-        TileCtx cur = fast_ctx(index, src, dst, f, g, (aligned & 4u) ? 3u : 0u, WREC ? rec : nullptr, wv);
+        TileCtx cur = fast_ctx(role.index, src, dst, f, g, (aligned & 4u) ? 3u : 0u, WREC ? rec : nullptr, wv);
         Stage st;
         SeedRegs seeds;
         HGI_MARK("stage_issue");
@@ -1905,7 +1840,6 @@ __global__ __launch_bounds__(NL * NWAVES) __attribute__((amdgpu_waves_per_eu(WRE
         enc_tile_fast<INTERP, IDENT, WREC>(buf, rbuf, slut, cur, st.o, k, W, H);
         HGI_MARK("end");
         HGI_TL_END();
-        if (role.pool) pool_leave(g);
         return;
     }
     const Tile tl = edge_tile(role.index, g);
@@ -2027,31 +1961,14 @@ inline void finish_grid(TileGrid &g)
     g.fd_band = make_fastdiv(g.band);
     g.fd_rem = make_fastdiv(g.rem_rows);
     g.fd_ex = make_fastdiv(g.ex);
-    if (g.pool == nullptr || HGI_PAIR || (u64)8 * g.pool_q >= g.nf) g.pool_q = g.pool_extra = 0;
-    g.ns = g.nf - 8u * g.pool_q;
     g.rr_own = g.rr_tail0 = 0;
-    if (g.xmode != 1 || HGI_PAIR || g.rem_rows != 0 || g.P == 0 || g.ns == 0) {
+    if (g.xmode != 1 || HGI_PAIR || g.rem_rows != 0 || g.P == 0 || g.nf == 0) {
         g.xmode = 0;
     } else {
-        const u32 nb8 = (g.ns / g.P) & ~7u;          // bands (of the statically owned part) in whole rounds of eight
+        const u32 nb8 = (g.nf / g.P) & ~7u;          // bands in whole rounds of eight
         g.rr_own = (nb8 >> 3) * g.P;
         g.rr_tail0 = nb8 * g.P;
     }
-}
-
-// Tail pool of a launch (TileGrid::pool*): `waves` = tiles resident per CU.  Launches at least four rounds of resident
-// tiles deep get a pool of 1.5 rounds (HGI_POOL in the environment: its size in per cent of a round, 0 = no pool;
-// experiments) and, per XCD label, extra blocks worth 2 % of that label's share of the whole launch.
-inline void plan_pool(TileGrid &g, u32 *counters, int waves, bool allowed)
-{
-    static const int pct = getenv("HGI_POOL") ? atoi(getenv("HGI_POOL")) : HGI_POOL_DEFAULT;
-    g.pool = nullptr;
-    g.pool_q = g.pool_extra = 0;
-    const u64 round = (u64)256 * (u64)(waves > 0 ? waves : 1);
-    if (!allowed || !counters || pct <= 0 || (u64)g.nfast < 4 * round || (g.nfast & 7u)) return;
-    g.pool = counters;
-    g.pool_q = (u32)(round * (u64)pct / 100 / 8);
-    g.pool_extra = g.nfast / 8 / 50 + 1;
 }
 
 // Dynamic LDS of a launch padded so that at most `waves` blocks fit a CU (160 KiB of LDS): a launch only a few rounds of
@@ -2074,7 +1991,7 @@ inline u32 xcd_mode()
 
 #ifdef HGI_FUSED_DECODE
 hipError_t HGI_TILED(launch_decode_fused)(const uint8_t *grid, uint8_t *img, const Frames &f, uint32_t k, int interp,
-                                          const Seeds *seeds, hipStream_t s, uint32_t row_limit, uint32_t *pool_counters)
+                                          const Seeds *seeds, hipStream_t s, uint32_t row_limit)
 {
     FusedGeom r = fused_geom(grid, img, f, row_limit);
     if (!r.ok || k < 1 || k > (u32)MAXK) return hipErrorInvalidValue;
@@ -2089,14 +2006,6 @@ hipError_t HGI_TILED(launch_decode_fused)(const uint8_t *grid, uint8_t *img, con
     r.g.reverse = dec_reverse ? 1u : 0u;
     r.g.band = band_rows(f, false);
     r.g.xmode = xcd_mode();
-    static const int dec_waves_forced = getenv("HGI_DEC_WAVES") ? atoi(getenv("HGI_DEC_WAVES")) : -1;
-    // A decode between one and eight rounds of resident tiles deep (8 192 ... 65 536 tiles: a lone 16384^2 frame has 32 768)
-    // runs with 20 tiles per CU instead of the 32 its LDS allows: the rate is the same down to 16 (round 1, and
-    // profiles/r03_waves_sweep.txt: 101.3 us at 32, 99.1 at 20, 98.5 at 16, 109.8 at 12), the tile lifetime -- what filling
-    // and draining the chip costs -- shorter.  (The encoder needs all 20 it can get: 98 us, 106 at 16.)
-    const u64 tiles = (u64)r.g.nfast + r.g.nedge;
-    const int dec_waves = dec_waves_forced >= 0 ? dec_waves_forced : (tiles >= 8192 && tiles < 65536 ? 20 : 0);
-    plan_pool(r.g, pool_counters, dec_waves > 0 ? dec_waves : 32, row_limit == 0);
     finish_grid(r.g);
     const TileGrid &g = r.g;
     if (seeds && k < (uint32_t)kSeededMinLevels) return hipErrorInvalidValue;      // one lane per lattice point (seed_issue)
@@ -2106,9 +2015,16 @@ hipError_t HGI_TILED(launch_decode_fused)(const uint8_t *grid, uint8_t *img, con
     if (inline_seeds && (TH != 64 || k != 6 || sd.stride < 1 || sd.stride > 2)) return hipErrorInvalidValue;
     const dim3 b(NL * NWAVES);
     const int nh = k >= 2 ? (int)k : 1;
+    // A decode between one and eight rounds of resident tiles deep (8 192 ... 65 536 tiles: a lone 16384^2 frame has 32 768)
+    // runs with 20 tiles per CU instead of the 32 its LDS allows: the rate is the same down to 16 (round 1, and
+    // profiles/r03_waves_sweep.txt: 101.3 us at 32, 99.1 at 20, 98.5 at 16, 109.8 at 12), the tile lifetime -- what filling
+    // and draining the chip costs -- shorter.  (The encoder needs all 20 it can get: 98 us, 106 at 16.)
+    static const int dec_waves_forced = getenv("HGI_DEC_WAVES") ? atoi(getenv("HGI_DEC_WAVES")) : -1;
+    const u64 tiles = (u64)g.nfast + g.nedge;
+    const int dec_waves = dec_waves_forced >= 0 ? dec_waves_forced : (tiles >= 8192 && tiles < 65536 ? 20 : 0);
     const size_t lds = lds_for_waves((size_t)buf_bytes(nh) * NWAVES, dec_waves);
     if (HGI_PAIR && (g.full_x & 1u)) return hipErrorInvalidValue;      // the experiment build pairs x-adjacent interior tiles
-    const dim3 blocks(((g.nedge + 7u) & ~7u) + g.ns + 8u * (g.pool_q + g.pool_extra));
+    const dim3 blocks(((g.nedge + 7u) & ~7u) + g.nfast / NWAVES);
 #define HGI_DEC(I, SE) hipLaunchKernelGGL((k_dec_tiles<I, SE, TH>), blocks, b, lds, s, grid, img, f, k, sd, g, r.aligned)
 #define HGI_DEC_I(I)                                                     \
     do {                                                                 \
@@ -2137,7 +2053,7 @@ hipError_t static_lds_is_empty(const void *kernel)
 
 hipError_t HGI_TILED(launch_encode_fused)(const uint8_t *img, uint8_t *grid, const Frames &f, uint32_t k, int interp,
                                           const Lut256 &lut, bool ident, const Seeds *seeds, hipStream_t s, uint32_t row_limit, uint8_t *rec_out,
-                                          const View *view, uint32_t *pool_counters)
+                                          const View *view)
 {
     // through a view `img` is the parent frame: the geometry checks below concern the plane (grid, rec_out); the parent only
     // has to be addressable with 32-bit offsets
@@ -2156,7 +2072,6 @@ hipError_t HGI_TILED(launch_encode_fused)(const uint8_t *img, uint8_t *grid, con
     if (rec_out && (seeds || !(r.aligned & 2u))) return hipErrorNotSupported;
     r.g.band = band_rows(f, true);
     r.g.xmode = xcd_mode();
-    plan_pool(r.g, pool_counters, 20, row_limit == 0 && !rec_out);
     finish_grid(r.g);
     const TileGrid &g = r.g;
     if (seeds && k < (uint32_t)kSeededMinLevels) return hipErrorInvalidValue;      // one lane per lattice point (seed_issue)
@@ -2166,7 +2081,7 @@ hipError_t HGI_TILED(launch_encode_fused)(const uint8_t *img, uint8_t *grid, con
     static const int enc_waves = getenv("HGI_ENC_WAVES") ? atoi(getenv("HGI_ENC_WAVES")) : 0;
     const size_t lds = lds_for_waves(((size_t)buf_bytes(nh) + ((rbuf_bytes(nh) + 15) & ~15)) * NWAVES + 256 + (view ? (size_t)(TH / 2) * TW : 0), enc_waves);
     if (HGI_PAIR && (g.full_x & 1u)) return hipErrorInvalidValue;      // the experiment build pairs x-adjacent interior tiles
-    const dim3 blocks(((g.nedge + 7u) & ~7u) + g.ns + 8u * (g.pool_q + g.pool_extra));
+    const dim3 blocks(((g.nedge + 7u) & ~7u) + g.nfast / NWAVES);
     // lut_at() addresses the table from LDS offset 0: only valid while the kernel has no static LDS in front of its
     // dynamic segment.  Checked once per instantiation on the host; a build that breaks it fails here, not on the device.
 #define HGI_ENC(I, ID, SE)                                                                                        \

@@ -68,14 +68,13 @@ hipError_t launch_encode_level(uint8_t *rec, uint8_t *grid, const Frames &f, uin
 // above which tile rows are launched, 0 = all -- bands of a frame that is still being uploaded; rec_out: the encoder
 // also writes its reconstruction there (unseeded launches on the check-free paths only, else hipErrorNotSupported);
 // view (with rec_out only): `img` is the PARENT frame and the launch codes its lattice plane -- f describes the plane --
-// which must consist of whole tiles (else hipErrorNotSupported); pool_counters: 4 KiB of zeroed device memory owned by
-// the caller's context (tail pool of large launches, hgi_fused_impl.h TileGrid::pool; nullptr: no pool))
+// which must consist of whole tiles (else hipErrorNotSupported))
 #define HGI_DECLARE_FUSED(TH)                                                                                      \
     hipError_t launch_decode_fused_##TH(const uint8_t *grid, uint8_t *img, const Frames &f, uint32_t k, int interp, \
-                                        const Seeds *seeds, hipStream_t s, uint32_t row_limit, uint32_t *pool_counters); \
+                                        const Seeds *seeds, hipStream_t s, uint32_t row_limit);                    \
     hipError_t launch_encode_fused_##TH(const uint8_t *img, uint8_t *grid, const Frames &f, uint32_t k, int interp, \
                                         const Lut256 &lut, bool lut_is_identity, const Seeds *seeds, hipStream_t s, \
-                                        uint32_t row_limit, uint8_t *rec_out, const View *view, uint32_t *pool_counters);
+                                        uint32_t row_limit, uint8_t *rec_out, const View *view);
 HGI_DECLARE_FUSED(64)
 HGI_DECLARE_FUSED(32)
 HGI_DECLARE_FUSED(16)
