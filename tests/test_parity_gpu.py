@@ -121,7 +121,8 @@ def test_criterion_bench_image(ctxs, oracle, golden, path):
 
 @pytest.mark.parametrize("w,h,levels", [(256, 64, 1), (256, 64, 6), (512, 128, 5), (272, 80, 4), (16, 16, 4),
                                         (1040, 200, 3), (255, 63, 4), (257, 65, 6), (300, 70, 7), (64, 700, 9),
-                                        (1, 1, 3), (1, 300, 5), (300, 1, 5), (1600, 520, 12), (4096, 64, 2)])
+                                        (1, 1, 3), (1, 300, 5), (300, 1, 5), (1600, 520, 12), (4096, 64, 2),
+                                        (1280, 640, 8), (1001, 333, 8), (2000, 300, 7), (640, 1280, 8)])
 @pytest.mark.parametrize("path", ["fused", "levelwise"])
 def test_random_shapes_and_tables(ctxs, oracle, w, h, levels, path):
     """Tile-edge, ragged and deeper-than-tile (levels > 6: lattice recursion) shapes with noise input
@@ -509,7 +510,7 @@ def test_fuzz_batches_against_oracle(H, ctxs, oracle):
         else:              # anything
             W, Hh = int(rng.integers(1, 700)), int(rng.integers(1, 400))
         B = int(rng.integers(1, 4))
-        levels = int(rng.choice([0, 1, 2, 3, 4, 4, 5, 6, 7, 9, 13]))
+        levels = int(rng.choice([0, 1, 2, 3, 4, 4, 5, 6, 7, 8, 9, 13]))
         interp = int(rng.integers(0, 2))
         lut = tables[int(rng.integers(0, 5))] if rng.integers(0, 3) else rng.integers(0, 256, 256, dtype=np.uint8)
         pad = int(rng.choice([0, 0, 16, 48, 5, 4096]))
