@@ -28,6 +28,8 @@ case " $PASSES " in *" pfine "*)
   ( cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/pfine" -- python3 "$OLDPWD/tools/pfine.py" ) > "$OUT/pfine.log" 2>&1
   echo "pfine rc=$?" >> "$OUT/passes.log";;
 esac
+# C4 (one 16384^2 frame, level 8) has a script of its own: tools/c4_profile.sh <tag>_c4 -> gpurun_out/prof/<tag>_c4/summary.md
+case " $PASSES " in *" c4 "*) tools/c4_profile.sh "${TAG}_c4" > "$OUT/c4.log" 2>&1; echo "c4 rc=$?" >> "$OUT/passes.log";; esac
 python3 tools/summarize_prof.py "$OUT" > "$OUT/summary.md" 2>"$OUT/summarize.err"
 python3 tools/summarize_prof.py "$OUT" --traffic 64 4096 4 > "$OUT/traffic.json" 2>>"$OUT/summarize.err"
 cat "$OUT/passes.log"
