@@ -547,8 +547,19 @@ class Codec:
             err = np.zeros(1, np.uint8)
             lut = np.zeros(256, np.uint8)
             _ffi.check(L.hgi_linear_lut(3, lut.ctypes.data, err.ctypes.data))
-            img = torch.empty((W, W), dtype=torch.uint8, device=self.dev)
-            grid, out = torch.empty_like(img), torch.empty_like(img)
+            # three planes from the library's placement allocator, like the headline's frame stacks (planes of 256 MiB are
+            # allocated at the probe's 512 MiB so that they can be placed: include/hgi.h)
+            c4_planes = None
+            if self.args.placement == "planes":
+                try:
+                    c4_planes = H.Planes(self.ctx, n, 3)
+                    img, grid, out = (c4_planes.torch(i, (W, W)) for i in range(3))
+                except Exception:
+                    c4_planes = None
+            if c4_planes is None:
+                img = torch.empty((W, W), dtype=torch.uint8, device=self.dev)
+                grid, out = torch.empty_like(img), torch.empty_like(img)
+            res["planes_separated"] = bool(c4_planes is not None and c4_planes.separated)
             _ffi.check(L.hgi_synth_u8_dev(self.ctx.handle, _ffi.SYNTH_RAMP, SEED0 + 4, 0, W, W, img.data_ptr(), 1, n))
             self.ctx.reserve(W, W, 8, 1)
 
@@ -592,6 +603,8 @@ class Codec:
                         "note": "per CALL (a deep pyramid is a chain of launches: lattice plane, then the seeded tile launch); "
                                 "decode reads the grid the encode before it has just written, as in the bench step"})
             del img, grid, out
+            if c4_planes is not None:
+                c4_planes.close()
         except Exception as e:      # an extra: never let it cost the line
             res["error"] = "%s: %s" % (type(e).__name__, e)
         self._restore()

@@ -202,8 +202,10 @@ HGI_API hgi_status hgi_huffman_plan(const uint64_t hist[286], uint8_t lens[286],
 /* 30-50 ms in all; when the device's free memory is one huge block, transient allocations of */
 /* up to ~60x `bytes` and several seconds -- set HGI_NO_PLACEMENT=1 to skip the search):      */
 /* *separated (optional) is 1 when every neighbouring pair was seen to be in different        */
-/* regions, 0 when that could not be established (planes below 512 MiB are not probed: such   */
-/* streams live in the Infinity Cache) -- the planes are valid either way.  Call it while the */
+/* regions, 0 when that could not be established -- the planes are valid either way.  Planes   */
+/* below 128 MiB are not probed (such streams live in the 256 MiB Infinity Cache); planes of   */
+/* 128 ... 512 MiB are allocated at 512 MiB each so that they can be (a launch over two of     */
+/* them no longer fits that cache: a lone 16384 x 16384 frame gains 2-3 %).  Call it while the  */
 /* device is otherwise idle: it measures.                                                      */
 HGI_API hgi_status hgi_planes_alloc(hgi_ctx *ctx, size_t bytes, uint32_t count, void **planes, int *separated);
 HGI_API hgi_status hgi_planes_free(hgi_ctx *ctx, uint32_t count, void **planes);

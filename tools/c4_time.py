@@ -11,7 +11,8 @@ LEVELS = int(os.environ.get("C4_LEVELS", "8"))
 lut = np.zeros(256, np.uint8); err = np.zeros(1, np.uint8)
 _ffi.check(L.hgi_linear_lut(3, lut.ctypes.data, err.ctypes.data))
 F = int(os.environ.get("C4_FRAMES", "1"))
-planes = H.Planes(ctx, F * n, 3)
+PLANE = max(F * n, int(os.environ.get("C4_PLANE_BYTES", "0")))      # larger planes are probed and placed in different HBM regions (>= 512 MiB)
+planes = H.Planes(ctx, PLANE, 3)
 img, grid, out = (planes.torch(i, (F, Hh, W)) for i in range(3))
 _ffi.check(L.hgi_synth_u8_dev(ctx.handle, _ffi.SYNTH_RAMP, 0x48474933 + 4, 0, W, Hh, img.data_ptr(), F, n))
 def enc(): _ffi.check(L.hgi_encode_u8_dev(ctx.handle, img.data_ptr(), W, Hh, LEVELS, 1, lut.ctypes.data, grid.data_ptr(), F, n))
@@ -32,5 +33,5 @@ def alone(fn):
     return a.elapsed_time(b) / reps * 1e3
 te1, td1 = alone(enc), alone(dec)
 hg = hashlib.sha256(grid.cpu().numpy().tobytes()).hexdigest()[:16]; ho = hashlib.sha256(out.cpu().numpy().tobytes()).hexdigest()[:16]
-print("k_enc=%s k_dec=%s  %d x %dx%d L%d: encode %.1f us (%.0f GB/s)  decode %.1f us (%.0f GB/s)  | back to back: encode %.1f decode %.1f us | grid %s out %s" % (
-    os.environ.get("HGI_DEEP_K_ENC", "6"), os.environ.get("HGI_DEEP_K_DEC", "6"), F, W, Hh, LEVELS, te, 2 * F * n / te / 1e3, td, 2 * F * n / td / 1e3, te1, td1, hg, ho))
+print("separated=%s k_enc=%s k_dec=%s  %d x %dx%d L%d: encode %.1f us (%.0f GB/s)  decode %.1f us (%.0f GB/s)  | back to back: encode %.1f decode %.1f us | grid %s out %s" % (
+    planes.separated, os.environ.get("HGI_DEEP_K_ENC", "6"), os.environ.get("HGI_DEEP_K_DEC", "6"), F, W, Hh, LEVELS, te, 2 * F * n / te / 1e3, td, 2 * F * n / td / 1e3, te1, td1, hg, ho))
