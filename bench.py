@@ -548,7 +548,7 @@ class Codec:
             lut = np.zeros(256, np.uint8)
             _ffi.check(L.hgi_linear_lut(3, lut.ctypes.data, err.ctypes.data))
             # three planes from the library's placement allocator, like the headline's frame stacks (planes of 256 MiB are
-            # allocated at the probe's 512 MiB so that they can be placed: include/hgi.h)
+            # allocated at the probe's 1 GiB so that they can be placed: include/hgi.h)
             c4_planes = None
             if self.args.placement == "planes":
                 try:

@@ -204,7 +204,7 @@ HGI_API hgi_status hgi_huffman_plan(const uint64_t hist[286], uint8_t lens[286],
 /* *separated (optional) is 1 when every neighbouring pair was seen to be in different        */
 /* regions, 0 when that could not be established -- the planes are valid either way.  Planes   */
 /* below 128 MiB are not probed (such streams live in the 256 MiB Infinity Cache); planes of   */
-/* 128 ... 512 MiB are allocated at 512 MiB each so that they can be (a launch over two of     */
+/* 128 MiB ... 1 GiB are allocated at 1 GiB each so that they can be (a launch over two of     */
 /* them no longer fits that cache: a lone 16384 x 16384 frame gains 2-3 %).  Call it while the  */
 /* device is otherwise idle: it measures.                                                      */
 HGI_API hgi_status hgi_planes_alloc(hgi_ctx *ctx, size_t bytes, uint32_t count, void **planes, int *separated);

@@ -1228,9 +1228,10 @@ hgi_status hgi_planes_alloc(hgi_ctx *c, size_t bytes, uint32_t count, void **pla
     if (count == 0 || bytes == 0) return HGI_OK;
     // Planes of 128 ... 512 MiB: a launch that reads one and writes the next (2 x 256 MiB for a lone 16384^2 frame) no longer
     // fits the 256 MiB Infinity Cache, so placement matters to it (16384^2 level 8: encode 101 -> 98.3 us, decode 99.8 -> 97.5,
-    // profiles/r03_c4_placement.txt) -- but a probe over less than 512 MiB would measure that cache, not the regions.  Such
-    // planes are allocated at the probe's size; the caller uses their first `bytes`.
-    if (bytes >= ((size_t)128 << 20) && bytes < kProbeMinBytes && count > 1 && !getenv("HGI_NO_PLACEMENT")) bytes = kProbeMinBytes;
+    // profiles/r03_c4_placement.txt) -- but a probe over less than 512 MiB would measure that cache, not the regions, and at
+    // exactly 512 MiB the signal is too weak to call (separated = 0 in every run).  Such planes are allocated at 1 GiB, the
+    // size the probe was calibrated on; the caller uses their first `bytes`.
+    if (bytes >= ((size_t)128 << 20) && bytes < ((size_t)1 << 30) && count > 1 && !getenv("HGI_NO_PLACEMENT")) bytes = (size_t)1 << 30;
     HIP_TRY(hipSetDevice(c->device));
     std::vector<void *> bufs, spacers;     // candidate planes; allocations that only push the driver onwards
     void *ref = nullptr;                   // one allocation whose two halves are the same-region yardstick
