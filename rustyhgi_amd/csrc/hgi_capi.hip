@@ -46,6 +46,15 @@ inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 #ifndef HGI_ENTROPY_GROUP_MIB_DEFAULT
 #define HGI_ENTROPY_GROUP_MIB_DEFAULT 256
 #endif
+// The shallowest pyramid that runs as four fused levels + cone (cone_up()).  Six: a lone frame then keeps the small tiles and
+// the short chain of a four-level launch (1920 x 1080 level 6: 10.6 / 6.5 -> 7.3 / 5.6 us), a batch is unchanged (64 x 4096^2:
+// +0.4 / -0.8 %); at five levels nothing is gained in either (profiles/r03_cone_levels.txt).
+#ifndef HGI_CONE_MIN_ENC_DEFAULT
+#define HGI_CONE_MIN_ENC_DEFAULT 6
+#endif
+#ifndef HGI_CONE_MIN_DEC_DEFAULT
+#define HGI_CONE_MIN_DEC_DEFAULT 6
+#endif
 #ifndef HGI_TILE16_MAX_DEFAULT
 #define HGI_TILE16_MAX_DEFAULT 600    // an ENCODE of at most this many 32-row tiles runs on 16-row tiles instead (profiles/r03_sizes.txt: 1920 x 1080 is 510)
 #endif
@@ -136,9 +145,22 @@ uint32_t fused_depth(uint32_t w, uint32_t h, uint32_t levels, bool encode)
     return (uint32_t)kFusedMaxLevels;
 }
 
+// Pyramids of HGI_CONE_MIN_* ... 8 levels run as ONE launch of the tile kernel at four fused levels, which rebuilds the
+// 1 ... 4 levels above a tile for itself (hgi_fused_impl.h, cone_*): no lattice planes, no scratch, no launch in front.
+// Returns the levels above the tile, 0 when the pyramid is not run that way.  HGI_CONE=0 in the environment keeps the
+// older chains (tests, experiments); HGI_CONE_MIN_ENC / HGI_CONE_MIN_DEC move the lower end.
+uint32_t cone_up(uint32_t levels, bool encode)
+{
+    static const bool off = getenv("HGI_CONE") && atoi(getenv("HGI_CONE")) == 0;
+    static const int lo[2] = {getenv("HGI_CONE_MIN_DEC") ? atoi(getenv("HGI_CONE_MIN_DEC")) : HGI_CONE_MIN_DEC_DEFAULT,
+                              getenv("HGI_CONE_MIN_ENC") ? atoi(getenv("HGI_CONE_MIN_ENC")) : HGI_CONE_MIN_ENC_DEFAULT};
+    const int m = lo[encode ? 1 : 0] < 5 ? 5 : lo[encode ? 1 : 0];
+    return (!off && levels >= (uint32_t)m && levels <= 8u) ? levels - 4u : 0u;
+}
+
 size_t ws_need_decode(uint32_t w, uint32_t h, uint32_t levels, size_t batch)
 {
-    if (levels <= (uint32_t)kFusedMaxLevels) return 0;
+    if (levels <= (uint32_t)kFusedMaxLevels || cone_up(levels, false)) return 0;
     const uint32_t k = fused_depth(w, h, levels, false);
     const SubGeom g = sub_geom(w, h, k);
     return 2 * plane_bytes(g, batch) + ws_need_decode(g.sw, g.sh, levels - k, batch);
@@ -146,7 +168,7 @@ size_t ws_need_decode(uint32_t w, uint32_t h, uint32_t levels, size_t batch)
 
 size_t ws_need_encode(uint32_t w, uint32_t h, uint32_t levels, size_t batch)
 {
-    if (levels <= (uint32_t)kFusedMaxLevels) return 0;
+    if (levels <= (uint32_t)kFusedMaxLevels || cone_up(levels, true)) return 0;
     const uint32_t k = fused_depth(w, h, levels, true);
     const SubGeom g = sub_geom(w, h, k);
     return 3 * plane_bytes(g, batch) + ws_need_encode(g.sw, g.sh, levels - k, batch) + ws_need_decode(g.sw, g.sh, levels - k, batch);
@@ -255,6 +277,12 @@ hgi_status encode_impl(hgi_ctx *c, const uint8_t *img, uint32_t w, uint32_t h, u
             HIP_TRY(launch_encode_level(rec, grid, f, levels - level - 1, interp, l, c->stream));
         return HGI_OK;
     }
+    if (const uint32_t up = cone_up(levels, true)) {
+        const SubGeom g = sub_geom(w, h, 4);
+        Seeds sd = {nullptr, nullptr, g.sw, g.sh, (uint64_t)up};
+        HIP_TRY(launch_encode_fused(img, grid, f, 4, interp, l, is_identity(lut), &sd, c->stream));
+        return HGI_OK;
+    }
     const uint32_t k = fused_depth(w, h, levels, true);
     if (levels > k) {
         // Deeper pyramid: the lattice = 0 (mod 2^k) is itself an HGI image with levels-k levels
@@ -317,6 +345,12 @@ hgi_status decode_impl(hgi_ctx *c, const uint8_t *grid, uint32_t w, uint32_t h, 
         HIP_TRY(launch_seed(grid, img, f, levels, c->stream));   // src/decoder.rs:22-28
         for (uint32_t level = 0; level < levels; ++level)        // src/decoder.rs:30
             HIP_TRY(launch_decode_level(grid, img, f, levels - level - 1, interp, c->stream));
+        return HGI_OK;
+    }
+    if (const uint32_t up = cone_up(levels, false)) {
+        const SubGeom g = sub_geom(w, h, 4);
+        Seeds sd = {nullptr, nullptr, g.sw, g.sh, (uint64_t)up};
+        HIP_TRY(launch_decode_fused(grid, img, f, 4, interp, &sd, c->stream));
         return HGI_OK;
     }
     const uint32_t k = fused_depth(w, h, levels, false);

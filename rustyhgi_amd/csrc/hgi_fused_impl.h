@@ -116,6 +116,9 @@ static_assert(TH != 64 || 18 * (buf_bytes(4) + rbuf_bytes(4) + 256) <= 160 * 102
 #define HGI_ABL 0   // timing experiments: 1 no coarse levels, 2 no fine arithmetic, 4 no halo cells, 8 no sub==2 level,
                     // 16 no halo-column loads, 32 no halo-row loads
 #endif
+#ifndef HGI_CONE_FIRST
+#define HGI_CONE_FIRST 0    // the cone's load goes out in front of the tile's staging loads (1) or behind them (0)
+#endif
 #ifndef HGI_XCD_MODE
 #define HGI_XCD_MODE 1      // default of the XCD dealing policy (block_role); HGI_XCD_MODE in the environment overrides it
 #endif
@@ -1516,6 +1519,152 @@ __device__ __forceinline__ SeedRegs inline_seed_finish(const InlineSeeds &s, con
     return r;
 }
 
+// ---- seeds rebuilt in the tile kernel, general form: the cone above a k = 4 tile (encode AND decode) ---------------
+// A pyramid of 5 ... 8 levels run with four fused levels has `up` = 1 ... 4 levels above the tile; their pixels are the
+// stride-16 lattice, a sw x sh plane with a pyramid of its own, and the tile needs reconstruction (encode: and residual)
+// of (TW / 16 + 2) x (TH / 16 + 2) of its points -- seed_issue()'s layout.  What those depend on is a CONE: a point that
+// is new at plane step 2s takes its corners from the multiples of 2s around it (src/interpolator.rs:57-91), so level by
+// level the set of points halves in density and grows by at most one step at its far side (and down to the aligned
+// origin at the near side).  In plane coordinates, with the tile's origin (A, B) = (X0 / 16, Y0 / 16) and s = 2^t:
+//     box_t = [A & ~(s - 1), ... + (nx_t - 1) s] x [B & ~(s - 1), ...],    nx = 10, 6, 4, 3, 3;  ny = 6, 4, 3, 3, 3 (TH = 64)
+// -- 60 points of the tile's own (level 0) and 24 + 12 + 9 + 9 = 54 above them.  Level 0 lies in the tile's halo frame: its
+// input bytes are staged anyway.  The 54 others get ONE lane each (lane - cone_off(t) is the point's index in level t),
+// which fetches the point's byte (source pixel when encoding, grid byte when decoding) with a single load instruction
+// behind the tile's staging loads -- or takes it from the staged frame when the point lies in it -- and prepares its
+// indices while the loads fly.  After staging the wave walks the levels from the base down: the lanes of a level read
+// their four corners of the coarser level from a small LDS array, predict, code (src/encoder.rs:46-65) or add the
+// residual (src/decoder.rs:32-41), and write their point to the array; last the 60 seeds, which stay in registers.
+// Neighbouring tiles recompute the same points -- pure functions of the input -- so nothing is exchanged and no launch
+// runs in front of the tile kernel (a 16384^2 level-8 encode had a 9 us plane launch there).  Points outside the plane
+// are 0, which is the out-of-image rule of the corners.
+constexpr int kConeMaxUp = 4;
+__host__ __device__ constexpr int cone_n(int tile_px, int t)      // points per dimension at stride 2^t (worst case over tile positions)
+{
+    const int c = tile_px >> 4;      // the tile origin is a multiple of c plane points
+    int n = c + 2;
+    for (int i = 0; i < t; ++i) n = (c % (2 << i) == 0 ? (n - 1) / 2 : n / 2) + 2;      // origin / 2^i even, or maybe odd
+    return n;
+}
+__host__ __device__ constexpr int cone_off(int t)      // first entry (= first lane) of level t, t = 1 .. kConeMaxUp + 1 (level 0 stays in registers)
+{
+    int o = 0;
+    for (int i = 1; i < t; ++i) o += cone_n(TW, i) * cone_n(TH, i);
+    return o;
+}
+// The arrays -- one byte of reconstruction per point and, encoding, one byte of residual -- live in the halo-column slots
+// of offsets 32 and 64, which a four-level tile never touches after staging (buf: reconstruction, rbuf: residuals): LDS is
+// allocated in 1280-byte granules and the encoder's 7 648 bytes leave 32 to spare -- an array of its own costs three of 21 tiles per CU.
+static_assert(cone_n(TW, 0) * cone_n(TH, 0) <= NL && cone_off(kConeMaxUp + 1) <= NL, "one lane per cone point");
+static_assert(HR == 6 && cone_off(kConeMaxUp + 1) <= 2 * HP && cone_off(kConeMaxUp + 1) <= 2 * HP2, "the cone's arrays fit the two unused halo-column slots");
+__device__ __forceinline__ u8 *cone_rec_array(u8 *buf) { return buf + HCOL + 4 * HP; }
+__device__ __forceinline__ u8 *cone_q_array(u8 *rbuf) { return rbuf + RCOL + 4 * HP2; }
+static_assert(cone_n(TW, 0) == 10 && cone_n(TW, 1) == 6 && cone_n(TW, 2) == 4 && cone_n(TW, 3) == 3 && cone_n(TW, 4) == 3, "cone widths of a 128-pixel tile");
+
+struct ConeLane {
+    u32 v;            // levels >= 1: the lane's input byte (loaded, 0 outside the plane; filled from the frame otherwise)
+    u32 t;            // its level (0: the lane has no point above level 0)
+    u32 src1;         // LDS offset in the staged frame of a level >= 1 point that lies in it (framed1)
+    bool framed1;
+    u32 from1, nx1;   // first corner in R (u32 index) and the pitch of that level's array
+    bool in1, down1;  // inside the plane / a point of the coarser lattice (handed down)
+    u32 src0, from0;  // the same for the lane's seed (level 0, lanes < 10 x ny0)
+    bool on0, in0, down0;
+};
+
+// the corner index of plane point (x, y) of level T in level T + 1's array, whose pitch is nx2
+__device__ __forceinline__ u32 cone_corner(u32 x, u32 y, u32 A, u32 B, u32 T, u32 nx2)
+{
+    const u32 m2 = (2u << T) - 1u;
+    return (((y & ~m2) - (B & ~m2)) >> (T + 1)) * nx2 + (((x & ~m2) - (A & ~m2)) >> (T + 1));
+}
+
+// Index work and the one load; nothing here waits.  fr: the frame (source or grid).
+__device__ __forceinline__ ConeLane cone_issue(const u8 *__restrict__ fr, u32 W, u32 sw, u32 sh, Tile tl, u32 up)
+{
+    constexpr u32 o2 = cone_off(2), o3 = cone_off(3), o4 = cone_off(4), o5 = cone_off(5);
+    constexpr u32 nx0 = cone_n(TW, 0), ny0 = cone_n(TH, 0);
+    const u32 lane = HGI_LANE, A = tl.X0 >> 4, B = tl.Y0 >> 4;
+    ConeLane c;
+    // levels 1 .. 4
+    const u32 t = 1u + (lane >= o2) + (lane >= o3) + (lane >= o4);
+    const u32 first = t == 1 ? 0u : t == 2 ? o2 : t == 3 ? o3 : o4;
+    const u32 nx = t == 1 ? (u32)cone_n(TW, 1) : t == 2 ? (u32)cone_n(TW, 2) : t == 3 ? (u32)cone_n(TW, 3) : (u32)cone_n(TW, 4);
+    const u32 rcp = t == 1 ? 43u : t == 2 ? 64u : 86u;      // (i * rcp) >> 8 == i / nx for nx = 6, 4, 3 and i < 64
+    static_assert(cone_n(TW, 1) == 6 && cone_n(TW, 2) == 4 && cone_n(TW, 3) == 3 && cone_n(TW, 4) == 3, "reciprocals above");
+    const u32 i = lane - first, iy = (i * rcp) >> 8, ix = i - iy * nx, m = (1u << t) - 1u;
+    const u32 x = (A & ~m) + (ix << t), y = (B & ~m) + (iy << t);
+    const bool on = lane < o5 && t <= up;
+    c.t = on ? t : 0u;
+    c.in1 = on && x < sw && y < sh;
+    c.down1 = !((x | y) & (1u << t));
+    c.nx1 = t == 1 ? (u32)cone_n(TW, 2) : (u32)cone_n(TW, 3);      // (level 4 has no coarser array)
+    c.from1 = (t == 1 ? o2 : t == 2 ? o3 : o4) + cone_corner(x, y, A, B, t, c.nx1);
+    const bool framed = x >= A && x < A + nx0 && y >= B && y < B + ny0;
+    c.framed1 = c.in1 && framed;
+    c.src1 = c.framed1 ? (u32)laddr((int)((x - A) << 4), (int)((y - B) << 4)) : 0u;
+    c.v = 0u;
+#ifdef HGI_CONE_ABL      // timing experiments: no load (wrong bytes)
+    if (!(HGI_CONE_ABL & 1))
+#endif
+    if (c.in1 && !framed) c.v = fr[((size_t)y << 4) * W + ((size_t)x << 4)];
+    // level 0: the seeds
+    const u32 by = (lane * 26u) >> 8, bx = lane - by * nx0;      // lane / 10
+    static_assert(nx0 == 10, "reciprocal above");
+    c.on0 = lane < nx0 * ny0;
+    c.in0 = c.on0 && A + bx < sw && B + by < sh;
+    c.down0 = !(((A + bx) | (B + by)) & 1u);      // (B is odd for every other row of 16-row tiles)
+    c.from0 = cone_corner(A + bx, B + by, A, B, 0u, (u32)cone_n(TW, 1));
+    c.src0 = c.on0 ? (u32)laddr((int)(bx << 4), (int)(by << 4)) : 0u;
+    return c;
+}
+
+template <int INTERP, bool ENC, bool IDENT>
+__device__ __forceinline__ void cone_code(u32 v, const u8 *r2, const u8 *q2, u32 nx2, bool down, bool inside, const u8 *slut, u32 &rec, u32 &q)
+{
+    const u32 c00 = r2[0], c01 = r2[nx2], c10 = r2[1], c11 = r2[nx2 + 1];      // (x0,y0) (x0,y1) (x1,y0) (x1,y1)
+    const u32 q00 = ENC ? (u32)q2[0] : 0u;
+    const u32 p = pred1<INTERP>(c00, c01, c10, c11);
+    q = ENC ? quant1<IDENT>(v, p, slut) : v;
+    rec = (p + q) & 255u;
+    if (down) {      // a point of the coarser lattice: handed down
+        rec = c00;
+        q = q00;
+    }
+    if (!inside) rec = q = 0u;
+}
+
+// After staging (and, encoding, after the table is in LDS).  buf / rbuf: the staged planes (rbuf: encode only).
+template <int INTERP, bool ENC, bool IDENT>
+__device__ __forceinline__ SeedRegs cone_finish(const ConeLane &c, u8 *buf, u8 *rbuf, u32 up, const u8 *slut)
+{
+    const u32 lane = HGI_LANE;
+    u8 *R = cone_rec_array(buf), *Q = ENC ? cone_q_array(rbuf) : nullptr;
+    const u32 v1 = c.framed1 ? (u32)buf[(int)c.src1] : c.v;
+    const u32 v0 = c.on0 ? (u32)buf[(int)c.src0] : 0u;
+    if (c.t == up) {      // base samples travel as they are (src/encoder.rs:26-37, src/decoder.rs:22-28); 0 outside
+        R[lane] = (u8)v1;
+        if (ENC) Q[lane] = (u8)v1;
+    }
+    LDS_ORDER();
+    for (u32 T = up - 1u; T >= 1u; --T) {         // (uniform)
+        if (c.t == T) {
+            u32 rec, q;
+            cone_code<INTERP, ENC, IDENT>(v1, R + c.from1, ENC ? Q + c.from1 : nullptr, c.nx1, c.down1, c.in1, slut, rec, q);
+            R[lane] = (u8)rec;
+            if (ENC) Q[lane] = (u8)q;
+        }
+        LDS_ORDER();
+    }
+    SeedRegs r;
+    r.by = (int)((lane * 26u) >> 8);
+    r.bx = (int)lane - r.by * cone_n(TW, 0);
+    r.on = c.on0;
+    r.rec = r.q = 0u;
+    if (c.on0) cone_code<INTERP, ENC, IDENT>(v0, R + c.from0, ENC ? Q + c.from0 : nullptr, (u32)cone_n(TW, 1), c.down0, c.in0, slut, r.rec, r.q);
+    LDS_ORDER();
+    return r;
+}
+
 // One tile of the fast path, out of LDS: levels sub = 2^(k-1) .. 2 in place, then the finest level to HBM.
 template <int INTERP>
 __device__ __forceinline__ void dec_tile_fast(u8 *buf, const TileCtx &cur, const v4u (&odd)[NFINE], u32 k, u32 W, u32 H)
@@ -1619,9 +1768,12 @@ __device__ __forceinline__ BlockRole block_role(const TileGrid &g)
 #define HGI_DEC_WAVES_PER_EU 8
 #endif
 // SEEDED: 0 = the pyramid fits the tile; 1 = seeds from planes coded by earlier launches; 2 = seeds rebuilt in the kernel
-// (k == 6 and at most two levels above: sd.sw x sd.sh is the stride-64 plane, sd.stride carries `up`)
+// (k == 6 and at most two levels above: sd.sw x sd.sh is the stride-64 plane, sd.stride carries `up`); 3 = the same in the
+// general form (cone_*: k == 4, up to four levels above: sd.sw x sd.sh is the stride-16 plane)
+// (that one is allowed 80 registers -- six waves per SIMD, 24 tiles per CU: the cone's bytes are live while the staging loads
+// fly, and the decoder's rate does not depend on occupancy down to 16 tiles per CU, profiles/r03_waves_sweep.txt)
 template <int INTERP, int SEEDED, int TILE_ROWS>   // TILE_ROWS == TH: only there to name the build in profiles
-__global__ __launch_bounds__(NL * NWAVES) __attribute__((amdgpu_waves_per_eu(HGI_DEC_WAVES_PER_EU))) void k_dec_tiles(const u8 *__restrict__ src, u8 *__restrict__ dst, Frames f, u32 k,
+__global__ __launch_bounds__(NL * NWAVES) __attribute__((amdgpu_waves_per_eu(SEEDED == 3 ? HGI_DEC_WAVES_PER_EU - 2 : HGI_DEC_WAVES_PER_EU))) void k_dec_tiles(const u8 *__restrict__ src, u8 *__restrict__ dst, Frames f, u32 k,
                                                   Seeds sd, TileGrid g, u32 aligned)
 {
     HGI_TL_ENTRY();
@@ -1646,7 +1798,14 @@ __global__ __launch_bounds__(NL * NWAVES) __attribute__((amdgpu_waves_per_eu(HGI
         SeedRegs seeds;
         HGI_MARK("stage_issue");
         HGI_TL_START();
+        ConeLane cone;
+#if HGI_CONE_FIRST
+        if (SEEDED == 3) cone = cone_issue(src + (size_t)cur.tl.frame * f.frame_stride, W, sd.sw, sd.sh, cur.tl, (u32)sd.stride);
+#endif
         stage_issue<false>(st, cur.b, cur.tl, (int)k, nh, wv);
+#if !HGI_CONE_FIRST
+        if (SEEDED == 3) cone = cone_issue(src + (size_t)cur.tl.frame * f.frame_stride, W, sd.sw, sd.sh, cur.tl, (u32)sd.stride);
+#endif
         InlineSeeds il = {0};
         if (SEEDED == 1) seeds = seed_issue<false>(sd, cur.tl, k);
         if (SEEDED == 2) il = inline_seed_issue(src + (size_t)cur.tl.frame * f.frame_stride, W, H, cur.tl, (u32)sd.stride);
@@ -1654,6 +1813,7 @@ __global__ __launch_bounds__(NL * NWAVES) __attribute__((amdgpu_waves_per_eu(HGI
         stage_commit<false>(buf, nullptr, st, nh, HGI_PAIR && wv == 0);
         LDS_ORDER();
         if (SEEDED == 2) seeds = inline_seed_finish<INTERP>(il, buf, cur.tl, (u32)sd.stride, sd.sw, sd.sh);
+        if (SEEDED == 3) seeds = cone_finish<INTERP, false, true>(cone, buf, nullptr, (u32)sd.stride, nullptr);
         LDS_ORDER();
         if (HGI_PAIR) {
             if (wv) pair_push_column<false>(buf, smem - HCOL, nullptr, nh);
@@ -1674,6 +1834,8 @@ __global__ __launch_bounds__(NL * NWAVES) __attribute__((amdgpu_waves_per_eu(HGI
     InlineSeeds il = {0};
     if (SEEDED == 1) seeds = seed_issue<false>(sd, tl, k);
     if (SEEDED == 2) il = inline_seed_issue(fr, W, H, tl, (u32)sd.stride);
+    ConeLane cone;
+    if (SEEDED == 3) cone = cone_issue(fr, W, sd.sw, sd.sh, tl, (u32)sd.stride);
     if (aligned & 2u) {   // 32-bit buffer offsets: buffer staging and the check-free levels with edge masks
         TileCtx cur = {tl, make_buf(fr, out, W, H, tl, (aligned & 4u) ? 3u : 0u)};
         Stage st;
@@ -1681,6 +1843,7 @@ __global__ __launch_bounds__(NL * NWAVES) __attribute__((amdgpu_waves_per_eu(HGI
         stage_commit<false>(buf, nullptr, st, nh);
         LDS_ORDER();
         if (SEEDED == 2) seeds = inline_seed_finish<INTERP>(il, buf, tl, (u32)sd.stride, sd.sw, sd.sh);
+        if (SEEDED == 3) seeds = cone_finish<INTERP, false, true>(cone, buf, nullptr, (u32)sd.stride, nullptr);
         if (SEEDED) dec_seed_commit(buf, seeds, k);
         if (tl.X0 + TW <= W && !(H & 1u))
             dec_tile_edge<INTERP, 1>(buf, cur, st.o, k, W, H);
@@ -1692,6 +1855,7 @@ __global__ __launch_bounds__(NL * NWAVES) __attribute__((amdgpu_waves_per_eu(HGI
     stage_tile_generic(buf, fr, W, H, tl, nh, (aligned & 1u) != 0);
     LDS_ORDER();
     if (SEEDED == 2) seeds = inline_seed_finish<INTERP>(il, buf, tl, (u32)sd.stride, sd.sw, sd.sh);
+    if (SEEDED == 3) seeds = cone_finish<INTERP, false, true>(cone, buf, nullptr, (u32)sd.stride, nullptr);
     if (SEEDED) dec_seed_commit(buf, seeds, k);
     for (int s = 1 << (k - 1); s >= 2; s >>= 1) {
         dec_cells<INTERP, true>(buf, s, tl, W, H);
@@ -1705,7 +1869,7 @@ __global__ __launch_bounds__(NL * NWAVES) __attribute__((amdgpu_waves_per_eu(HGI
 // lattice points = 0 (mod 2^k): reconstruction == original (src/encoder.rs:26-37) -- which is what staging
 // left in rbuf -- or, when this launch is the lower part of a deeper pyramid, the coarser pyramid's
 // reconstruction, with its residuals taking the place of the originals in the output.
-template <bool SEEDED>
+template <int SEEDED>
 __device__ __forceinline__ void enc_seed_commit(u8 *buf, u8 *rbuf, const SeedRegs &r, u32 k)
 {
     if (SEEDED && r.on) {
@@ -1773,7 +1937,7 @@ __device__ __forceinline__ void enc_tile_fast(u8 *buf, u8 *rbuf, const u8 *slut,
 // dst) -- the top of a deeper pyramid's chain codes the lattice plane once and hands both planes on as seeds.  These are
 // small, latency-bound launches (a lattice plane): their register budget is not held to the main kernels' occupancy
 // target -- the view staging keeps sixteen byte loads per chunk in flight.
-template <int INTERP, bool IDENT, bool SEEDED, int TILE_ROWS, bool WREC = false>
+template <int INTERP, bool IDENT, int SEEDED, int TILE_ROWS, bool WREC = false>
 __global__ __launch_bounds__(NL * NWAVES) __attribute__((amdgpu_waves_per_eu(WREC ? 2 : IDENT ? HGI_ENC_WAVES_PER_EU - 1 : HGI_ENC_WAVES_PER_EU))) void k_enc_tiles(const u8 *__restrict__ src, u8 *__restrict__ dst, Frames f, u32 k,
                                                   Lut256 lut, Seeds sd, TileGrid g, u32 aligned, u8 *__restrict__ rec, View vw)
 {
@@ -1809,6 +1973,7 @@ __global__ __launch_bounds__(NL * NWAVES) __attribute__((amdgpu_waves_per_eu(WRE
         TileCtx cur = fast_ctx(role.index, src, dst, f, g, (aligned & 4u) ? 3u : 0u, WREC ? rec : nullptr, wv);
         Stage st;
         SeedRegs seeds;
+        ConeLane cone;
         HGI_MARK("stage_issue");
         HGI_TL_START();
         const bool through_view = WREC && vw.shift != 0;
@@ -1823,14 +1988,21 @@ __global__ __launch_bounds__(NL * NWAVES) __attribute__((amdgpu_waves_per_eu(WRE
             for (int j = 0; j < NFINE; ++j)
                 st.o[j] = *reinterpret_cast<const v4u *>(oddbuf + (fine_pair0() + 8 * j) * TW + 16 * (HGI_LANE & (CH - 1)));
         } else {
+#if HGI_CONE_FIRST
+            if (SEEDED == 2) cone = cone_issue(src + (size_t)cur.tl.frame * f.frame_stride, W, sd.sw, sd.sh, cur.tl, (u32)sd.stride);
+#endif
             stage_issue<false>(st, cur.b, cur.tl, (int)k, nh, wv);
-            if (SEEDED) seeds = seed_issue<true>(sd, cur.tl, k);
+            if (SEEDED == 1) seeds = seed_issue<true>(sd, cur.tl, k);
+#if !HGI_CONE_FIRST
+            if (SEEDED == 2) cone = cone_issue(src + (size_t)cur.tl.frame * f.frame_stride, W, sd.sw, sd.sh, cur.tl, (u32)sd.stride);
+#endif
             if (!IDENT) lutv = lut.w[HGI_LANE];      // (pair build: both waves write the same table)
             HGI_MARK("stage_commit");
             stage_commit<true>(buf, rbuf, st, nh, HGI_PAIR && wv == 0);
         }
         if (!IDENT) reinterpret_cast<u32 *>(slut)[HGI_LANE] = lutv;
         LDS_ORDER();
+        if (SEEDED == 2) seeds = cone_finish<INTERP, true, IDENT>(cone, buf, rbuf, (u32)sd.stride, slut);
         if (HGI_PAIR) {
             if (wv) pair_push_column<true>(buf, smem + 256 - HCOL, smem + 256 + buf_bytes(nh) - RCOL, nh);
             __syncthreads();
@@ -1846,7 +2018,9 @@ __global__ __launch_bounds__(NL * NWAVES) __attribute__((amdgpu_waves_per_eu(WRE
     const u8 *fr = src + (size_t)tl.frame * f.frame_stride;
     u8 *out = dst + (size_t)tl.frame * f.frame_stride;
     SeedRegs seeds;
-    if (SEEDED) seeds = seed_issue<true>(sd, tl, k);
+    if (SEEDED == 1) seeds = seed_issue<true>(sd, tl, k);
+    ConeLane cone;
+    if (SEEDED == 2) cone = cone_issue(fr, W, sd.sw, sd.sh, tl, (u32)sd.stride);
     if (aligned & 2u) {   // 32-bit buffer offsets: buffer staging and the check-free levels with edge masks
         TileCtx cur = {tl, make_buf(fr, out, W, H, tl, (aligned & 4u) ? 3u : 0u, WREC ? rec + (size_t)tl.frame * f.frame_stride : nullptr)};
         Stage st;
@@ -1855,6 +2029,7 @@ __global__ __launch_bounds__(NL * NWAVES) __attribute__((amdgpu_waves_per_eu(WRE
         stage_commit<true>(buf, rbuf, st, nh);
         if (!IDENT) reinterpret_cast<u32 *>(slut)[HGI_LANE] = lutv;
         LDS_ORDER();
+        if (SEEDED == 2) seeds = cone_finish<INTERP, true, IDENT>(cone, buf, rbuf, (u32)sd.stride, slut);
         enc_seed_commit<SEEDED>(buf, rbuf, seeds, k);
         if (tl.X0 + TW <= W && !(H & 1u))
             enc_tile_edge<INTERP, IDENT, 1, WREC>(buf, rbuf, slut, cur, st.o, k, W, H);
@@ -1867,6 +2042,7 @@ __global__ __launch_bounds__(NL * NWAVES) __attribute__((amdgpu_waves_per_eu(WRE
     LDS_ORDER();
     lattice_from_buf(buf, rbuf, nh);
     LDS_ORDER();
+    if (SEEDED == 2) seeds = cone_finish<INTERP, true, IDENT>(cone, buf, rbuf, (u32)sd.stride, slut);
     enc_seed_commit<SEEDED>(buf, rbuf, seeds, k);
     for (int s = 1 << (k - 1); s >= 2; s >>= 1) {
         enc_cells<INTERP, IDENT, true>(buf, rbuf, slut, s, tl, W, H);
@@ -2011,8 +2187,10 @@ hipError_t HGI_TILED(launch_decode_fused)(const uint8_t *grid, uint8_t *img, con
     if (seeds && k < (uint32_t)kSeededMinLevels) return hipErrorInvalidValue;      // one lane per lattice point (seed_issue)
     Seeds sd = seeds ? *seeds : Seeds{nullptr, nullptr, 0, 0, 0};
     // seeds without planes: the kernel rebuilds them from the grid (inline_seed_*): six fused levels, one or two above them
-    const bool inline_seeds = seeds && !seeds->rec;
-    if (inline_seeds && (TH != 64 || k != 6 || sd.stride < 1 || sd.stride > 2)) return hipErrorInvalidValue;
+    // -- or, at four fused levels, up to four above them (cone_*)
+    const bool inline_seeds = seeds && !seeds->rec, cone = inline_seeds && k == 4;
+    if (inline_seeds && !cone && (TH != 64 || k != 6 || sd.stride < 1 || sd.stride > 2)) return hipErrorInvalidValue;
+    if (cone && (sd.stride < 1 || sd.stride > (u64)kConeMaxUp || HGI_PAIR)) return hipErrorInvalidValue;
     const dim3 b(NL * NWAVES);
     const int nh = k >= 2 ? (int)k : 1;
     // A decode between one and eight rounds of resident tiles deep (8 192 ... 65 536 tiles: a lone 16384^2 frame has 32 768)
@@ -2030,6 +2208,7 @@ hipError_t HGI_TILED(launch_decode_fused)(const uint8_t *grid, uint8_t *img, con
     do {                                                                 \
         if (!seeds) HGI_DEC(I, 0);                                       \
         else if (!inline_seeds) HGI_DEC(I, 1);                           \
+        else if (cone) HGI_DEC(I, 3);                                    \
         else if (TH == 64) HGI_DEC(I, (TH == 64 ? 2 : 1));               \
     } while (0)
     if (interp == kInterpCrossed) HGI_DEC_I(kInterpCrossed); else HGI_DEC_I(kInterpLeftTop);
@@ -2076,6 +2255,9 @@ hipError_t HGI_TILED(launch_encode_fused)(const uint8_t *img, uint8_t *grid, con
     const TileGrid &g = r.g;
     if (seeds && k < (uint32_t)kSeededMinLevels) return hipErrorInvalidValue;      // one lane per lattice point (seed_issue)
     Seeds sd = seeds ? *seeds : Seeds{nullptr, nullptr, 0, 0, 0};
+    // seeds without planes: the kernel rebuilds them from the frame (cone_*): four fused levels, up to four above them
+    const bool cone = seeds && !seeds->rec;
+    if (cone && (k != 4 || sd.stride < 1 || sd.stride > (u64)kConeMaxUp || HGI_PAIR)) return hipErrorInvalidValue;
     const dim3 b(NL * NWAVES);
     const int nh = k >= 2 ? (int)k : 1;
     static const int enc_waves = getenv("HGI_ENC_WAVES") ? atoi(getenv("HGI_ENC_WAVES")) : 0;
@@ -2092,15 +2274,15 @@ hipError_t HGI_TILED(launch_encode_fused)(const uint8_t *img, uint8_t *grid, con
     } while (0)
 #define HGI_ENC_REC(I, ID)                                                                                        \
     do {                                                                                                          \
-        static const hipError_t lds0 = static_lds_is_empty(reinterpret_cast<const void *>(&k_enc_tiles<I, ID, false, TH, true>)); \
+        static const hipError_t lds0 = static_lds_is_empty(reinterpret_cast<const void *>(&k_enc_tiles<I, ID, 0, TH, true>)); \
         if (lds0 != hipSuccess) return lds0;                                                                      \
-        hipLaunchKernelGGL((k_enc_tiles<I, ID, false, TH, true>), blocks, b, lds, s, img, grid, f, k, lut, sd, g, r.aligned, rec_out, vw); \
+        hipLaunchKernelGGL((k_enc_tiles<I, ID, 0, TH, true>), blocks, b, lds, s, img, grid, f, k, lut, sd, g, r.aligned, rec_out, vw); \
     } while (0)
 #define HGI_ENC_I(I)                                                          \
     do {                                                                      \
         if (rec_out) { if (ident) HGI_ENC_REC(I, true); else HGI_ENC_REC(I, false); } \
-        else if (ident) { if (seeds) HGI_ENC(I, true, true); else HGI_ENC(I, true, false); } \
-        else       { if (seeds) HGI_ENC(I, false, true); else HGI_ENC(I, false, false); } \
+        else if (ident) { if (cone) HGI_ENC(I, true, 2); else if (seeds) HGI_ENC(I, true, 1); else HGI_ENC(I, true, 0); } \
+        else       { if (cone) HGI_ENC(I, false, 2); else if (seeds) HGI_ENC(I, false, 1); else HGI_ENC(I, false, 0); } \
     } while (0)
     if (interp == kInterpCrossed) HGI_ENC_I(kInterpCrossed); else HGI_ENC_I(kInterpLeftTop);
 #undef HGI_ENC_I

@@ -587,10 +587,13 @@ def test_hip_graph_capture_and_replay(H, ctxs, oracle):
 
 
 @pytest.mark.parametrize("mode", ["HGI_FORCE_CHECKED=1", "HGI_TILE_H=64", "HGI_TILE_H=32", "HGI_TILE_H=16", "HGI_NO_LATTICE_KERNEL=1",
-                                  "HGI_NO_LATTICE_KERNEL=1,HGI_NO_ENC_REC=1", "HGI_DEC_REVERSE=1", "HGI_NO_INLINE_SEEDS=1",
-                                  "HGI_NO_INLINE_SEEDS=1,HGI_NO_LATTICE_KERNEL=1", "HGI_DEEP_K_ENC=4,HGI_DEEP_K_DEC=4,HGI_NO_LATTICE_KERNEL=1",
-                                  "HGI_DEEP_K_ENC=4,HGI_NO_LATTICE_KERNEL=1,HGI_NO_ENC_VIEW=1",
-                                  "HGI_DEEP_K_ENC=4,HGI_DEEP_K_DEC=4", "HGI_DEEP_K_ENC=5,HGI_DEEP_K_DEC=5"])
+                                  "HGI_CONE=0", "HGI_CONE_MIN_ENC=5,HGI_CONE_MIN_DEC=5", "HGI_CONE_MIN_ENC=5,HGI_CONE_MIN_DEC=5,HGI_TILE_H=16",
+                                  "HGI_CONE_MIN_ENC=5,HGI_CONE_MIN_DEC=5,HGI_TILE_H=32", "HGI_CONE_MIN_ENC=5,HGI_CONE_MIN_DEC=5,HGI_TILE_H=64",
+                                  "HGI_CONE_MIN_ENC=5,HGI_CONE_MIN_DEC=5,HGI_FORCE_CHECKED=1",
+                                  "HGI_CONE=0,HGI_NO_LATTICE_KERNEL=1,HGI_NO_ENC_REC=1", "HGI_DEC_REVERSE=1", "HGI_CONE=0,HGI_NO_INLINE_SEEDS=1",
+                                  "HGI_CONE=0,HGI_NO_INLINE_SEEDS=1,HGI_NO_LATTICE_KERNEL=1", "HGI_CONE=0,HGI_DEEP_K_ENC=4,HGI_DEEP_K_DEC=4,HGI_NO_LATTICE_KERNEL=1",
+                                  "HGI_CONE=0,HGI_DEEP_K_ENC=4,HGI_NO_LATTICE_KERNEL=1,HGI_NO_ENC_VIEW=1",
+                                  "HGI_CONE=0,HGI_DEEP_K_ENC=4,HGI_DEEP_K_DEC=4", "HGI_CONE=0,HGI_DEEP_K_ENC=5,HGI_DEEP_K_DEC=5"])
 def test_forced_code_paths_in_a_child_process(mode):
     """The library picks tile geometry and code path per launch: 128x16, 128x32 or 128x64 tiles, and the fully checked path only
     for widths that are not multiples of 4 or frames beyond 32-bit offsets.  Each switch is read once per process, so a
@@ -600,7 +603,9 @@ def test_forced_code_paths_in_a_child_process(mode):
     (one launch) and with the older encode-then-decode chain (HGI_NO_ENC_REC) --, the decoder walking its tile list
     backwards, seven- and eight-level decodes through seed planes instead of seeds rebuilt inside the tile kernel, and deep
     pyramids split at four or five levels instead of six (what a lone 16384^2 encode does by itself;
-    the bytes must not depend on the split)."""
+    the bytes must not depend on the split).  Pyramids of seven and eight levels run as ONE launch that rebuilds the levels
+    above a four-level tile for itself (the cone): HGI_CONE=0 keeps all the older chains under test, HGI_CONE_MIN_*=5 sends
+    five- and six-level pyramids through the cone too, on every tile height and through the fully checked path."""
     import os
     import subprocess
     import sys
