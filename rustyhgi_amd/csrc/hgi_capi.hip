@@ -46,7 +46,7 @@ inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 #ifndef HGI_ENTROPY_GROUP_MIB_DEFAULT
 #define HGI_ENTROPY_GROUP_MIB_DEFAULT 256
 #endif
-// The shallowest pyramid that runs as four fused levels + cone (cone_up()).  Six: a lone frame then keeps the small tiles and
+// The shallowest pyramid that runs as four fused levels + cone (split_pyramid()).  Six: a lone frame then keeps the small tiles and
 // the short chain of a four-level launch (1920 x 1080 level 6: 10.6 / 6.5 -> 7.3 / 5.6 us), a batch is unchanged (64 x 4096^2:
 // +0.4 / -0.8 %); at five levels nothing is gained in either (profiles/r03_cone_levels.txt).
 #ifndef HGI_CONE_MIN_ENC_DEFAULT
@@ -118,60 +118,56 @@ SubGeom sub_geom(uint32_t w, uint32_t h, uint32_t k)
     return g;
 }
 
-// Scratch bytes one encode (or decode) of this shape takes, recursion included.  The bump allocator only resets
-// between calls, so this mirrors encode_impl / decode_impl plane for plane: a decode deeper than a tile takes two
-// lattice planes per recursion level; an encode takes three -- and then both encodes AND decodes its lattice
-// (the reconstruction feeds the tile kernel as seeds), each of which recurses on its own.
-size_t plane_bytes(const SubGeom &g, size_t batch) { return align_up(batch * g.stride, 256) + 256; }
+// How a pyramid is split between the tile kernel and what has to be coded in front of it.
+//   levels <= 5 (HGI_CONE_MIN_* - 1): the tile holds the pyramid: k = levels, nothing else.
+//   6 ... 8: ONE launch at four fused levels that rebuilds the 2 ... 4 levels above a tile for itself (hgi_fused_impl.h,
+//            cone_*): k = 4, up = levels - 4.  No lattice planes, no scratch, no launch in front.
+//   deeper:  k = 4, up = 4, and the stride-256 lattice -- an HGI image with levels - 8 levels of its own (same OOB rule:
+//            x < W <=> x >> 8 < ceil(W / 256)) -- is coded first; its planes are the cone's base.
+//   HGI_CONE=0 in the environment (tests, experiments): no cone; the tile kernel takes six levels (or HGI_DEEP_K_ENC /
+//            HGI_DEEP_K_DEC = 4 | 5) and the stride-2^k lattice is coded first.  Every split gives the same bytes.
+struct Split {
+    uint32_t k, up, shift;      // fused levels, cone levels, log2 of the lattice coded in front (0: none)
+};
 
-// How many of a pyramid's levels the tile kernel takes when the pyramid is deeper than a tile (the rest is the lattice
-// plane's own pyramid, coded first).  Six -- everything a 64-row tile holds -- unless the frame is so large that its
-// stride-64 lattice is itself a sizeable image (>= 200 x 200 points: a lone 16384^2 frame): there the encoder's tile
-// kernel at k = 4 saves more than the larger lattice plane costs (measured, tools/c4_time.py, 16384^2 level 8 encode:
-// 125.5 us at k = 6, 119.5 at 5, 115.8 at 4; decode 105.9 / 107.8 / 108.0; smaller frames and batches of 4K frames
-// are faster at 6 in both directions).  Any depth from kSeededMinLevels up gives the same bytes.
-// HGI_DEEP_K_ENC / HGI_DEEP_K_DEC in the environment force one (experiments, tests).
-uint32_t fused_depth(uint32_t w, uint32_t h, uint32_t levels, bool encode)
-{
-    if (levels <= (uint32_t)kFusedMaxLevels) return levels;
-    static const int forced[2] = {getenv("HGI_DEEP_K_DEC") ? atoi(getenv("HGI_DEEP_K_DEC")) : 0,
-                                  getenv("HGI_DEEP_K_ENC") ? atoi(getenv("HGI_DEEP_K_ENC")) : 0};
-    const int f = forced[encode ? 1 : 0];
-    if (f >= kSeededMinLevels && f <= kFusedMaxLevels) return (uint32_t)f;
-    if (encode) {
-        const SubGeom g = sub_geom(w, h, kFusedMaxLevels);
-        if ((uint64_t)g.sw * g.sh >= 40000) return 4;
-    }
-    return (uint32_t)kFusedMaxLevels;
-}
-
-// Pyramids of HGI_CONE_MIN_* ... 8 levels run as ONE launch of the tile kernel at four fused levels, which rebuilds the
-// 1 ... 4 levels above a tile for itself (hgi_fused_impl.h, cone_*): no lattice planes, no scratch, no launch in front.
-// Returns the levels above the tile, 0 when the pyramid is not run that way.  HGI_CONE=0 in the environment keeps the
-// older chains (tests, experiments); HGI_CONE_MIN_ENC / HGI_CONE_MIN_DEC move the lower end.
-uint32_t cone_up(uint32_t levels, bool encode)
+Split split_pyramid(uint32_t levels, bool encode)
 {
     static const bool off = getenv("HGI_CONE") && atoi(getenv("HGI_CONE")) == 0;
     static const int lo[2] = {getenv("HGI_CONE_MIN_DEC") ? atoi(getenv("HGI_CONE_MIN_DEC")) : HGI_CONE_MIN_DEC_DEFAULT,
                               getenv("HGI_CONE_MIN_ENC") ? atoi(getenv("HGI_CONE_MIN_ENC")) : HGI_CONE_MIN_ENC_DEFAULT};
+    static const int forced[2] = {getenv("HGI_DEEP_K_DEC") ? atoi(getenv("HGI_DEEP_K_DEC")) : 0,
+                                  getenv("HGI_DEEP_K_ENC") ? atoi(getenv("HGI_DEEP_K_ENC")) : 0};
     const int m = lo[encode ? 1 : 0] < 5 ? 5 : lo[encode ? 1 : 0];
-    return (!off && levels >= (uint32_t)m && levels <= 8u) ? levels - 4u : 0u;
+    if (!off && levels >= (uint32_t)m) {
+        if (levels <= 8u) return {4u, levels - 4u, 0u};
+        return {4u, 4u, 8u};
+    }
+    if (levels <= (uint32_t)kFusedMaxLevels) return {levels, 0u, 0u};
+    const int f = forced[encode ? 1 : 0];
+    const uint32_t k = (f >= kSeededMinLevels && f <= kFusedMaxLevels) ? (uint32_t)f : (uint32_t)kFusedMaxLevels;
+    return {k, 0u, k};
 }
+
+// Scratch bytes one encode (or decode) of this shape takes, recursion included.  The bump allocator only resets
+// between calls, so this mirrors encode_impl / decode_impl plane for plane: a decode with a lattice in front takes two
+// planes per recursion level; an encode takes three -- and then both encodes AND decodes its lattice (the
+// reconstruction is what the tile kernel starts from), each of which recurses on its own.
+size_t plane_bytes(const SubGeom &g, size_t batch) { return align_up(batch * g.stride, 256) + 256; }
 
 size_t ws_need_decode(uint32_t w, uint32_t h, uint32_t levels, size_t batch)
 {
-    if (levels <= (uint32_t)kFusedMaxLevels || cone_up(levels, false)) return 0;
-    const uint32_t k = fused_depth(w, h, levels, false);
-    const SubGeom g = sub_geom(w, h, k);
-    return 2 * plane_bytes(g, batch) + ws_need_decode(g.sw, g.sh, levels - k, batch);
+    const Split sp = split_pyramid(levels, false);
+    if (!sp.shift) return 0;
+    const SubGeom g = sub_geom(w, h, sp.shift);
+    return 2 * plane_bytes(g, batch) + ws_need_decode(g.sw, g.sh, levels - sp.shift, batch);
 }
 
 size_t ws_need_encode(uint32_t w, uint32_t h, uint32_t levels, size_t batch)
 {
-    if (levels <= (uint32_t)kFusedMaxLevels || cone_up(levels, true)) return 0;
-    const uint32_t k = fused_depth(w, h, levels, true);
-    const SubGeom g = sub_geom(w, h, k);
-    return 3 * plane_bytes(g, batch) + ws_need_encode(g.sw, g.sh, levels - k, batch) + ws_need_decode(g.sw, g.sh, levels - k, batch);
+    const Split sp = split_pyramid(levels, true);
+    if (!sp.shift) return 0;
+    const SubGeom g = sub_geom(w, h, sp.shift);
+    return 3 * plane_bytes(g, batch) + ws_need_encode(g.sw, g.sh, levels - sp.shift, batch) + ws_need_decode(g.sw, g.sh, levels - sp.shift, batch);
 }
 
 size_t ws_need(const hgi_ctx *c, uint32_t w, uint32_t h, uint32_t levels, size_t batch, size_t stride)
@@ -219,14 +215,13 @@ bool use_lattice_kernel(const SubGeom &g, size_t batch)
 }
 
 hipError_t launch_encode_fused(const uint8_t *img, uint8_t *grid, const Frames &f, uint32_t k, int interp,
-                               const Lut256 &lut, bool ident, const Seeds *seeds, hipStream_t s, uint32_t row_limit = 0, uint8_t *rec_out = nullptr,
-                               const View *view = nullptr)
+                               const Lut256 &lut, bool ident, const Seeds *seeds, hipStream_t s, uint32_t row_limit = 0)
 {
     const uint32_t rows = row_limit && row_limit < f.height ? row_limit : f.height;   // what this launch really covers
     switch (use_tile_rows(f.width, rows, k, f.batch, true)) {
-    case 16: return launch_encode_fused_16(img, grid, f, k, interp, lut, ident, seeds, s, row_limit, rec_out, view);
-    case 32: return launch_encode_fused_32(img, grid, f, k, interp, lut, ident, seeds, s, row_limit, rec_out, view);
-    default: return launch_encode_fused_64(img, grid, f, k, interp, lut, ident, seeds, s, row_limit, rec_out, view);
+    case 16: return launch_encode_fused_16(img, grid, f, k, interp, lut, ident, seeds, s, row_limit);
+    case 32: return launch_encode_fused_32(img, grid, f, k, interp, lut, ident, seeds, s, row_limit);
+    default: return launch_encode_fused_64(img, grid, f, k, interp, lut, ident, seeds, s, row_limit);
     }
 }
 
@@ -277,57 +272,29 @@ hgi_status encode_impl(hgi_ctx *c, const uint8_t *img, uint32_t w, uint32_t h, u
             HIP_TRY(launch_encode_level(rec, grid, f, levels - level - 1, interp, l, c->stream));
         return HGI_OK;
     }
-    if (const uint32_t up = cone_up(levels, true)) {
-        const SubGeom g = sub_geom(w, h, 4);
-        Seeds sd = {nullptr, nullptr, g.sw, g.sh, (uint64_t)up};
-        HIP_TRY(launch_encode_fused(img, grid, f, 4, interp, l, is_identity(lut), &sd, c->stream));
-        return HGI_OK;
-    }
-    const uint32_t k = fused_depth(w, h, levels, true);
-    if (levels > k) {
-        // Deeper pyramid: the lattice = 0 (mod 2^k) is itself an HGI image with levels-k levels
-        // (same OOB rule: x < W <=> x >> k < ceil(W / 2^k) on the lattice).  Code it first, then
-        // hand its reconstruction and residuals to the tile kernel as seeds.
-        SubGeom g = sub_geom(w, h, k);
+    const Split sp = split_pyramid(levels, true);
+    if (sp.shift) {
+        // the lattice = 0 (mod 2^shift) first: its reconstruction and residuals are what the tile launch starts from
+        const SubGeom g = sub_geom(w, h, sp.shift);
         uint8_t *sub_img = ws_take(c, batch * g.stride);
         uint8_t *sub_grid = ws_take(c, batch * g.stride);
         uint8_t *sub_rec = ws_take(c, batch * g.stride);
         if (!sub_img || !sub_grid || !sub_rec) return fail(HGI_ENOMEM, "scratch exhausted (lattice planes)");
-        if (use_lattice_kernel(g, batch)) {   // small planes: gather + all upper levels + both seed planes in one launch
-            HIP_TRY(launch_lattice_pyramid(img, f, k, levels - k, interp, l, is_identity(lut), true, sub_grid, sub_rec, g.sw,
-                                           g.sh, g.stride, c->stream));
-        } else {
-            // The plane's own pyramid in ONE launch when a tile holds it: the encoder writes its reconstruction beside the
-            // residuals (src/encoder.rs:63-64 has it in place anyway), so the plane need not be decoded again for the seeds --
-            // and when the plane consists of whole tiles that launch stages them straight from the frame (a view), so the
-            // gather launch goes too.  HGI_NO_ENC_REC / HGI_NO_ENC_VIEW keep the older chains (tests, experiments).
-            static const bool no_rec = getenv("HGI_NO_ENC_REC") != nullptr, no_view = getenv("HGI_NO_ENC_VIEW") != nullptr;
-            const bool one_launch = levels - k <= (uint32_t)kFusedMaxLevels && !no_rec;
-            const Frames sf = {g.sw, g.sh, g.stride, (uint32_t)batch};
-            hipError_t e = hipErrorNotSupported;
-            if (one_launch && !no_view) {
-                const View vw = {k, w, h, (uint64_t)stride};
-                e = launch_encode_fused(img, sub_grid, sf, levels - k, interp, l, is_identity(lut), nullptr, c->stream, 0, sub_rec, &vw);
-                if (e != hipSuccess && e != hipErrorNotSupported) HIP_TRY(e);
-            }
-            if (e != hipSuccess) {
-                (void)hipGetLastError();
-                HIP_TRY(launch_gather_lattice(img, f, k, sub_img, g.sw, g.sh, g.stride, c->stream));
-                if (one_launch) {
-                    e = launch_encode_fused(sub_img, sub_grid, sf, levels - k, interp, l, is_identity(lut), nullptr, c->stream, 0, sub_rec);
-                    if (e != hipSuccess && e != hipErrorNotSupported) HIP_TRY(e);
-                }
-            }
-            if (e != hipSuccess) {
-                (void)hipGetLastError();
-                HGI_TRY(encode_impl(c, sub_img, g.sw, g.sh, levels - k, interp, lut, sub_grid, batch, g.stride));
-                HGI_TRY(decode_impl(c, sub_grid, g.sw, g.sh, levels - k, interp, sub_rec, batch, g.stride));
-            }
+        if (use_lattice_kernel(g, batch)) {   // small planes: gather + all upper levels + both planes in one launch
+            HIP_TRY(launch_lattice_pyramid(img, f, sp.shift, levels - sp.shift, interp, l, is_identity(lut), true, sub_grid, sub_rec,
+                                           g.sw, g.sh, g.stride, c->stream));
+        } else {                              // an image in its own right: gather it, code it, decode it (each may recurse)
+            HIP_TRY(launch_gather_lattice(img, f, sp.shift, sub_img, g.sw, g.sh, g.stride, c->stream));
+            HGI_TRY(encode_impl(c, sub_img, g.sw, g.sh, levels - sp.shift, interp, lut, sub_grid, batch, g.stride));
+            HGI_TRY(decode_impl(c, sub_grid, g.sw, g.sh, levels - sp.shift, interp, sub_rec, batch, g.stride));
         }
-        Seeds sd = {sub_rec, sub_grid, g.sw, g.sh, g.stride};
-        HIP_TRY(launch_encode_fused(img, grid, f, k, interp, l, is_identity(lut), &sd, c->stream));
+        const Seeds sd = {sub_rec, sub_grid, g.sw, g.sh, g.stride, sp.up};
+        HIP_TRY(launch_encode_fused(img, grid, f, sp.k, interp, l, is_identity(lut), &sd, c->stream));
+    } else if (sp.up) {
+        const Seeds sd = {nullptr, nullptr, 0, 0, 0, sp.up};
+        HIP_TRY(launch_encode_fused(img, grid, f, sp.k, interp, l, is_identity(lut), &sd, c->stream));
     } else {
-        HIP_TRY(launch_encode_fused(img, grid, f, k, interp, l, is_identity(lut), nullptr, c->stream));
+        HIP_TRY(launch_encode_fused(img, grid, f, sp.k, interp, l, is_identity(lut), nullptr, c->stream));
     }
     return HGI_OK;
 }
@@ -347,37 +314,26 @@ hgi_status decode_impl(hgi_ctx *c, const uint8_t *grid, uint32_t w, uint32_t h, 
             HIP_TRY(launch_decode_level(grid, img, f, levels - level - 1, interp, c->stream));
         return HGI_OK;
     }
-    if (const uint32_t up = cone_up(levels, false)) {
-        const SubGeom g = sub_geom(w, h, 4);
-        Seeds sd = {nullptr, nullptr, g.sw, g.sh, (uint64_t)up};
-        HIP_TRY(launch_decode_fused(grid, img, f, 4, interp, &sd, c->stream));
-        return HGI_OK;
-    }
-    const uint32_t k = fused_depth(w, h, levels, false);
-    if (levels > k) {
-        SubGeom g = sub_geom(w, h, k);
-        // one or two levels above a 64-row tile's six: the tile kernel rebuilds its seeds from the grid itself -- no plane,
-        // no launch in front of it (hgi_fused_impl.h, inline_seed_*).  HGI_NO_INLINE_SEEDS keeps the planes (tests).
-        static const bool no_inline = getenv("HGI_NO_INLINE_SEEDS") != nullptr;
-        if (k == (uint32_t)kFusedMaxLevels && levels - k <= 2 && !no_inline) {
-            Seeds sd = {nullptr, nullptr, g.sw, g.sh, (uint64_t)(levels - k)};
-            HIP_TRY(launch_decode_fused(grid, img, f, k, interp, &sd, c->stream));
-            return HGI_OK;
-        }
+    const Split sp = split_pyramid(levels, false);
+    if (sp.shift) {
+        const SubGeom g = sub_geom(w, h, sp.shift);
         uint8_t *sub_grid = ws_take(c, batch * g.stride);
         uint8_t *sub_rec = ws_take(c, batch * g.stride);
         if (!sub_grid || !sub_rec) return fail(HGI_ENOMEM, "scratch exhausted (lattice planes)");
         if (use_lattice_kernel(g, batch)) {
-            HIP_TRY(launch_lattice_pyramid(grid, f, k, levels - k, interp, Lut256{}, true, false, nullptr, sub_rec, g.sw, g.sh,
-                                           g.stride, c->stream));
+            HIP_TRY(launch_lattice_pyramid(grid, f, sp.shift, levels - sp.shift, interp, Lut256{}, true, false, nullptr, sub_rec, g.sw,
+                                           g.sh, g.stride, c->stream));
         } else {
-            HIP_TRY(launch_gather_lattice(grid, f, k, sub_grid, g.sw, g.sh, g.stride, c->stream));
-            HGI_TRY(decode_impl(c, sub_grid, g.sw, g.sh, levels - k, interp, sub_rec, batch, g.stride));
+            HIP_TRY(launch_gather_lattice(grid, f, sp.shift, sub_grid, g.sw, g.sh, g.stride, c->stream));
+            HGI_TRY(decode_impl(c, sub_grid, g.sw, g.sh, levels - sp.shift, interp, sub_rec, batch, g.stride));
         }
-        Seeds sd = {sub_rec, nullptr, g.sw, g.sh, g.stride};
-        HIP_TRY(launch_decode_fused(grid, img, f, k, interp, &sd, c->stream));
+        const Seeds sd = {sub_rec, nullptr, g.sw, g.sh, g.stride, sp.up};
+        HIP_TRY(launch_decode_fused(grid, img, f, sp.k, interp, &sd, c->stream));
+    } else if (sp.up) {
+        const Seeds sd = {nullptr, nullptr, 0, 0, 0, sp.up};
+        HIP_TRY(launch_decode_fused(grid, img, f, sp.k, interp, &sd, c->stream));
     } else {
-        HIP_TRY(launch_decode_fused(grid, img, f, k, interp, nullptr, c->stream));
+        HIP_TRY(launch_decode_fused(grid, img, f, sp.k, interp, nullptr, c->stream));
     }
     return HGI_OK;
 }
@@ -629,22 +585,27 @@ static hgi_status host_banded(hgi_ctx *c, const uint8_t *in, uint8_t *out, uint3
     const size_t n = (size_t)w * h;
     HGI_TRY(pipe_ensure(c));
     const size_t slot = align_up(n, 256) + 256;
-    HGI_TRY(ws_ensure(c, 2 * slot + ws_need(c, w, h, levels, 1, n) + 1024));
+    // Pyramids deeper than a tile: the stride-2^k lattice (every 64th pixel of every 64th row) is gathered on the host --
+    // it is tiny -- and goes up first; its seeds are ready long before the first band is.  The split is six levels + seed
+    // planes here, not split_pyramid()'s: a tile that rebuilt the levels above it for itself (the cone) would read rows
+    // far below its band, which have not been uploaded yet.  This path is bound by PCIe anyway (6 ms for 16384^2 against
+    // 0.1 ms of kernels), and six keeps the host-side gather at w*h / 4096 bytes.
+    const uint32_t k = levels < (uint32_t)kFusedMaxLevels ? levels : (uint32_t)kFusedMaxLevels;
+    const bool deep = levels > k;
+    SubGeom g = {0, 0, 0};
+    size_t lattice_need = 0;
+    if (deep) {
+        g = sub_geom(w, h, k);
+        lattice_need = 3 * plane_bytes(g, 1) + ws_need_encode(g.sw, g.sh, levels - k, 1) + ws_need_decode(g.sw, g.sh, levels - k, 1);
+    }
+    HGI_TRY(ws_ensure(c, 2 * slot + lattice_need + 1024));
     c->ws_used = 0;
     uint8_t *d_in = ws_take(c, n), *d_out = ws_take(c, n);
     if (!d_in || !d_out) return fail(HGI_ENOMEM, "scratch exhausted (host staging)");
     HIP_TRY(hipStreamSynchronize(c->stream));
-    // Pyramids deeper than a tile: the stride-2^k lattice (every 64th pixel of every 64th row) is gathered on the host --
-    // it is tiny -- and goes up first; its seeds are ready long before the first band is.  The split stays at six levels
-    // here whatever fused_depth() picks for device-resident frames: this path is bound by PCIe (6 ms for 16384^2 against
-    // 0.1 ms of kernels), so the tile kernel's depth does not show, and six keeps the host-side gather at w*h / 4096 bytes.
-    const uint32_t k = levels < (uint32_t)kFusedMaxLevels ? levels : (uint32_t)kFusedMaxLevels;
-    const bool deep = levels > k;
-    SubGeom g = {0, 0, 0};
     uint8_t *sub_src = nullptr, *sub_grid = nullptr, *sub_rec = nullptr;
     std::vector<uint8_t> lattice;
     if (deep) {
-        g = sub_geom(w, h, k);
         sub_src = ws_take(c, g.stride);
         sub_grid = encode ? ws_take(c, g.stride) : sub_src;     // decoding: the gathered plane IS the lattice's grid
         sub_rec = ws_take(c, g.stride);
@@ -711,7 +672,7 @@ static hgi_status host_banded(hgi_ctx *c, const uint8_t *in, uint8_t *out, uint3
         // the view starts y0 rows down (a multiple of 64 = 2^6 >= 2^k): its seeds start y0 >> k lattice rows down
         const size_t ly = y0 >> k;
         const Seeds sd = {deep ? sub_rec + ly * g.sw : nullptr, deep && encode ? sub_grid + ly * g.sw : nullptr, g.sw,
-                          deep ? (uint32_t)(g.sh - ly) : 0u, g.stride};
+                          deep ? (uint32_t)(g.sh - ly) : 0u, g.stride, 0u};
         r = encode ? launch_encode_fused(d_in + y0 * w, d_out + y0 * w, f, k, interp, l, ident, deep ? &sd : nullptr, down, limit)
                    : launch_decode_fused(d_in + y0 * w, d_out + y0 * w, f, k, interp, deep ? &sd : nullptr, down, limit);
         if (r == hipSuccess && hold) r = hipEventRecord(c->ev_free[b % 3], down);

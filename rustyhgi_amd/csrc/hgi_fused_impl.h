@@ -116,9 +116,6 @@ static_assert(TH != 64 || 18 * (buf_bytes(4) + rbuf_bytes(4) + 256) <= 160 * 102
 #define HGI_ABL 0   // timing experiments: 1 no coarse levels, 2 no fine arithmetic, 4 no halo cells, 8 no sub==2 level,
                     // 16 no halo-column loads, 32 no halo-row loads
 #endif
-#ifndef HGI_CONE_FIRST
-#define HGI_CONE_FIRST 0    // the cone's load goes out in front of the tile's staging loads (1) or behind them (0)
-#endif
 #ifndef HGI_XCD_MODE
 #define HGI_XCD_MODE 1      // default of the XCD dealing policy (block_role); HGI_XCD_MODE in the environment overrides it
 #endif
@@ -772,9 +769,7 @@ __device__ __forceinline__ void enc_level_coarse_fast(u8 *buf, u8 *rbuf, const u
 struct Buf {
     __amdgpu_buffer_rsrc_t rs;   // frame being read  (range check -> 0 beyond width*height)
     __amdgpu_buffer_rsrc_t rd;   // frame being written
-    __amdgpu_buffer_rsrc_t rr;   // encode with WREC: the reconstruction plane (src/encoder.rs:63-64 keeps it in place; here it is an output on request)
     u32 W, base;                 // base = Y0 * W + X0
-    u32 vshift, vrow, vbase;     // view staging (encoder's plane launch): pixel shift, parent bytes per plane row, parent offset of (X0, Y0)
 };
 
 // Row pair (image rows 2p, 2p + 1) a lane owns in iteration `it` of the finest level, p = fine_pair0 + 8 * it:
@@ -869,67 +864,6 @@ __device__ __forceinline__ void stage_issue(Stage &st, const Buf &b, Tile tl, in
     } else {
         issue_body();
         issue_halo();
-    }
-}
-
-// Interior tile of a lattice plane staged straight from the parent frame (no gather launch in front of the plane launch).
-// Plane pixels are single bytes 2^shift apart, so this path loads BYTES, one plane pixel per lane: a wave instruction
-// covers 64 neighbouring pixels of one plane row = 64 << shift parent bytes (8 lines at shift 4; the first version gave
-// each lane a 16-pixel chunk like the ordinary staging does and touched 64 lines per instruction: the launch took
-// 10 us).  The bytes go straight to their places in LDS -- even rows and halo rows into `buf`, halo columns into the
-// transposed column slots, odd rows into a scratch area behind the planes (`oddbuf`, TH / 2 rows of TW bytes) from
-// which the finest level's lane map picks them up as 16-byte chunks; the half-resolution plane is derived from `buf`
-// afterwards (lattice_from_buf).  Everything behind staging is unchanged.
-__device__ __forceinline__ void stage_view_to_lds(u8 *buf, u8 *oddbuf, const Buf &b, int k, int nh, bool has_right)
-{
-    const u32 lane = HGI_LANE, sh = b.vshift;
-    const u32 rw = __builtin_amdgcn_readfirstlane(b.vrow);
-    const u32 col = b.vbase + (lane << sh), half = 64u << sh;
-    u32 ev[TH / 2][2], od[TH / 2][2], hr[HR][2];
-#pragma unroll
-    for (int z = 0; z < TH / 2; ++z) {
-        ev[z][0] = __builtin_amdgcn_raw_buffer_load_b8(b.rs, col + (u32)(2 * z) * rw, 0, 0);
-        ev[z][1] = __builtin_amdgcn_raw_buffer_load_b8(b.rs, col + (u32)(2 * z) * rw + half, 0, 0);
-        od[z][0] = __builtin_amdgcn_raw_buffer_load_b8(b.rs, col + (u32)(2 * z + 1) * rw, 0, 0);
-        od[z][1] = __builtin_amdgcn_raw_buffer_load_b8(b.rs, col + (u32)(2 * z + 1) * rw + half, 0, 0);
-    }
-#pragma unroll
-    for (int i = 0; i < HR; ++i) {
-        hr[i][0] = hr[i][1] = 0;
-        if (i < nh) {
-            hr[i][0] = __builtin_amdgcn_raw_buffer_load_b8(b.rs, col + (u32)(TH + hoff(i)) * rw, 0, 0);
-            hr[i][1] = __builtin_amdgcn_raw_buffer_load_b8(b.rs, col + (u32)(TH + hoff(i)) * rw + half, 0, 0);
-        }
-    }
-    // the column right of the tile: the plane consists of whole tiles, so either the whole next tile exists or nothing does
-    // (the parent's range check does not help here: x << shift would run on into the parent's next row)
-    u32 hc[HR] = {0, 0, 0, 0, 0, 0};
-    const int hy = (int)lane < TH / 2 ? 2 * (int)lane : TH + hoff((int)lane - TH / 2);
-    if ((int)lane < TH / 2 + nh && has_right) {
-        const u32 xo = b.vbase + (u32)hy * rw + ((u32)TW << sh);
-        hc[0] = __builtin_amdgcn_raw_buffer_load_b8(b.rs, xo, 0, 0);
-        hc[1] = __builtin_amdgcn_raw_buffer_load_b8(b.rs, xo + (4u << sh), 0, 0);
-        hc[2] = __builtin_amdgcn_raw_buffer_load_b8(b.rs, xo + (8u << sh), 0, 0);
-        if (k >= 4 && !(hy & 15)) hc[3] = __builtin_amdgcn_raw_buffer_load_b8(b.rs, xo + (16u << sh), 0, 0);
-        if (k >= 5 && !(hy & 31)) hc[4] = __builtin_amdgcn_raw_buffer_load_b8(b.rs, xo + (32u << sh), 0, 0);
-        if (k >= 6 && !(hy & 63)) hc[5] = __builtin_amdgcn_raw_buffer_load_b8(b.rs, xo + (64u << sh), 0, 0);
-    }
-#pragma unroll
-    for (int z = 0; z < TH / 2; ++z) {
-        buf[z * S + lane] = (u8)ev[z][0];
-        buf[z * S + 64 + lane] = (u8)ev[z][1];
-        oddbuf[z * TW + lane] = (u8)od[z][0];
-        oddbuf[z * TW + 64 + lane] = (u8)od[z][1];
-    }
-#pragma unroll
-    for (int i = 0; i < HR; ++i)
-        if (i < nh) {
-            buf[(TH / 2 + i) * S + lane] = (u8)hr[i][0];
-            buf[(TH / 2 + i) * S + 64 + lane] = (u8)hr[i][1];
-        }
-    if ((int)lane < TH / 2 + nh) {
-#pragma unroll
-        for (int i = 0; i < HR; ++i) buf[HCOL + i * HP + lane] = (u8)hc[i];
     }
 }
 
@@ -1192,9 +1126,7 @@ __device__ __forceinline__ void enc_level2_fast(u8 *buf, u8 *rbuf, const u8 *slu
     enc_halo_pass<INTERP, IDENT>(buf, rbuf, slut, 2, tl, W, H);
 }
 
-// WREC: the reconstruction of the tile goes out too (plane b.rr): lattice points from rbuf, new pixels as prediction +
-// residual -- what src/encoder.rs:63-64 writes back in place, and what the tile kernel of a deeper pyramid takes as seeds.
-template <int INTERP, bool IDENT, int EDGE = 0, bool WREC = false>
+template <int INTERP, bool IDENT, int EDGE = 0>
 __device__ __forceinline__ void enc_fine_fast(const u8 *buf, const u8 *rbuf, const u8 *slut, const Buf &b,
                                               const v4u (&odd)[NFINE], int rows = TH, int cols = TW)
 {
@@ -1264,21 +1196,6 @@ __device__ __forceinline__ void enc_fine_fast(const u8 *buf, const u8 *rbuf, con
             } else {
                 store_row_pair(o0, o1, b.rd, vo, Ws);
             }
-            if (WREC) {
-                const u32 oddm = 0xFF00FF00u;
-                const u32 q0 = __builtin_amdgcn_perm(P0, P0, 0x01010000u), q1 = __builtin_amdgcn_perm(P0, P0, 0x03030202u);
-                const u32 q2 = __builtin_amdgcn_perm(P1, P1, 0x01010000u), q3 = __builtin_amdgcn_perm(P1, P1, 0x03030202u);
-                // row y: even columns are lattice points (their reconstruction is rbuf's), odd columns prediction + residual
-                v4u r0 = {__builtin_amdgcn_perm(0u, c.x, 0x0c010c00u) | (add4(e0, q0) & oddm), __builtin_amdgcn_perm(0u, c.x, 0x0c030c02u) | (add4(e1, q1) & oddm),
-                          __builtin_amdgcn_perm(0u, c.y, 0x0c010c00u) | (add4(e2, q2) & oddm), __builtin_amdgcn_perm(0u, c.y, 0x0c030c02u) | (add4(e3, q3) & oddm)};
-                v4u r1 = {add4(g0, q0), add4(g1, q1), add4(g2, q2), add4(g3, q3)};
-                if (EDGE == 2) {
-                    const int y = 2 * (rp0 + (it + j) * (NL / CH));
-                    store_rows_edge(r0, r1, b.rr, vo, Ws, cols - 16 * (lane & (CH - 1)), y < rows, y + 1 < rows);
-                } else {
-                    store_row_pair(r0, r1, b.rr, vo, Ws);
-                }
-            }
         }
         r0 += PAIR * (NL / CH) * S;
         c0 += PAIR * (NL / CH) * S2;
@@ -1300,27 +1217,15 @@ __device__ __forceinline__ u8 *uniform_ptr(const u8 *p)
 // straddle the end of the frame, and the range check would drop it whole -- valid bytes included.  The host grants
 // the 3 bytes only when reading them is safe (fused_geom); what they hold lies right of the image and is masked.
 // Dwords that START at or beyond W * H are still out of range, so rows below the image keep reading as zero.
-__device__ __forceinline__ Buf make_buf(const u8 *fr, u8 *out, u32 W, u32 H, Tile tl, u32 tail, u8 *rec = nullptr)
+__device__ __forceinline__ Buf make_buf(const u8 *fr, u8 *out, u32 W, u32 H, Tile tl, u32 tail)
 {
     Buf b;
     const u32 bytes = W * H;   // the host only selects the fast path when this (plus the halo) fits 32 bits
     b.rs = __builtin_amdgcn_make_buffer_rsrc(uniform_ptr(fr), 0, bytes + tail, 0x00020000);
     b.rd = __builtin_amdgcn_make_buffer_rsrc(uniform_ptr(out), 0, bytes, 0x00020000);
-    b.rr = __builtin_amdgcn_make_buffer_rsrc(uniform_ptr(rec ? rec : out), 0, bytes, 0x00020000);
     b.W = W;
     b.base = __builtin_amdgcn_readfirstlane(tl.Y0 * W + tl.X0);
-    b.vshift = b.vrow = b.vbase = 0;
     return b;
-}
-
-// ... reading through a view: the read descriptor spans the PARENT frame; rows below the plane lie beyond it (range check
-// -> 0, as ever), columns right of it do not occur (the host launches views on planes of whole tiles only)
-__device__ __forceinline__ void make_buf_view(Buf &b, const u8 *parent, const View &vw, Tile tl)
-{
-    b.rs = __builtin_amdgcn_make_buffer_rsrc(uniform_ptr(parent), 0, vw.pitch * vw.height, 0x00020000);
-    b.vshift = vw.shift;
-    b.vrow = vw.pitch << vw.shift;
-    b.vbase = __builtin_amdgcn_readfirstlane(tl.Y0 * b.vrow + (tl.X0 << vw.shift));
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1409,12 +1314,12 @@ struct TileCtx {
     Buf b;
 };
 
-__device__ __forceinline__ TileCtx fast_ctx(u32 t, const u8 *src, u8 *dst, const Frames &f, const TileGrid &g, u32 tail, u8 *rec = nullptr, u32 wv = 0)
+__device__ __forceinline__ TileCtx fast_ctx(u32 t, const u8 *src, u8 *dst, const Frames &f, const TileGrid &g, u32 tail, u32 wv = 0)
 {
     TileCtx c;
     c.tl = fast_tile(t, g, wv);
     c.b = make_buf(src + (size_t)c.tl.frame * f.frame_stride, dst + (size_t)c.tl.frame * f.frame_stride, f.width,
-                   f.height, c.tl, tail, rec ? rec + (size_t)c.tl.frame * f.frame_stride : nullptr);
+                   f.height, c.tl, tail);
     return c;
 }
 
@@ -1453,70 +1358,6 @@ __device__ __forceinline__ void dec_seed_commit(u8 *buf, const SeedRegs &r, u32 
 {
     if (r.on) buf[laddr(r.bx << k, r.by << k)] = (u8)r.rec;
     LDS_ORDER();
-}
-
-// ---- decode, seeds computed in the tile kernel itself (k = 6, at most two levels above it) -------------------------
-// A pyramid of 7 or 8 levels has one or two levels above a 64-row tile's six.  Their pixels are the stride-64 lattice, a
-// sw x sh plane with `up` = levels - 6 levels of its own, and a tile needs the reconstruction of 4 x 3 of its points.
-// Instead of coding that plane in launches of its own first (gather, decode: 9 us in front of a 16384^2 decode), every
-// wave rebuilds the few points it needs from the grid: the 5 x 5 patch of even/even plane points around its seeds (base
-// samples and, for up = 2, the level with step 4), then the seeds themselves.  Corners travel between lanes through the
-// LDS crossbar (ds_bpermute); nothing is exchanged between tiles -- neighbouring tiles recompute the same values, which
-// are pure functions of the grid (src/decoder.rs:30-44).  The loads go out with the tile's own staging loads.
-struct InlineSeeds {
-    u32 gv;          // grid byte of this lane's patch point (the seeds' own residuals are in the staged tile already)
-};
-
-__device__ __forceinline__ u32 grid_at(const u8 *__restrict__ fr, u32 W, u32 H, u32 px, u32 py)
-{
-    const u64 x = (u64)px << 6, y = (u64)py << 6;       // plane point (px, py) is image pixel (64 px, 64 py)
-    return (x < W && y < H) ? fr[y * W + x] : 0u;
-}
-
-__device__ __forceinline__ InlineSeeds inline_seed_issue(const u8 *__restrict__ fr, u32 W, u32 H, Tile tl, u32 up)
-{
-    const u32 lane = HGI_LANE, bm = (1u << up) - 1u;
-    const u32 px0 = tl.X0 >> 6, py0 = tl.Y0 >> 6, ax = px0 & ~bm, ay = py0 & ~bm;
-    InlineSeeds s;
-    s.gv = lane < 25u ? grid_at(fr, W, H, ax + 2u * (lane % 5u), ay + 2u * (lane / 5u)) : 0u;
-    return s;
-}
-
-__device__ __forceinline__ u32 lane_value(u32 v, u32 from) { return (u32)__builtin_amdgcn_ds_bpermute((int)(from << 2), (int)v); }
-
-// `buf`: the staged tile (after stage_commit): the residual of seed (bx, by) sits at its lattice position in the tile's
-// halo frame -- the byte dec_seed_commit() is about to replace by the reconstruction.
-template <int INTERP>
-__device__ __forceinline__ SeedRegs inline_seed_finish(const InlineSeeds &s, const u8 *buf, Tile tl, u32 up, u32 sw, u32 sh)
-{
-    const u32 lane = HGI_LANE, bm = (1u << up) - 1u;
-    const u32 px0 = tl.X0 >> 6, py0 = tl.Y0 >> 6, ax = px0 & ~bm, ay = py0 & ~bm;
-    // the patch: lane l < 25 holds plane point (ax + 2 (l % 5), ay + 2 (l / 5)); points outside the plane read 0
-    const u32 ix = lane % 5u, iy = lane / 5u, mx = ax + 2u * ix, my = ay + 2u * iy;
-    const bool in_patch = lane < 25u && mx < sw && my < sh;
-    u32 rec0 = in_patch ? s.gv : 0u;
-    if (up == 2) {      // level with step 4 (sub 2): points even/even, not both = 0 mod 4; corners = base points of the patch
-        const u32 cx = (mx & ~3u) - ax, cy = (my & ~3u) - ay;                    // cell origin relative to the patch: 0 or 4 (or 8)
-        const u32 jx = cx >> 1, jy = cy >> 1, j0 = jy * 5u + jx;                  // its patch index; the far corners are 2 further
-        const u32 lt = lane_value(rec0, j0), rt = lane_value(rec0, j0 + 10u), lb = lane_value(rec0, j0 + 2u), rb = lane_value(rec0, j0 + 12u);
-        const u32 p = pred1<INTERP>(lt, rt, lb, rb);
-        const bool base = !((mx | my) & 3u);
-        rec0 = in_patch ? (base ? s.gv : ((p + s.gv) & 255u)) : 0u;
-    }
-    // the seeds: lane i < 12 is plane point (px0 + i % 4, py0 + i / 4) -- seed_issue()'s layout at k = 6
-    SeedRegs r;
-    r.bx = (int)(lane & 3u);
-    r.by = (int)(lane >> 2);
-    r.on = lane < 12u;
-    r.q = 0;
-    const u32 sx = px0 + (lane & 3u), sy = py0 + (lane >> 2);
-    const u32 ox = ((sx & ~1u) - ax) >> 1, oy = ((sy & ~1u) - ay) >> 1, o0 = (oy * 5u + ox) & 63u;
-    const u32 lt = lane_value(rec0, o0), rt = lane_value(rec0, (o0 + 5u) & 63u), lb = lane_value(rec0, (o0 + 1u) & 63u), rb = lane_value(rec0, (o0 + 6u) & 63u);
-    const u32 p = pred1<INTERP>(lt, rt, lb, rb);
-    const bool even = !((sx | sy) & 1u), inside = sx < sw && sy < sh;
-    const u32 gs = r.on ? buf[laddr(r.bx << 6, r.by << 6)] : 0u;
-    r.rec = (r.on && inside) ? (even ? lt : ((p + gs) & 255u)) : 0u;
-    return r;
 }
 
 // ---- seeds rebuilt in the tile kernel, general form: the cone above a k = 4 tile (encode AND decode) ---------------
@@ -1561,7 +1402,7 @@ __device__ __forceinline__ u8 *cone_q_array(u8 *rbuf) { return rbuf + RCOL + 4 *
 static_assert(cone_n(TW, 0) == 10 && cone_n(TW, 1) == 6 && cone_n(TW, 2) == 4 && cone_n(TW, 3) == 3 && cone_n(TW, 4) == 3, "cone widths of a 128-pixel tile");
 
 struct ConeLane {
-    u32 v;            // levels >= 1: the lane's input byte (loaded, 0 outside the plane; filled from the frame otherwise)
+    u32 v, vq;        // levels >= 1: the lane's input byte (loaded, 0 outside the plane; filled from the frame otherwise); a base point that comes from seed planes: reconstruction and residual
     u32 t;            // its level (0: the lane has no point above level 0)
     u32 src1;         // LDS offset in the staged frame of a level >= 1 point that lies in it (framed1)
     bool framed1;
@@ -1578,9 +1419,12 @@ __device__ __forceinline__ u32 cone_corner(u32 x, u32 y, u32 A, u32 B, u32 T, u3
     return (((y & ~m2) - (B & ~m2)) >> (T + 1)) * nx2 + (((x & ~m2) - (A & ~m2)) >> (T + 1));
 }
 
-// Index work and the one load; nothing here waits.  fr: the frame (source or grid).
-__device__ __forceinline__ ConeLane cone_issue(const u8 *__restrict__ fr, u32 W, u32 sw, u32 sh, Tile tl, u32 up)
+// Index work and the one load; nothing here waits.  fr: the frame (source or grid).  Pyramids deeper than 4 + sd.up levels: the
+// base points come from the seed planes (stride-2^(4 + up) lattice, coded by earlier launches) instead of the frame.
+template <bool WANT_Q>
+__device__ __forceinline__ ConeLane cone_issue(const u8 *__restrict__ fr, u32 W, u32 H, const Seeds &sd, Tile tl)
 {
+    const u32 up = sd.up, sw = ((W - 1u) >> 4) + 1u, sh = ((H - 1u) >> 4) + 1u;      // the stride-16 plane
     constexpr u32 o2 = cone_off(2), o3 = cone_off(3), o4 = cone_off(4), o5 = cone_off(5);
     constexpr u32 nx0 = cone_n(TW, 0), ny0 = cone_n(TH, 0);
     const u32 lane = HGI_LANE, A = tl.X0 >> 4, B = tl.Y0 >> 4;
@@ -1602,11 +1446,18 @@ __device__ __forceinline__ ConeLane cone_issue(const u8 *__restrict__ fr, u32 W,
     const bool framed = x >= A && x < A + nx0 && y >= B && y < B + ny0;
     c.framed1 = c.in1 && framed;
     c.src1 = c.framed1 ? (u32)laddr((int)((x - A) << 4), (int)((y - B) << 4)) : 0u;
-    c.v = 0u;
-#ifdef HGI_CONE_ABL      // timing experiments: no load (wrong bytes)
-    if (!(HGI_CONE_ABL & 1))
-#endif
-    if (c.in1 && !framed) c.v = fr[((size_t)y << 4) * W + ((size_t)x << 4)];
+    c.v = c.vq = 0u;
+    if (t == up && sd.rec) {      // (uniform in sd.rec) the base, coded earlier: plane point (x >> up, y >> up)
+        c.framed1 = false;
+        if (c.in1) {
+            const size_t at = (size_t)tl.frame * sd.stride + (size_t)(y >> up) * sd.sw + (x >> up);
+            c.v = sd.rec[at];
+            if (WANT_Q) c.vq = sd.q[at];
+        }
+    } else if (c.in1 && !framed) {
+        c.v = fr[((size_t)y << 4) * W + ((size_t)x << 4)];
+    }
+    if (!WANT_Q || !sd.rec) c.vq = c.v;      // base samples of the frame itself: residual == sample
     // level 0: the seeds
     const u32 by = (lane * 26u) >> 8, bx = lane - by * nx0;      // lane / 10
     static_assert(nx0 == 10, "reciprocal above");
@@ -1643,7 +1494,7 @@ __device__ __forceinline__ SeedRegs cone_finish(const ConeLane &c, u8 *buf, u8 *
     const u32 v0 = c.on0 ? (u32)buf[(int)c.src0] : 0u;
     if (c.t == up) {      // base samples travel as they are (src/encoder.rs:26-37, src/decoder.rs:22-28); 0 outside
         R[lane] = (u8)v1;
-        if (ENC) Q[lane] = (u8)v1;
+        if (ENC) Q[lane] = (u8)(c.framed1 ? v1 : c.vq);
     }
     LDS_ORDER();
     for (u32 T = up - 1u; T >= 1u; --T) {         // (uniform)
@@ -1767,13 +1618,12 @@ __device__ __forceinline__ BlockRole block_role(const TileGrid &g)
 #ifndef HGI_DEC_WAVES_PER_EU
 #define HGI_DEC_WAVES_PER_EU 8
 #endif
-// SEEDED: 0 = the pyramid fits the tile; 1 = seeds from planes coded by earlier launches; 2 = seeds rebuilt in the kernel
-// (k == 6 and at most two levels above: sd.sw x sd.sh is the stride-64 plane, sd.stride carries `up`); 3 = the same in the
-// general form (cone_*: k == 4, up to four levels above: sd.sw x sd.sh is the stride-16 plane)
-// (that one is allowed 80 registers -- six waves per SIMD, 24 tiles per CU: the cone's bytes are live while the staging loads
-// fly, and the decoder's rate does not depend on occupancy down to 16 tiles per CU, profiles/r03_waves_sweep.txt)
+// SEEDED: 0 = the pyramid fits the tile; 1 = seeds from planes coded by earlier launches (sd.up == 0); 2 = seeds rebuilt in
+// the kernel (cone_*: k == 4, sd.up levels above the tile).  (That one is allowed 80 registers -- six waves per SIMD, 24 tiles
+// per CU: the cone's lane state is live while the staging loads fly, and the decoder's rate does not depend on occupancy
+// down to 16 tiles per CU, profiles/r03_waves_sweep.txt.)
 template <int INTERP, int SEEDED, int TILE_ROWS>   // TILE_ROWS == TH: only there to name the build in profiles
-__global__ __launch_bounds__(NL * NWAVES) __attribute__((amdgpu_waves_per_eu(SEEDED == 3 ? HGI_DEC_WAVES_PER_EU - 2 : HGI_DEC_WAVES_PER_EU))) void k_dec_tiles(const u8 *__restrict__ src, u8 *__restrict__ dst, Frames f, u32 k,
+__global__ __launch_bounds__(NL * NWAVES) __attribute__((amdgpu_waves_per_eu(SEEDED == 2 ? HGI_DEC_WAVES_PER_EU - 2 : HGI_DEC_WAVES_PER_EU))) void k_dec_tiles(const u8 *__restrict__ src, u8 *__restrict__ dst, Frames f, u32 k,
                                                   Seeds sd, TileGrid g, u32 aligned)
 {
     HGI_TL_ENTRY();
@@ -1793,27 +1643,19 @@ __global__ __launch_bounds__(NL * NWAVES) __attribute__((amdgpu_waves_per_eu(SEE
 #endif
     if (role.idle || (HGI_PAIR && role.edge && wv)) return;
     if (!role.edge) {
-        TileCtx cur = fast_ctx(role.index, src, dst, f, g, (aligned & 4u) ? 3u : 0u, nullptr, wv);
+        TileCtx cur = fast_ctx(role.index, src, dst, f, g, (aligned & 4u) ? 3u : 0u, wv);
         Stage st;
         SeedRegs seeds;
         HGI_MARK("stage_issue");
         HGI_TL_START();
         ConeLane cone;
-#if HGI_CONE_FIRST
-        if (SEEDED == 3) cone = cone_issue(src + (size_t)cur.tl.frame * f.frame_stride, W, sd.sw, sd.sh, cur.tl, (u32)sd.stride);
-#endif
         stage_issue<false>(st, cur.b, cur.tl, (int)k, nh, wv);
-#if !HGI_CONE_FIRST
-        if (SEEDED == 3) cone = cone_issue(src + (size_t)cur.tl.frame * f.frame_stride, W, sd.sw, sd.sh, cur.tl, (u32)sd.stride);
-#endif
-        InlineSeeds il = {0};
         if (SEEDED == 1) seeds = seed_issue<false>(sd, cur.tl, k);
-        if (SEEDED == 2) il = inline_seed_issue(src + (size_t)cur.tl.frame * f.frame_stride, W, H, cur.tl, (u32)sd.stride);
+        if (SEEDED == 2) cone = cone_issue<false>(src + (size_t)cur.tl.frame * f.frame_stride, W, H, sd, cur.tl);
         HGI_MARK("stage_commit");
         stage_commit<false>(buf, nullptr, st, nh, HGI_PAIR && wv == 0);
         LDS_ORDER();
-        if (SEEDED == 2) seeds = inline_seed_finish<INTERP>(il, buf, cur.tl, (u32)sd.stride, sd.sw, sd.sh);
-        if (SEEDED == 3) seeds = cone_finish<INTERP, false, true>(cone, buf, nullptr, (u32)sd.stride, nullptr);
+        if (SEEDED == 2) seeds = cone_finish<INTERP, false, true>(cone, buf, nullptr, sd.up, nullptr);
         LDS_ORDER();
         if (HGI_PAIR) {
             if (wv) pair_push_column<false>(buf, smem - HCOL, nullptr, nh);
@@ -1831,19 +1673,16 @@ __global__ __launch_bounds__(NL * NWAVES) __attribute__((amdgpu_waves_per_eu(SEE
     const u8 *fr = src + (size_t)tl.frame * f.frame_stride;
     u8 *out = dst + (size_t)tl.frame * f.frame_stride;
     SeedRegs seeds;
-    InlineSeeds il = {0};
-    if (SEEDED == 1) seeds = seed_issue<false>(sd, tl, k);
-    if (SEEDED == 2) il = inline_seed_issue(fr, W, H, tl, (u32)sd.stride);
     ConeLane cone;
-    if (SEEDED == 3) cone = cone_issue(fr, W, sd.sw, sd.sh, tl, (u32)sd.stride);
+    if (SEEDED == 1) seeds = seed_issue<false>(sd, tl, k);
+    if (SEEDED == 2) cone = cone_issue<false>(fr, W, H, sd, tl);
     if (aligned & 2u) {   // 32-bit buffer offsets: buffer staging and the check-free levels with edge masks
         TileCtx cur = {tl, make_buf(fr, out, W, H, tl, (aligned & 4u) ? 3u : 0u)};
         Stage st;
         stage_issue<true, true>(st, cur.b, tl, (int)k, nh);
         stage_commit<false>(buf, nullptr, st, nh);
         LDS_ORDER();
-        if (SEEDED == 2) seeds = inline_seed_finish<INTERP>(il, buf, tl, (u32)sd.stride, sd.sw, sd.sh);
-        if (SEEDED == 3) seeds = cone_finish<INTERP, false, true>(cone, buf, nullptr, (u32)sd.stride, nullptr);
+        if (SEEDED == 2) seeds = cone_finish<INTERP, false, true>(cone, buf, nullptr, sd.up, nullptr);
         if (SEEDED) dec_seed_commit(buf, seeds, k);
         if (tl.X0 + TW <= W && !(H & 1u))
             dec_tile_edge<INTERP, 1>(buf, cur, st.o, k, W, H);
@@ -1854,8 +1693,7 @@ __global__ __launch_bounds__(NL * NWAVES) __attribute__((amdgpu_waves_per_eu(SEE
     // frames whose byte offsets do not fit 32 bits: every access checked, 64-bit addressing
     stage_tile_generic(buf, fr, W, H, tl, nh, (aligned & 1u) != 0);
     LDS_ORDER();
-    if (SEEDED == 2) seeds = inline_seed_finish<INTERP>(il, buf, tl, (u32)sd.stride, sd.sw, sd.sh);
-    if (SEEDED == 3) seeds = cone_finish<INTERP, false, true>(cone, buf, nullptr, (u32)sd.stride, nullptr);
+    if (SEEDED == 2) seeds = cone_finish<INTERP, false, true>(cone, buf, nullptr, sd.up, nullptr);
     if (SEEDED) dec_seed_commit(buf, seeds, k);
     for (int s = 1 << (k - 1); s >= 2; s >>= 1) {
         dec_cells<INTERP, true>(buf, s, tl, W, H);
@@ -1879,7 +1717,7 @@ __device__ __forceinline__ void enc_seed_commit(u8 *buf, u8 *rbuf, const SeedReg
     LDS_ORDER();
 }
 
-template <int INTERP, bool IDENT, int EDGE, bool WREC>
+template <int INTERP, bool IDENT, int EDGE>
 __device__ __forceinline__ void enc_tile_edge(u8 *buf, u8 *rbuf, const u8 *slut, const TileCtx &cur,
                                               const v4u (&odd)[NFINE], u32 k, u32 W, u32 H)
 {
@@ -1898,10 +1736,10 @@ __device__ __forceinline__ void enc_tile_edge(u8 *buf, u8 *rbuf, const u8 *slut,
         enc_level2_fast<INTERP, IDENT, EDGE>(buf, rbuf, slut, cur.tl, W, H);
         LDS_ORDER();
     }
-    enc_fine_fast<INTERP, IDENT, EDGE, WREC>(buf, rbuf, slut, cur.b, odd, (int)(H - cur.tl.Y0), (int)(W - cur.tl.X0));
+    enc_fine_fast<INTERP, IDENT, EDGE>(buf, rbuf, slut, cur.b, odd, (int)(H - cur.tl.Y0), (int)(W - cur.tl.X0));
 }
 
-template <int INTERP, bool IDENT, bool WREC>
+template <int INTERP, bool IDENT>
 __device__ __forceinline__ void enc_tile_fast(u8 *buf, u8 *rbuf, const u8 *slut, const TileCtx &cur,
                                               const v4u (&odd)[NFINE], u32 k, u32 W, u32 H)
 {
@@ -1925,7 +1763,7 @@ __device__ __forceinline__ void enc_tile_fast(u8 *buf, u8 *rbuf, const u8 *slut,
         LDS_ORDER();
     }
     HGI_MARK("fine");
-    enc_fine_fast<INTERP, IDENT, 0, WREC>(buf, rbuf, slut, cur.b, odd);
+    enc_fine_fast<INTERP, IDENT, 0>(buf, rbuf, slut, cur.b, odd);
 }
 
 // Occupancy targets handed to the register allocator: encode fits 96 VGPRs (5 waves per SIMD, 20 per CU;
@@ -1933,13 +1771,10 @@ __device__ __forceinline__ void enc_tile_fast(u8 *buf, u8 *rbuf, const u8 *slut,
 #ifndef HGI_ENC_WAVES_PER_EU
 #define HGI_ENC_WAVES_PER_EU 5
 #endif
-// WREC (never together with SEEDED): the launch also writes the reconstruction of every pixel to `rec` (same geometry as
-// dst) -- the top of a deeper pyramid's chain codes the lattice plane once and hands both planes on as seeds.  These are
-// small, latency-bound launches (a lattice plane): their register budget is not held to the main kernels' occupancy
-// target -- the view staging keeps sixteen byte loads per chunk in flight.
-template <int INTERP, bool IDENT, int SEEDED, int TILE_ROWS, bool WREC = false>
-__global__ __launch_bounds__(NL * NWAVES) __attribute__((amdgpu_waves_per_eu(WREC ? 2 : IDENT ? HGI_ENC_WAVES_PER_EU - 1 : HGI_ENC_WAVES_PER_EU))) void k_enc_tiles(const u8 *__restrict__ src, u8 *__restrict__ dst, Frames f, u32 k,
-                                                  Lut256 lut, Seeds sd, TileGrid g, u32 aligned, u8 *__restrict__ rec, View vw)
+// SEEDED: as in k_dec_tiles
+template <int INTERP, bool IDENT, int SEEDED, int TILE_ROWS>
+__global__ __launch_bounds__(NL * NWAVES) __attribute__((amdgpu_waves_per_eu(IDENT ? HGI_ENC_WAVES_PER_EU - 1 : HGI_ENC_WAVES_PER_EU))) void k_enc_tiles(const u8 *__restrict__ src, u8 *__restrict__ dst, Frames f, u32 k,
+                                                  Lut256 lut, Seeds sd, TileGrid g, u32 aligned)
 {
     HGI_TL_ENTRY();
     extern __shared__ __attribute__((aligned(16))) u8 smem[];
@@ -1970,46 +1805,28 @@ __global__ __launch_bounds__(NL * NWAVES) __attribute__((amdgpu_waves_per_eu(WRE
     // and lands with them -- the table is first needed after staging has been committed to LDS anyway.
     u32 lutv = 0;
     if (!role.edge) {
-        TileCtx cur = fast_ctx(role.index, src, dst, f, g, (aligned & 4u) ? 3u : 0u, WREC ? rec : nullptr, wv);
+        TileCtx cur = fast_ctx(role.index, src, dst, f, g, (aligned & 4u) ? 3u : 0u, wv);
         Stage st;
         SeedRegs seeds;
         ConeLane cone;
         HGI_MARK("stage_issue");
         HGI_TL_START();
-        const bool through_view = WREC && vw.shift != 0;
-        if (through_view) {      // the lattice plane of a larger frame, staged straight from that frame (no gather launch)
-            u8 *oddbuf = smem + 256 + slice;                  // scratch behind the planes (the launcher sized LDS for it)
-            make_buf_view(cur.b, src + (size_t)cur.tl.frame * vw.frame_stride, vw, cur.tl);
-            stage_view_to_lds(buf, oddbuf, cur.b, (int)k, nh, cur.tl.X0 + TW < W);
-            if (!IDENT) lutv = lut.w[HGI_LANE];
-            LDS_ORDER();
-            lattice_from_buf(buf, rbuf, nh);
-#pragma unroll
-            for (int j = 0; j < NFINE; ++j)
-                st.o[j] = *reinterpret_cast<const v4u *>(oddbuf + (fine_pair0() + 8 * j) * TW + 16 * (HGI_LANE & (CH - 1)));
-        } else {
-#if HGI_CONE_FIRST
-            if (SEEDED == 2) cone = cone_issue(src + (size_t)cur.tl.frame * f.frame_stride, W, sd.sw, sd.sh, cur.tl, (u32)sd.stride);
-#endif
-            stage_issue<false>(st, cur.b, cur.tl, (int)k, nh, wv);
-            if (SEEDED == 1) seeds = seed_issue<true>(sd, cur.tl, k);
-#if !HGI_CONE_FIRST
-            if (SEEDED == 2) cone = cone_issue(src + (size_t)cur.tl.frame * f.frame_stride, W, sd.sw, sd.sh, cur.tl, (u32)sd.stride);
-#endif
-            if (!IDENT) lutv = lut.w[HGI_LANE];      // (pair build: both waves write the same table)
-            HGI_MARK("stage_commit");
-            stage_commit<true>(buf, rbuf, st, nh, HGI_PAIR && wv == 0);
-        }
+        stage_issue<false>(st, cur.b, cur.tl, (int)k, nh, wv);
+        if (SEEDED == 1) seeds = seed_issue<true>(sd, cur.tl, k);
+        if (SEEDED == 2) cone = cone_issue<true>(src + (size_t)cur.tl.frame * f.frame_stride, W, H, sd, cur.tl);
+        if (!IDENT) lutv = lut.w[HGI_LANE];      // (pair build: both waves write the same table)
+        HGI_MARK("stage_commit");
+        stage_commit<true>(buf, rbuf, st, nh, HGI_PAIR && wv == 0);
         if (!IDENT) reinterpret_cast<u32 *>(slut)[HGI_LANE] = lutv;
         LDS_ORDER();
-        if (SEEDED == 2) seeds = cone_finish<INTERP, true, IDENT>(cone, buf, rbuf, (u32)sd.stride, slut);
+        if (SEEDED == 2) seeds = cone_finish<INTERP, true, IDENT>(cone, buf, rbuf, sd.up, slut);
         if (HGI_PAIR) {
             if (wv) pair_push_column<true>(buf, smem + 256 - HCOL, smem + 256 + buf_bytes(nh) - RCOL, nh);
             __syncthreads();
         }
         HGI_TL_STAGED();
         enc_seed_commit<SEEDED>(buf, rbuf, seeds, k);
-        enc_tile_fast<INTERP, IDENT, WREC>(buf, rbuf, slut, cur, st.o, k, W, H);
+        enc_tile_fast<INTERP, IDENT>(buf, rbuf, slut, cur, st.o, k, W, H);
         HGI_MARK("end");
         HGI_TL_END();
         return;
@@ -2020,21 +1837,21 @@ __global__ __launch_bounds__(NL * NWAVES) __attribute__((amdgpu_waves_per_eu(WRE
     SeedRegs seeds;
     if (SEEDED == 1) seeds = seed_issue<true>(sd, tl, k);
     ConeLane cone;
-    if (SEEDED == 2) cone = cone_issue(fr, W, sd.sw, sd.sh, tl, (u32)sd.stride);
+    if (SEEDED == 2) cone = cone_issue<true>(fr, W, H, sd, tl);
     if (aligned & 2u) {   // 32-bit buffer offsets: buffer staging and the check-free levels with edge masks
-        TileCtx cur = {tl, make_buf(fr, out, W, H, tl, (aligned & 4u) ? 3u : 0u, WREC ? rec + (size_t)tl.frame * f.frame_stride : nullptr)};
+        TileCtx cur = {tl, make_buf(fr, out, W, H, tl, (aligned & 4u) ? 3u : 0u)};
         Stage st;
         stage_issue<true, true>(st, cur.b, tl, (int)k, nh);
         if (!IDENT) lutv = lut.w[HGI_LANE];
         stage_commit<true>(buf, rbuf, st, nh);
         if (!IDENT) reinterpret_cast<u32 *>(slut)[HGI_LANE] = lutv;
         LDS_ORDER();
-        if (SEEDED == 2) seeds = cone_finish<INTERP, true, IDENT>(cone, buf, rbuf, (u32)sd.stride, slut);
+        if (SEEDED == 2) seeds = cone_finish<INTERP, true, IDENT>(cone, buf, rbuf, sd.up, slut);
         enc_seed_commit<SEEDED>(buf, rbuf, seeds, k);
         if (tl.X0 + TW <= W && !(H & 1u))
-            enc_tile_edge<INTERP, IDENT, 1, WREC>(buf, rbuf, slut, cur, st.o, k, W, H);
+            enc_tile_edge<INTERP, IDENT, 1>(buf, rbuf, slut, cur, st.o, k, W, H);
         else
-            enc_tile_edge<INTERP, IDENT, 2, WREC>(buf, rbuf, slut, cur, st.o, k, W, H);
+            enc_tile_edge<INTERP, IDENT, 2>(buf, rbuf, slut, cur, st.o, k, W, H);
         return;
     }
     if (!IDENT) reinterpret_cast<u32 *>(slut)[HGI_LANE] = lut.w[HGI_LANE];
@@ -2042,7 +1859,7 @@ __global__ __launch_bounds__(NL * NWAVES) __attribute__((amdgpu_waves_per_eu(WRE
     LDS_ORDER();
     lattice_from_buf(buf, rbuf, nh);
     LDS_ORDER();
-    if (SEEDED == 2) seeds = cone_finish<INTERP, true, IDENT>(cone, buf, rbuf, (u32)sd.stride, slut);
+    if (SEEDED == 2) seeds = cone_finish<INTERP, true, IDENT>(cone, buf, rbuf, sd.up, slut);
     enc_seed_commit<SEEDED>(buf, rbuf, seeds, k);
     for (int s = 1 << (k - 1); s >= 2; s >>= 1) {
         enc_cells<INTERP, IDENT, true>(buf, rbuf, slut, s, tl, W, H);
@@ -2185,12 +2002,11 @@ hipError_t HGI_TILED(launch_decode_fused)(const uint8_t *grid, uint8_t *img, con
     finish_grid(r.g);
     const TileGrid &g = r.g;
     if (seeds && k < (uint32_t)kSeededMinLevels) return hipErrorInvalidValue;      // one lane per lattice point (seed_issue)
-    Seeds sd = seeds ? *seeds : Seeds{nullptr, nullptr, 0, 0, 0};
-    // seeds without planes: the kernel rebuilds them from the grid (inline_seed_*): six fused levels, one or two above them
-    // -- or, at four fused levels, up to four above them (cone_*)
-    const bool inline_seeds = seeds && !seeds->rec, cone = inline_seeds && k == 4;
-    if (inline_seeds && !cone && (TH != 64 || k != 6 || sd.stride < 1 || sd.stride > 2)) return hipErrorInvalidValue;
-    if (cone && (sd.stride < 1 || sd.stride > (u64)kConeMaxUp || HGI_PAIR)) return hipErrorInvalidValue;
+    Seeds sd = seeds ? *seeds : Seeds{nullptr, nullptr, 0, 0, 0, 0};
+    // sd.up levels above the tile are rebuilt by the kernel (cone_*): four fused levels, one lane per cone point
+    const bool cone = seeds && seeds->up != 0;
+    if (cone && (k != 4 || sd.up > (u32)kConeMaxUp || HGI_PAIR)) return hipErrorInvalidValue;
+    if (seeds && !cone && !seeds->rec) return hipErrorInvalidValue;
     const dim3 b(NL * NWAVES);
     const int nh = k >= 2 ? (int)k : 1;
     // A decode between one and eight rounds of resident tiles deep (8 192 ... 65 536 tiles: a lone 16384^2 frame has 32 768)
@@ -2207,9 +2023,8 @@ hipError_t HGI_TILED(launch_decode_fused)(const uint8_t *grid, uint8_t *img, con
 #define HGI_DEC_I(I)                                                     \
     do {                                                                 \
         if (!seeds) HGI_DEC(I, 0);                                       \
-        else if (!inline_seeds) HGI_DEC(I, 1);                           \
-        else if (cone) HGI_DEC(I, 3);                                    \
-        else if (TH == 64) HGI_DEC(I, (TH == 64 ? 2 : 1));               \
+        else if (!cone) HGI_DEC(I, 1);                                   \
+        else HGI_DEC(I, 2);                                              \
     } while (0)
     if (interp == kInterpCrossed) HGI_DEC_I(kInterpCrossed); else HGI_DEC_I(kInterpLeftTop);
 #undef HGI_DEC_I
@@ -2231,37 +2046,24 @@ hipError_t static_lds_is_empty(const void *kernel)
 }  // namespace
 
 hipError_t HGI_TILED(launch_encode_fused)(const uint8_t *img, uint8_t *grid, const Frames &f, uint32_t k, int interp,
-                                          const Lut256 &lut, bool ident, const Seeds *seeds, hipStream_t s, uint32_t row_limit, uint8_t *rec_out,
-                                          const View *view)
+                                          const Lut256 &lut, bool ident, const Seeds *seeds, hipStream_t s, uint32_t row_limit)
 {
-    // through a view `img` is the parent frame: the geometry checks below concern the plane (grid, rec_out); the parent only
-    // has to be addressable with 32-bit offsets
-    FusedGeom r = fused_geom(view ? grid : img, grid, f, row_limit);
+    FusedGeom r = fused_geom(img, grid, f, row_limit);
     if (!r.ok || k < 1 || k > (u32)MAXK) return hipErrorInvalidValue;
-    View vw = {0, 0, 0, 0};
-    if (view) {
-        const u64 row = (u64)view->pitch << view->shift;
-        if (!rec_out || seeds || r.g.nedge != 0 || !(r.aligned & 2u) || view->shift < 1 || view->shift > 8 ||
-            (u64)view->pitch * view->height >= (1ull << 32) || ((u64)f.height + 2 * TH + 64) * row >= (1ull << 32))
-            return hipErrorNotSupported;
-        vw = *view;
-    }
-    // the reconstruction output exists on the check-free paths only (and never under seeds): the caller falls back to
-    // decoding the grid it just made
-    if (rec_out && (seeds || !(r.aligned & 2u))) return hipErrorNotSupported;
     r.g.band = band_rows(f, true);
     r.g.xmode = xcd_mode();
     finish_grid(r.g);
     const TileGrid &g = r.g;
     if (seeds && k < (uint32_t)kSeededMinLevels) return hipErrorInvalidValue;      // one lane per lattice point (seed_issue)
-    Seeds sd = seeds ? *seeds : Seeds{nullptr, nullptr, 0, 0, 0};
-    // seeds without planes: the kernel rebuilds them from the frame (cone_*): four fused levels, up to four above them
-    const bool cone = seeds && !seeds->rec;
-    if (cone && (k != 4 || sd.stride < 1 || sd.stride > (u64)kConeMaxUp || HGI_PAIR)) return hipErrorInvalidValue;
+    Seeds sd = seeds ? *seeds : Seeds{nullptr, nullptr, 0, 0, 0, 0};
+    // sd.up levels above the tile are rebuilt by the kernel (cone_*): four fused levels, one lane per cone point
+    const bool cone = seeds && seeds->up != 0;
+    if (cone && (k != 4 || sd.up > (u32)kConeMaxUp || HGI_PAIR)) return hipErrorInvalidValue;
+    if (seeds && (!seeds->rec != !seeds->q || (!cone && !seeds->rec))) return hipErrorInvalidValue;
     const dim3 b(NL * NWAVES);
     const int nh = k >= 2 ? (int)k : 1;
     static const int enc_waves = getenv("HGI_ENC_WAVES") ? atoi(getenv("HGI_ENC_WAVES")) : 0;
-    const size_t lds = lds_for_waves(((size_t)buf_bytes(nh) + ((rbuf_bytes(nh) + 15) & ~15)) * NWAVES + 256 + (view ? (size_t)(TH / 2) * TW : 0), enc_waves);
+    const size_t lds = lds_for_waves(((size_t)buf_bytes(nh) + ((rbuf_bytes(nh) + 15) & ~15)) * NWAVES + 256, enc_waves);
     if (HGI_PAIR && (g.full_x & 1u)) return hipErrorInvalidValue;      // the experiment build pairs x-adjacent interior tiles
     const dim3 blocks(((g.nedge + 7u) & ~7u) + g.nfast / NWAVES);
     // lut_at() addresses the table from LDS offset 0: only valid while the kernel has no static LDS in front of its
@@ -2270,23 +2072,15 @@ hipError_t HGI_TILED(launch_encode_fused)(const uint8_t *img, uint8_t *grid, con
     do {                                                                                                          \
         static const hipError_t lds0 = static_lds_is_empty(reinterpret_cast<const void *>(&k_enc_tiles<I, ID, SE, TH>)); \
         if (lds0 != hipSuccess) return lds0;                                                                      \
-        hipLaunchKernelGGL((k_enc_tiles<I, ID, SE, TH>), blocks, b, lds, s, img, grid, f, k, lut, sd, g, r.aligned, (u8 *)nullptr, vw); \
-    } while (0)
-#define HGI_ENC_REC(I, ID)                                                                                        \
-    do {                                                                                                          \
-        static const hipError_t lds0 = static_lds_is_empty(reinterpret_cast<const void *>(&k_enc_tiles<I, ID, 0, TH, true>)); \
-        if (lds0 != hipSuccess) return lds0;                                                                      \
-        hipLaunchKernelGGL((k_enc_tiles<I, ID, 0, TH, true>), blocks, b, lds, s, img, grid, f, k, lut, sd, g, r.aligned, rec_out, vw); \
+        hipLaunchKernelGGL((k_enc_tiles<I, ID, SE, TH>), blocks, b, lds, s, img, grid, f, k, lut, sd, g, r.aligned); \
     } while (0)
 #define HGI_ENC_I(I)                                                          \
     do {                                                                      \
-        if (rec_out) { if (ident) HGI_ENC_REC(I, true); else HGI_ENC_REC(I, false); } \
-        else if (ident) { if (cone) HGI_ENC(I, true, 2); else if (seeds) HGI_ENC(I, true, 1); else HGI_ENC(I, true, 0); } \
+        if (ident) { if (cone) HGI_ENC(I, true, 2); else if (seeds) HGI_ENC(I, true, 1); else HGI_ENC(I, true, 0); } \
         else       { if (cone) HGI_ENC(I, false, 2); else if (seeds) HGI_ENC(I, false, 1); else HGI_ENC(I, false, 0); } \
     } while (0)
     if (interp == kInterpCrossed) HGI_ENC_I(kInterpCrossed); else HGI_ENC_I(kInterpLeftTop);
 #undef HGI_ENC_I
-#undef HGI_ENC_REC
 #undef HGI_ENC
     return hipGetLastError();
 }

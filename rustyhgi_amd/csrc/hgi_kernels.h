@@ -34,26 +34,23 @@ struct Frames {
     uint32_t batch;
 };
 
-// Compact planes holding the stride-2^k lattice of a deeper pyramid (levels > kFusedMaxLevels):
-// seed_rec = reconstructed values, seed_q = grid (residual) values, both sw x sh per frame.
+// What a tile launch of a pyramid deeper than its fused depth k starts from.
+//   up == 0: compact planes holding the stride-2^k lattice, coded by earlier launches: rec = reconstructed values, q = grid
+//            (residual) values (encode only), both sw x sh per frame, `stride` bytes apart.
+//   up >= 1 (k == 4 only): the tile kernel rebuilds the `up` (<= 4) levels above the tile itself (hgi_fused_impl.h, cone_*).
+//            rec == nullptr: the pyramid has 4 + up levels, the cone's base are the frame's own base samples.
+//            rec != nullptr: the pyramid is deeper still; the planes hold the stride-2^(4 + up) lattice -- the cone's base.
 struct Seeds {
     const uint8_t *rec;
     const uint8_t *q;
     uint32_t sw, sh;
     uint64_t stride;
+    uint32_t up;
 };
 
 #ifdef HGI_TIMELINE
 extern uint64_t *g_timeline;   // experiment builds only (tools/timeline.py): where the tile kernels log their blocks
 #endif
-
-// A lattice of a larger frame seen as an image of its own: plane pixel (x, y) is parent byte (y << shift) * pitch + (x << shift).
-// The encoder's plane launch (reconstruction out) can stage its tiles straight through such a view, which saves the gather
-// launch in front of it (hgi_fused_impl.h, stage_issue_view); shift == 0: no view, `img` is the plane itself.
-struct View {
-    uint32_t shift, pitch, height;   // parent geometry
-    uint64_t frame_stride;           // bytes between parent frames
-};
 
 // ---- level-wise path: one launch per level, straight global-memory stencil -----------------
 hipError_t launch_seed(const uint8_t *src, uint8_t *dst, const Frames &f, uint32_t levels,
@@ -65,16 +62,13 @@ hipError_t launch_encode_level(uint8_t *rec, uint8_t *grid, const Frames &f, uin
 
 // ---- fused path: the last k <= kFusedMaxLevels levels of every tile in one launch ------------
 // (_64 / _32 = tile rows; k <= kFusedMaxLevels resp. kFusedMaxLevelsSmall; row_limit: pixel rows (multiple of 64)
-// above which tile rows are launched, 0 = all -- bands of a frame that is still being uploaded; rec_out: the encoder
-// also writes its reconstruction there (unseeded launches on the check-free paths only, else hipErrorNotSupported);
-// view (with rec_out only): `img` is the PARENT frame and the launch codes its lattice plane -- f describes the plane --
-// which must consist of whole tiles (else hipErrorNotSupported))
+// above which tile rows are launched, 0 = all -- bands of a frame that is still being uploaded)
 #define HGI_DECLARE_FUSED(TH)                                                                                      \
     hipError_t launch_decode_fused_##TH(const uint8_t *grid, uint8_t *img, const Frames &f, uint32_t k, int interp, \
                                         const Seeds *seeds, hipStream_t s, uint32_t row_limit);                    \
     hipError_t launch_encode_fused_##TH(const uint8_t *img, uint8_t *grid, const Frames &f, uint32_t k, int interp, \
                                         const Lut256 &lut, bool lut_is_identity, const Seeds *seeds, hipStream_t s, \
-                                        uint32_t row_limit, uint8_t *rec_out, const View *view);
+                                        uint32_t row_limit);
 HGI_DECLARE_FUSED(64)
 HGI_DECLARE_FUSED(32)
 HGI_DECLARE_FUSED(16)

@@ -587,25 +587,23 @@ def test_hip_graph_capture_and_replay(H, ctxs, oracle):
 
 
 @pytest.mark.parametrize("mode", ["HGI_FORCE_CHECKED=1", "HGI_TILE_H=64", "HGI_TILE_H=32", "HGI_TILE_H=16", "HGI_NO_LATTICE_KERNEL=1",
-                                  "HGI_CONE=0", "HGI_CONE_MIN_ENC=5,HGI_CONE_MIN_DEC=5", "HGI_CONE_MIN_ENC=5,HGI_CONE_MIN_DEC=5,HGI_TILE_H=16",
+                                  "HGI_DEC_REVERSE=1", "HGI_CONE_MIN_ENC=5,HGI_CONE_MIN_DEC=5", "HGI_CONE_MIN_ENC=5,HGI_CONE_MIN_DEC=5,HGI_TILE_H=16",
                                   "HGI_CONE_MIN_ENC=5,HGI_CONE_MIN_DEC=5,HGI_TILE_H=32", "HGI_CONE_MIN_ENC=5,HGI_CONE_MIN_DEC=5,HGI_TILE_H=64",
-                                  "HGI_CONE_MIN_ENC=5,HGI_CONE_MIN_DEC=5,HGI_FORCE_CHECKED=1",
-                                  "HGI_CONE=0,HGI_NO_LATTICE_KERNEL=1,HGI_NO_ENC_REC=1", "HGI_DEC_REVERSE=1", "HGI_CONE=0,HGI_NO_INLINE_SEEDS=1",
-                                  "HGI_CONE=0,HGI_NO_INLINE_SEEDS=1,HGI_NO_LATTICE_KERNEL=1", "HGI_CONE=0,HGI_DEEP_K_ENC=4,HGI_DEEP_K_DEC=4,HGI_NO_LATTICE_KERNEL=1",
-                                  "HGI_CONE=0,HGI_DEEP_K_ENC=4,HGI_NO_LATTICE_KERNEL=1,HGI_NO_ENC_VIEW=1",
+                                  "HGI_CONE_MIN_ENC=5,HGI_CONE_MIN_DEC=5,HGI_FORCE_CHECKED=1", "HGI_NO_LATTICE_KERNEL=1,HGI_FORCE_CHECKED=1",
+                                  "HGI_CONE=0", "HGI_CONE=0,HGI_NO_LATTICE_KERNEL=1", "HGI_CONE=0,HGI_DEEP_K_ENC=4,HGI_DEEP_K_DEC=4,HGI_NO_LATTICE_KERNEL=1",
                                   "HGI_CONE=0,HGI_DEEP_K_ENC=4,HGI_DEEP_K_DEC=4", "HGI_CONE=0,HGI_DEEP_K_ENC=5,HGI_DEEP_K_DEC=5"])
 def test_forced_code_paths_in_a_child_process(mode):
     """The library picks tile geometry and code path per launch: 128x16, 128x32 or 128x64 tiles, and the fully checked path only
     for widths that are not multiples of 4 or frames beyond 32-bit offsets.  Each switch is read once per process, so a
     child process re-runs the shape-heavy parity cases with one of them forced: aligned shapes through the checked
-    path, small shapes through 64-row tiles, large ones through 32-row and (pyramids up to four levels) 16-row tiles, deep pyramids through the host recursion
-    instead of the one-workgroup lattice kernel -- with the lattice plane's encoder writing its reconstruction itself
-    (one launch) and with the older encode-then-decode chain (HGI_NO_ENC_REC) --, the decoder walking its tile list
-    backwards, seven- and eight-level decodes through seed planes instead of seeds rebuilt inside the tile kernel, and deep
-    pyramids split at four or five levels instead of six (what a lone 16384^2 encode does by itself;
-    the bytes must not depend on the split).  Pyramids of seven and eight levels run as ONE launch that rebuilds the levels
-    above a four-level tile for itself (the cone): HGI_CONE=0 keeps all the older chains under test, HGI_CONE_MIN_*=5 sends
-    five- and six-level pyramids through the cone too, on every tile height and through the fully checked path."""
+    path, small shapes through 64-row tiles, large ones through 32-row and (pyramids up to four levels) 16-row tiles, the
+    decoder walking its tile list backwards.  Pyramids of six to eight levels run as ONE launch that rebuilds the levels
+    above a four-level tile for itself (the cone), deeper ones code the stride-256 lattice first -- in the one-workgroup
+    lattice kernel, or (HGI_NO_LATTICE_KERNEL) by host recursion: gather, encode, decode -- and start the cone from its
+    planes.  HGI_CONE_MIN_*=5 sends five-level pyramids through the cone too, on every tile height and through the
+    fully checked path; HGI_CONE=0 switches the cone off: six fused levels (or four / five: HGI_DEEP_K_*) on seed planes of
+    the stride-2^k lattice, which is also what frames coded band by band from host memory use.  The bytes must not
+    depend on any of it."""
     import os
     import subprocess
     import sys
@@ -620,10 +618,9 @@ def test_forced_code_paths_in_a_child_process(mode):
 
 @pytest.mark.parametrize("w,h,levels,batch", [(2048, 512, 7, 2), (4096, 1024, 8, 1), (2048, 2048, 9, 1), (4096, 512, 6, 3)])
 def test_deep_pyramid_plane_of_whole_tiles(H, oracle, w, h, levels, batch):
-    """Frames whose stride-16 lattice plane consists of whole tiles: with the pyramid split at four levels and the
-    one-workgroup lattice kernel off (the forced-path child processes do that) the encoder's plane launch stages its tiles
-    straight from the frame through a view -- no gather launch -- and writes residuals and reconstruction in one go; here,
-    with the default switches, the same shapes go through whatever the library picks.  Bytes must not depend on it."""
+    """Frames of whole tiles whose pyramids are deeper than a tile, in batches: six to eight levels in one launch (the cone
+    on interior tiles only), nine through the stride-256 lattice first; the forced-path child processes re-run them with
+    the cone off and the lattice kernel off.  Bytes must not depend on it."""
     import torch
     from rustyhgi_amd import _ffi
     L = _ffi.lib()
