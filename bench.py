@@ -535,8 +535,8 @@ class Codec:
         """BASELINE config C4 -- ONE 16384 x 16384 u8 frame ramp(4), level 8, High, Crossed: the only config whose single
         launch exceeds the 256 MiB Infinity Cache.  Timed in the bench step's own pattern (encode, then decode of what
         was just written), per launch with events on the codec's stream, after the frame stacks of the headline workload
-        have been released.  A deep pyramid: each direction is a short chain of launches (lattice plane first, then the
-        seeded tile launch; profiles/r03_c4_summary.md has the rocprofv3 rows)."""
+        have been released.  A deep pyramid, yet ONE launch per direction: the tile kernel runs four fused levels and
+        rebuilds the four above a tile for itself (profiles/r03_c4_summary.md has the rocprofv3 rows)."""
         import hashlib
         torch, H, _ffi = self.torch, self.H, self._ffi
         L = _ffi.lib()
@@ -569,7 +569,7 @@ class Codec:
             def dec():
                 _ffi.check(L.hgi_decode_u8_dev(self.ctx.handle, grid.data_ptr(), W, W, 8, 1, out.data_ptr(), 1, n))
 
-            reps, warm = 30, 60
+            reps, warm = 60, 120
             ev = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(reps)]
             for i in range(warm + reps):
                 e = ev[max(i - warm, 0)]
@@ -579,8 +579,9 @@ class Codec:
                 dec()
                 e[2].record()
             torch.cuda.synchronize(self.dev)
-            e_us = float(np.mean([e[0].elapsed_time(e[1]) for e in ev])) * 1e3
-            d_us = float(np.mean([e[1].elapsed_time(e[2]) for e in ev])) * 1e3
+            e_all = np.array([e[0].elapsed_time(e[1]) for e in ev]) * 1e3
+            d_all = np.array([e[1].elapsed_time(e[2]) for e in ev]) * 1e3
+            e_us, d_us = float(e_all.mean()), float(d_all.mean())
             c_us = self._timed(lambda: _ffi.check(L.hgi_copy_u8_dev(self.ctx.handle, img.data_ptr(), out.data_ptr(), n)), 20, warm=5) * 1e3
             dec()
             torch.cuda.synchronize(self.dev)
@@ -594,14 +595,19 @@ class Codec:
                 pass
             alg = 2.0 * n
 
-            def rate(us):
-                return {"us": round(us, 2), "achieved": round(alg / us / 1e3, 1), "unit": "GB/s", "frac": round(alg / us / 1e3 / HBM_PEAK_GBS, 4)}
+            def rate(us, series=None):
+                r = {"us": round(us, 2), "achieved": round(alg / us / 1e3, 1), "unit": "GB/s", "frac": round(alg / us / 1e3 / HBM_PEAK_GBS, 4)}
+                if series is not None:
+                    r.update({"calls": int(series.size), "min_us": round(float(series.min()), 2), "median_us": round(float(np.median(series)), 2),
+                              "max_us": round(float(series.max()), 2)})
+                return r
 
-            res.update({"algorithmic_bytes_per_call": alg, "peak": HBM_PEAK_GBS, "encode": rate(e_us), "decode": rate(d_us),
+            res.update({"algorithmic_bytes_per_call": alg, "peak": HBM_PEAK_GBS, "encode": rate(e_us, e_all), "decode": rate(d_us, d_all),
                         "copy_same_run": rate(c_us), "max_abs_err": max_err, "grid_sha256": sha[:16],
                         "grid_matches_golden": (sha == want) if want else None,
-                        "note": "per CALL (a deep pyramid is a chain of launches: lattice plane, then the seeded tile launch); "
-                                "decode reads the grid the encode before it has just written, as in the bench step"})
+                        "launches_per_call": 1,
+                        "note": "per CALL, mean of the timed calls (one launch each: four fused levels, the four above a tile "
+                                "rebuilt in the kernel); decode reads the grid the encode before it has just written, as in the bench step"})
             del img, grid, out
             if c4_planes is not None:
                 c4_planes.close()

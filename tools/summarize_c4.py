@@ -59,8 +59,10 @@ def main(out):
             print("| %d | `%s` | %.2f | %.2f | %s |" % (i + 1, k, st, du, "%.2f" % gap if i else "-"))
         span = sum(c[-1][1] - c[0][0] for c in same) / len(same) / 1e3
         main_d = sum(c[-1][1] - c[-1][0] for c in same) / len(same) / 1e3
-        print("\ndevice span of the call %.1f us = %.0f GB/s algorithmic (2 x %d B) = **%.3f of 8 TB/s**; the main launch alone %.1f us = %.3f\n" % (
-            span, ALG / span / 1e3, N, ALG / span / 8e6, main_d, ALG / main_d / 8e6))
+        spans = sorted((c[-1][1] - c[0][0]) / 1e3 for c in same)
+        print("\ndevice span of the call %.1f us = %.0f GB/s algorithmic (2 x %d B) = **%.3f of 8 TB/s**; the main launch alone %.1f us = %.3f; "
+              "spans of the %d calls: min %.1f / median %.1f / max %.1f us\n" % (
+                  span, ALG / span / 1e3, N, ALG / span / 8e6, main_d, ALG / main_d / 8e6, len(spans), spans[0], spans[len(spans) // 2], spans[-1]))
     # all kernels, stats
     dur = defaultdict(list)
     for s, e, k in ks:
