@@ -16,7 +16,7 @@ import sys
 import tempfile
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-KERNELS = {"hgi_fused_enc.hip": "k_enc_tilesILi1ELb0ELb0ELi64", "hgi_fused_dec.hip": "k_dec_tilesILi1ELb0ELi64"}
+KERNELS = {"hgi_fused_enc.hip": "k_enc_tilesILi1ELb0ELi0ELi64", "hgi_fused_dec.hip": "k_dec_tilesILi1ELi0ELi64"}
 
 
 def classify(ins):
