@@ -473,9 +473,13 @@ def test_batch_layouts_and_alignment(H, ctxs, oracle):
 
 
 @pytest.mark.parametrize("w,h,levels", [(8192, 64, 4), (128, 4096, 6), (16, 5000, 3), (5000, 16, 3), (2048, 2048, 31),
-                                        (129, 65, 31), (1920, 1080, 1), (1920, 1080, 2), (1936, 1096, 6)])
+                                        (129, 65, 31), (1920, 1080, 1), (1920, 1080, 2), (1936, 1096, 6),
+                                        (1, 1, 8), (1, 300, 7), (300, 1, 6), (16, 16, 8), (17, 33, 7), (255, 257, 8), (256, 256, 9),
+                                        (4097, 130, 8), (130, 4097, 10), (8192, 48, 7), (3, 5000, 8)])
 def test_extreme_shapes_and_levels(ctxs, oracle, w, h, levels):
-    """Strips, tile-boundary +1 sizes, levels = 31 (only the base sample (0,0) seeds the whole image)."""
+    """Strips, tile-boundary +1 sizes, levels = 31 (only the base sample (0,0) seeds the whole image); pyramids of six and
+    more levels on frames smaller than, equal to and one pixel beyond the lattices their cone walks (a single pixel, single
+    rows and columns, 16, 17, 255 ... 257 pixels, strips one tile high and thousands wide)."""
     img = oracle.synth(oracle.SYNTH_NOISE, 77, levels, w, h)
     for q in (0, 2):
         lut = oracle.linear_lut(q)[0]
