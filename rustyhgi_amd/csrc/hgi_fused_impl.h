@@ -1361,7 +1361,8 @@ __device__ __forceinline__ void dec_seed_commit(u8 *buf, const SeedRegs &r, u32 
 }
 
 // ---- seeds rebuilt in the tile kernel, general form: the cone above a k = 4 tile (encode AND decode) ---------------
-// A pyramid of 5 ... 8 levels run with four fused levels has `up` = 1 ... 4 levels above the tile; their pixels are the
+// A pyramid run with four fused levels has `up` = 1 ... 4 levels above the tile that the tile rebuilds (and, beyond eight
+// levels, seed planes of the stride-256 lattice under those: Seeds in hgi_kernels.h); their pixels are the
 // stride-16 lattice, a sw x sh plane with a pyramid of its own, and the tile needs reconstruction (encode: and residual)
 // of (TW / 16 + 2) x (TH / 16 + 2) of its points -- seed_issue()'s layout.  What those depend on is a CONE: a point that
 // is new at plane step 2s takes its corners from the multiples of 2s around it (src/interpolator.rs:57-91), so level by
@@ -1373,8 +1374,8 @@ __device__ __forceinline__ void dec_seed_commit(u8 *buf, const SeedRegs &r, u32 
 // which fetches the point's byte (source pixel when encoding, grid byte when decoding) with a single load instruction
 // behind the tile's staging loads -- or takes it from the staged frame when the point lies in it -- and prepares its
 // indices while the loads fly.  After staging the wave walks the levels from the base down: the lanes of a level read
-// their four corners of the coarser level from a small LDS array, predict, code (src/encoder.rs:46-65) or add the
-// residual (src/decoder.rs:32-41), and write their point to the array; last the 60 seeds, which stay in registers.
+// their four corners of the coarser level from a small byte array in LDS, predict, code (src/encoder.rs:46-65) or add
+// the residual (src/decoder.rs:32-41), and write their point to the array; last the 60 seeds, which stay in registers.
 // Neighbouring tiles recompute the same points -- pure functions of the input -- so nothing is exchanged and no launch
 // runs in front of the tile kernel (a 16384^2 level-8 encode had a 9 us plane launch there).  Points outside the plane
 // are 0, which is the out-of-image rule of the corners.
@@ -1402,11 +1403,12 @@ __device__ __forceinline__ u8 *cone_q_array(u8 *rbuf) { return rbuf + RCOL + 4 *
 static_assert(cone_n(TW, 0) == 10 && cone_n(TW, 1) == 6 && cone_n(TW, 2) == 4 && cone_n(TW, 3) == 3 && cone_n(TW, 4) == 3, "cone widths of a 128-pixel tile");
 
 struct ConeLane {
-    u32 v, vq;        // levels >= 1: the lane's input byte (loaded, 0 outside the plane; filled from the frame otherwise); a base point that comes from seed planes: reconstruction and residual
+    u32 v, vq;        // levels >= 1: the lane's input byte (loaded; 0 outside the plane; read from the staged frame at the walk when
+                      // framed1).  A base point taken from seed planes: v = reconstruction, vq = residual
     u32 t;            // its level (0: the lane has no point above level 0)
     u32 src1;         // LDS offset in the staged frame of a level >= 1 point that lies in it (framed1)
     bool framed1;
-    u32 from1, nx1;   // first corner in R (u32 index) and the pitch of that level's array
+    u32 from1, nx1;   // index of its first corner in the arrays, and the pitch of that (coarser) level's box
     bool in1, down1;  // inside the plane / a point of the coarser lattice (handed down)
     u32 src0, from0;  // the same for the lane's seed (level 0, lanes < 10 x ny0)
     bool on0, in0, down0;
