@@ -84,10 +84,10 @@ HGI_API hgi_status hgi_ctx_use_own_stream(hgi_ctx *ctx);
 HGI_API hgi_status hgi_ctx_set_path(hgi_ctx *ctx, hgi_path path);
 /* Pre-size scratch so later *_dev calls allocate nothing (needed before graph capture). */
 /* Scratch only grows, and growing it FREES the old block: a HIP graph captured from calls */
-/* that used scratch (levels > 8; the level-wise path) keeps pointing at the block it was  */
-/* captured with, so                                                                      */
-/* reserve for the largest shape the ctx will ever see BEFORE capturing, and do not let a  */
-/* later, larger call on the same ctx grow it while such graphs are alive.                 */
+/* that used scratch (pyramids deeper than eight levels; the level-wise path) keeps        */
+/* pointing at the block it was captured with, so reserve for the largest shape the ctx    */
+/* will ever see BEFORE capturing, and do not let a later, larger call on the same ctx     */
+/* grow it while such graphs are alive.                                                    */
 HGI_API hgi_status hgi_ctx_reserve(hgi_ctx *ctx, uint32_t width, uint32_t height, uint32_t levels,
                            size_t batch);
 HGI_API hgi_status hgi_sync(hgi_ctx *ctx);
