@@ -116,6 +116,12 @@ static_assert(TH != 64 || 18 * (buf_bytes(4) + rbuf_bytes(4) + 256) <= 160 * 102
 #define HGI_ABL 0   // timing experiments: 1 no coarse levels, 2 no fine arithmetic, 4 no halo cells, 8 no sub==2 level,
                     // 16 no halo-column loads, 32 no halo-row loads
 #endif
+#ifndef HGI_DEC_CONE_FIRST
+#define HGI_DEC_CONE_FIRST 0     // the decoder's cone load in front of the tile's staging loads (1) or behind them (0)
+#endif
+#ifndef HGI_DEC_SHALLOW_WAVES
+#define HGI_DEC_SHALLOW_WAVES 20  // resident tiles per CU asked for on decodes 1-8 rounds deep (launch_decode_fused)
+#endif
 #ifndef HGI_XCD_MODE
 #define HGI_XCD_MODE 1      // default of the XCD dealing policy (block_role); HGI_XCD_MODE in the environment overrides it
 #endif
@@ -1651,9 +1657,14 @@ __global__ __launch_bounds__(NL * NWAVES) __attribute__((amdgpu_waves_per_eu(SEE
         HGI_MARK("stage_issue");
         HGI_TL_START();
         ConeLane cone;
+#if HGI_DEC_CONE_FIRST
+        if (SEEDED == 2) cone = cone_issue<false>(src + (size_t)cur.tl.frame * f.frame_stride, W, H, sd, cur.tl);
+#endif
         stage_issue<false>(st, cur.b, cur.tl, (int)k, nh, wv);
         if (SEEDED == 1) seeds = seed_issue<false>(sd, cur.tl, k);
+#if !HGI_DEC_CONE_FIRST
         if (SEEDED == 2) cone = cone_issue<false>(src + (size_t)cur.tl.frame * f.frame_stride, W, H, sd, cur.tl);
+#endif
         HGI_MARK("stage_commit");
         stage_commit<false>(buf, nullptr, st, nh, HGI_PAIR && wv == 0);
         LDS_ORDER();
@@ -2017,7 +2028,7 @@ hipError_t HGI_TILED(launch_decode_fused)(const uint8_t *grid, uint8_t *img, con
     // and draining the chip costs -- shorter.  (The encoder needs all 20 it can get: 98 us, 106 at 16.)
     static const int dec_waves_forced = getenv("HGI_DEC_WAVES") ? atoi(getenv("HGI_DEC_WAVES")) : -1;
     const u64 tiles = (u64)g.nfast + g.nedge;
-    const int dec_waves = dec_waves_forced >= 0 ? dec_waves_forced : (tiles >= 8192 && tiles < 65536 ? 20 : 0);
+    const int dec_waves = dec_waves_forced >= 0 ? dec_waves_forced : (tiles >= 8192 && tiles < 65536 ? HGI_DEC_SHALLOW_WAVES : 0);
     const size_t lds = lds_for_waves((size_t)buf_bytes(nh) * NWAVES, dec_waves);
     if (HGI_PAIR && (g.full_x & 1u)) return hipErrorInvalidValue;      // the experiment build pairs x-adjacent interior tiles
     const dim3 blocks(((g.nedge + 7u) & ~7u) + g.nfast / NWAVES);
