@@ -32,6 +32,8 @@ def alone(fn):
     b.record(); torch.cuda.synchronize()
     return a.elapsed_time(b) / reps * 1e3
 te1, td1 = alone(enc), alone(dec)
+def pair(): enc(); dec()
+tp = alone(pair)      # the bench pattern without an event between the two calls
 hg = hashlib.sha256(grid.cpu().numpy().tobytes()).hexdigest()[:16]; ho = hashlib.sha256(out.cpu().numpy().tobytes()).hexdigest()[:16]
-print("separated=%s k_enc=%s k_dec=%s  %d x %dx%d L%d: encode %.1f us (%.0f GB/s)  decode %.1f us (%.0f GB/s)  | back to back: encode %.1f decode %.1f us | grid %s out %s" % (
-    planes.separated, os.environ.get("HGI_DEEP_K_ENC", "6"), os.environ.get("HGI_DEEP_K_DEC", "6"), F, W, Hh, LEVELS, te, 2 * F * n / te / 1e3, td, 2 * F * n / td / 1e3, te1, td1, hg, ho))
+print("separated=%s  %d x %dx%d L%d: encode %.1f us (%.0f GB/s)  decode %.1f us (%.0f GB/s)  | encode+decode pairs, no event in between: %.1f us per pair (%.3f of 8 TB/s) | back to back: encode %.1f decode %.1f us | grid %s out %s" % (
+    planes.separated, F, W, Hh, LEVELS, te, 2 * F * n / te / 1e3, td, 2 * F * n / td / 1e3, tp, 4 * F * n / tp / 8e6, te1, td1, hg, ho))
