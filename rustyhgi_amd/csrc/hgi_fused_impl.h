@@ -116,6 +116,9 @@ static_assert(TH != 64 || 18 * (buf_bytes(4) + rbuf_bytes(4) + 256) <= 160 * 102
 #define HGI_ABL 0   // timing experiments: 1 no coarse levels, 2 no fine arithmetic, 4 no halo cells, 8 no sub==2 level,
                     // 16 no halo-column loads, 32 no halo-row loads
 #endif
+#ifndef HGI_ODD_LATE
+#define HGI_ODD_LATE 1      // interior tiles request their odd rows after the even rows are committed (stage_issue_odd); 0: with them
+#endif
 #ifndef HGI_DEC_CONE_FIRST
 #define HGI_DEC_CONE_FIRST 0     // the decoder's cone load in front of the tile's staging loads (1) or behind them (0)
 #endif
@@ -834,7 +837,7 @@ __device__ __forceinline__ void stage_issue(Stage &st, const Buf &b, Tile tl, in
 #pragma unroll
     for (int j = 0; j < NFINE; ++j) {
         st.o[j] = v4u{0, 0, 0, 0};
-        if (!RAGGED) st.o[j] = __builtin_amdgcn_raw_buffer_load_b128(b.rs, vodd, j * 16 * W, HGI_ODD_LOAD_AUX);
+        if (!RAGGED && !HGI_ODD_LATE) st.o[j] = __builtin_amdgcn_raw_buffer_load_b128(b.rs, vodd, j * 16 * W, HGI_ODD_LOAD_AUX);
         if (RAGGED && ODD_CHECKED && cin) st.o[j] = __builtin_amdgcn_raw_buffer_load_b128(b.rs, vodd + j * 16 * W, 0, HGI_ODD_LOAD_AUX);
         if (narrow) st.o[j] &= cm;
     }
@@ -871,6 +874,22 @@ __device__ __forceinline__ void stage_issue(Stage &st, const Buf &b, Tile tl, in
         issue_body();
         issue_halo();
     }
+}
+
+// The odd rows of an interior tile -- half its bytes, first needed by the finest level -- are requested only after the even
+// rows have been committed: the tile waits for half as much before its first level, and the rest flies while the coarse
+// levels compute.  What that buys depends on how deep the launch is (tools/ab.py, profiles/r03_ab_odd_late.txt): a lone
+// 8192^2 frame -11 % / -6 %, 4096^2 -8 % / -9 %, 16384^2 level 8 -5 % / -3 %, 16 x 4096^2 -4 % / -2 %, 64 x 4096^2 -0.6 % /
+// +0.4 % -- fill and drain of a launch are made of tile lifetimes, the steady state is not.  Issuing everything up front and
+// waiting for the even rows only (halo loads first, HGI_HALO_FIRST) gains a third of that: what helps is fewer requests
+// queued at once, not the shorter wait alone.
+__device__ __forceinline__ void stage_issue_odd(Stage &st, const Buf &b)
+{
+    const int c = HGI_LANE & (CH - 1);
+    const u32 W = __builtin_amdgcn_readfirstlane(b.W);
+    const u32 vodd = b.base + (2 * fine_pair0() + 1) * W + 16 * c;
+#pragma unroll
+    for (int j = 0; j < NFINE; ++j) st.o[j] = __builtin_amdgcn_raw_buffer_load_b128(b.rs, vodd, j * 16 * W, HGI_ODD_LOAD_AUX);
 }
 
 // the even bytes of a 16-B row chunk: its eight even/even lattice points
@@ -1668,6 +1687,7 @@ __global__ __launch_bounds__(NL * NWAVES) __attribute__((amdgpu_waves_per_eu(SEE
         HGI_MARK("stage_commit");
         stage_commit<false>(buf, nullptr, st, nh, HGI_PAIR && wv == 0);
         LDS_ORDER();
+        if (HGI_ODD_LATE) stage_issue_odd(st, cur.b);
         if (SEEDED == 2) seeds = cone_finish<INTERP, false, true>(cone, buf, nullptr, sd.up, nullptr);
         LDS_ORDER();
         if (HGI_PAIR) {
@@ -1832,6 +1852,7 @@ __global__ __launch_bounds__(NL * NWAVES) __attribute__((amdgpu_waves_per_eu(IDE
         stage_commit<true>(buf, rbuf, st, nh, HGI_PAIR && wv == 0);
         if (!IDENT) reinterpret_cast<u32 *>(slut)[HGI_LANE] = lutv;
         LDS_ORDER();
+        if (HGI_ODD_LATE) stage_issue_odd(st, cur.b);
         if (SEEDED == 2) seeds = cone_finish<INTERP, true, IDENT>(cone, buf, rbuf, sd.up, slut);
         if (HGI_PAIR) {
             if (wv) pair_push_column<true>(buf, smem + 256 - HCOL, smem + 256 + buf_bytes(nh) - RCOL, nh);
