@@ -19,6 +19,7 @@ gloo backend and NO codec work (there is no CPU codec in the product): what the 
 `python bench.py --gpus 2` starts two ranks and returns one line.  Its line carries "rehearsal": true and value null.
 """
 import argparse
+import gc
 import json
 import os
 import socket
@@ -237,12 +238,16 @@ def run_rank(args):
     if codec:
         codec.make_events(args.steps)
     fence()
+    gc_was_on = gc.isenabled()
+    gc.disable()      # (a collection in the middle of the enqueue loop would leave the device idle)
     t0 = time.perf_counter()
     for k in range(args.steps):
         if codec:
             codec.timed_step(k)
     fence()
     elapsed = batch.max_over_ranks(dist, time.perf_counter() - t0, cdev)
+    if gc_was_on:
+        gc.enable()
 
     if rehearse:
         # what the ranks would gather: [squared error, max error, checksum] -- here the shard itself, so that the
@@ -455,6 +460,12 @@ class Codec:
 
     def make_events(self, steps):
         self.ev = [[self.torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(steps)]
+        # torch creates the HIP event behind an Event at its first record(): do that here, not inside the timed region
+        # (60 hipEventCreate calls cost nothing on a warm box and have cost 10 ms of idle GPU on a freshly started one)
+        for trio in self.ev:
+            for e in trio:
+                e.record()
+        self.torch.cuda.synchronize(self.dev)
 
     def timed_step(self, k):
         ev = self.ev[k]
