@@ -1687,6 +1687,7 @@ __global__ __launch_bounds__(NL * NWAVES) __attribute__((amdgpu_waves_per_eu(SEE
         HGI_MARK("stage_commit");
         stage_commit<false>(buf, nullptr, st, nh, HGI_PAIR && wv == 0);
         LDS_ORDER();
+        HGI_TL_STAGED();      // (timeline build: waits for everything requested so far -- in front of the odd rows' request)
         if (HGI_ODD_LATE) stage_issue_odd(st, cur.b);
         if (SEEDED == 2) seeds = cone_finish<INTERP, false, true>(cone, buf, nullptr, sd.up, nullptr);
         LDS_ORDER();
@@ -1694,7 +1695,6 @@ __global__ __launch_bounds__(NL * NWAVES) __attribute__((amdgpu_waves_per_eu(SEE
             if (wv) pair_push_column<false>(buf, smem - HCOL, nullptr, nh);
             __syncthreads();
         }
-        HGI_TL_STAGED();
         if (SEEDED) dec_seed_commit(buf, seeds, k);
         dec_tile_fast<INTERP>(buf, cur, st.o, k, W, H);
         HGI_MARK("end");
@@ -1852,13 +1852,13 @@ __global__ __launch_bounds__(NL * NWAVES) __attribute__((amdgpu_waves_per_eu(IDE
         stage_commit<true>(buf, rbuf, st, nh, HGI_PAIR && wv == 0);
         if (!IDENT) reinterpret_cast<u32 *>(slut)[HGI_LANE] = lutv;
         LDS_ORDER();
+        HGI_TL_STAGED();
         if (HGI_ODD_LATE) stage_issue_odd(st, cur.b);
         if (SEEDED == 2) seeds = cone_finish<INTERP, true, IDENT>(cone, buf, rbuf, sd.up, slut);
         if (HGI_PAIR) {
             if (wv) pair_push_column<true>(buf, smem + 256 - HCOL, smem + 256 + buf_bytes(nh) - RCOL, nh);
             __syncthreads();
         }
-        HGI_TL_STAGED();
         enc_seed_commit<SEEDED>(buf, rbuf, seeds, k);
         enc_tile_fast<INTERP, IDENT>(buf, rbuf, slut, cur, st.o, k, W, H);
         HGI_MARK("end");
