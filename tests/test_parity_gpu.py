@@ -125,7 +125,7 @@ def test_criterion_bench_image(ctxs, oracle, golden, path):
                                         (1280, 640, 8), (1001, 333, 8), (2000, 300, 7), (640, 1280, 8)])
 @pytest.mark.parametrize("path", ["fused", "levelwise"])
 def test_random_shapes_and_tables(ctxs, oracle, w, h, levels, path):
-    """Tile-edge, ragged and deeper-than-tile (levels > 6: lattice recursion) shapes with noise input
+    """Tile-edge, ragged and deeper-than-tile (levels 6 ... 8: the cone; beyond: the stride-256 lattice first) shapes with noise input
     and ARBITRARY quantizer tables, so the overflow fallback fires often (src/encoder.rs:56-60)."""
     rng = np.random.default_rng(w * 7919 + h * 31 + levels)
     img = rng.integers(0, 256, (h, w), dtype=np.uint8)
