@@ -1339,6 +1339,25 @@ struct TileCtx {
     Buf b;
 };
 
+// Every launch constant the prologue of an interior tile reads is asked for at the kernel's first instruction, in one go:
+// left to itself the compiler places the scalar loads next to their uses, in three dependent rounds (block role -> tile
+// index -> addresses), each a trip to the scalar cache.  Worth 0.1-0.2 us of a tile's lifetime, which shows where launches
+// are shallow (tools/ab.py, profiles/r03_ab_args_early.txt: 16384^2 level 8 encode -1.7 %, lone 4096^2 -2.7 % / -1.6 %,
+// 1024^2 -2.3 % / -2.8 %, 64 x 4096^2 0).  -DHGI_ARGS_EARLY=0: the compiler's placement.
+#ifndef HGI_ARGS_EARLY
+#define HGI_ARGS_EARLY 1
+#endif
+__device__ __forceinline__ void args_early(const u8 *src, const u8 *dst, const Frames &f, const TileGrid &g, u32 aligned, u32 k)
+{
+#if HGI_ARGS_EARLY
+    asm volatile("" ::"s"(k), "s"(g.full_x), "s"(g.full_y), "s"(g.tiles_x), "s"(g.tiles_y));
+    asm volatile("" ::"s"(src), "s"(dst), "s"(f.width), "s"(f.height), "s"(f.frame_stride), "s"(aligned), "s"(g.nedge), "s"(g.nf), "s"(g.xmode),
+                 "s"(g.rr_own), "s"(g.rr_tail0), "s"(g.P), "s"(g.fd_P.m), "s"(g.fd_P.s1), "s"(g.fd_P.s2), "s"(g.reverse), "s"(g.tpf), "s"(g.fd_tpf.m),
+                 "s"(g.fd_tpf.s1), "s"(g.fd_tpf.s2), "s"(g.nfull), "s"(g.rem_rows), "s"(g.band), "s"(g.ex), "s"(g.fd_band.m), "s"(g.fd_band.s1),
+                 "s"(g.fd_band.s2), "s"(g.fd_rem.m), "s"(g.fd_rem.s1), "s"(g.fd_rem.s2));
+#endif
+}
+
 __device__ __forceinline__ TileCtx fast_ctx(u32 t, const u8 *src, u8 *dst, const Frames &f, const TileGrid &g, u32 tail, u32 wv = 0)
 {
     TileCtx c;
@@ -1654,6 +1673,7 @@ __global__ __launch_bounds__(NL * NWAVES) __attribute__((amdgpu_waves_per_eu(SEE
                                                   Seeds sd, TileGrid g, u32 aligned)
 {
     HGI_TL_ENTRY();
+    args_early(src, dst, f, g, aligned, k);
     extern __shared__ __attribute__((aligned(16))) u8 smem[];
 #ifdef HGI_ANALYZE_K
     k = HGI_ANALYZE_K;
@@ -1810,6 +1830,7 @@ __global__ __launch_bounds__(NL * NWAVES) __attribute__((amdgpu_waves_per_eu(IDE
                                                   Lut256 lut, Seeds sd, TileGrid g, u32 aligned)
 {
     HGI_TL_ENTRY();
+    args_early(src, dst, f, g, aligned, k);
     extern __shared__ __attribute__((aligned(16))) u8 smem[];
 #ifdef HGI_ANALYZE_K
     k = HGI_ANALYZE_K;
