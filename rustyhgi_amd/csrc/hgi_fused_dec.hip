@@ -3,6 +3,9 @@
 // rows unpadded: k = 4 needs 4 848 B of LDS per wave; ~50 VGPRs, so 8 waves per SIMD.  Measured on the
 // 64 x 4096^2 shard: row pad 0 / 16 / 32 B -> 0.396 / 0.403 / 0.402 ms.
 #define HGI_FUSED_DECODE 1
+#if defined(HGI_DEC_STORE_AUX) && !defined(HGI_STORE_AUX)
+#define HGI_STORE_AUX HGI_DEC_STORE_AUX      // experiments: a store policy for this direction only
+#endif
 #ifndef HGI_S_PAD
 #define HGI_S_PAD 0
 #endif

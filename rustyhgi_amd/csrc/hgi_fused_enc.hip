@@ -3,6 +3,9 @@
 // (21 waves per CU); the kernel is held to 96 VGPRs = 5 waves per SIMD.  Row pad 0 / 32 B -> 0.414 / 0.422 ms
 // on the 64 x 4096^2 shard.
 #define HGI_FUSED_ENCODE 1
+#if defined(HGI_ENC_STORE_AUX) && !defined(HGI_STORE_AUX)
+#define HGI_STORE_AUX HGI_ENC_STORE_AUX      // experiments: a store policy for this direction only
+#endif
 #ifndef HGI_S_PAD
 #define HGI_S_PAD 0
 #endif
