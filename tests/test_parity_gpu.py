@@ -823,6 +823,22 @@ def test_banded_host_frames(ctxs, oracle, w, h, levels):
     assert_same(gpu_decode(ctxs["fused"], want, levels), oracle.decode(want, levels), "banded decode %dx%d L%d" % (w, h, levels))
 
 
+@pytest.mark.parametrize("w,h,levels", [(4096, 1100, 8), (2048, 2500, 7), (2304, 2000, 12)])
+def test_banded_deep_pyramid_first_call_on_fresh_context(H, oracle, w, h, levels):
+    """The banded host path codes deep pyramids at six fused levels on seed planes of its own (a band cannot rebuild levels
+    from rows that are not uploaded yet) and reserves that scratch itself: the very first call on a context must find it
+    (the device-resident path of the same depth needs none, so its estimate says nothing about this one)."""
+    img = oracle.synth(oracle.SYNTH_RAMP, SEED0 + 17, levels, w, h)
+    lut = oracle.linear_lut(1)[0]
+    want = oracle.encode(img, levels, lut)
+    ctx = H.Context(0)
+    assert_same(gpu_encode(ctx, img, levels, lut), want, "first call, banded encode %dx%d L%d" % (w, h, levels))
+    ctx.close()
+    ctx = H.Context(0)
+    assert_same(gpu_decode(ctx, want, levels), oracle.decode(want, levels), "first call, banded decode %dx%d L%d" % (w, h, levels))
+    ctx.close()
+
+
 def test_banded_bands_never_read_rows_of_the_next_upload():
     """Deterministic form of the band / halo dependency (a tile of a band's last tile row reads input rows down to
     offset 2^k = 64 below the band INCLUSIVE at levels = 6: 65 rows, not 64).  HGI_TEST_BAND_HOLD poisons the device
