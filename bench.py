@@ -3,12 +3,16 @@
 
   python bench.py --gpus N --steps K --warmup W
 
+The workload is BASELINE.json configs[3] itself: a batch of 512 independent 4096 x 4096 frames, sharded by frame over the N
+GPUs -- 512 // N frames per GPU, "scaling": "strong" -- so N = 1 runs the literal config on one GPU (three planes of 8 GiB) and
+N = 8 the 64-frame shards of the 8 x MI355X form.  `--frames F` runs F frames per GPU instead ("scaling": "weak").
+
 N > 1 without a rendezvous in the environment: this process becomes a LAUNCHER -- it never touches the GPU, starts
 `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...` as a child (one rank per GPU over
 RCCL), relays rank 0's JSON line and exits with the child's code.  Started under torchrun (WORLD_SIZE set) it is a
 rank, as before.
 
-One step = one pass of the hot path over this rank's batch: encode `frames` frames, then decode
+One step = one pass of the hot path over this rank's shard: encode its frames, then decode
 them (BASELINE.json config C3, sharded by frame; frames are generated in place on each GPU from the
 global frame index, so no pixel ever crosses xGMI).  Inputs are resident in HBM before the timed
 region.  RCCL is used only where the batch split needs it: broadcast of the quantizer table and
@@ -56,40 +60,87 @@ def table_quantizator(table, error):
     return TableQuantizator(table, error)
 
 
-def pmc_traffic(kernel, frames, size, levels):
-    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (FETCH_SIZE with the
-    gfx950 x2 correction + WRITE_SIZE; tools/profile.sh -> profiles/*_traffic.json), if that profile was
-    taken on this exact workload; else None.  bench.py cannot run the profiler on itself."""
-    for name in ("r03_traffic.json", "r02_traffic.json", "r01_traffic.json"):      # newest committed profile of this workload
+def build_stamp():
+    """What identifies the library build a number was measured on: SHA-256 over the library's SOURCES (csrc/*.hip, *.h, the
+    Makefile, the version script, include/hgi.h) -- a rebuild of the same sources on another box keeps it, any change to a
+    kernel or its flags moves it -- beside the hash of the shared object that is loaded and the library's own version string."""
+    import hashlib
+    csrc = os.path.join(ROOT, "rustyhgi_amd", "csrc")
+    files = sorted(os.path.join(csrc, f) for f in os.listdir(csrc) if f.endswith((".hip", ".h", ".map")) or f == "Makefile")
+    files.append(os.path.join(ROOT, "include", "hgi.h"))
+    h = hashlib.sha256()
+    for path in files:
+        h.update(os.path.basename(path).encode() + b"\0")
+        with open(path, "rb") as f:
+            h.update(f.read())
+    stamp = {"source_sha256": h.hexdigest()[:16]}
+    try:
+        from rustyhgi_amd import _ffi
+        with open(_ffi.LIB_PATH, "rb") as f:
+            stamp["lib_sha256"] = hashlib.sha256(f.read()).hexdigest()[:16]
+        stamp["lib"] = os.path.basename(_ffi.LIB_PATH)
+        stamp["version"] = _ffi.lib().hgi_version().decode()
+    except Exception as e:      # (the stamp is information: never let it cost the line)
+        stamp["lib_error"] = str(e)
+    return stamp
+
+
+def pmc_traffic(kernel, frames, size, levels, stamp):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (FETCH_SIZE with the gfx950 x2 correction +
+    WRITE_SIZE; tools/profile.sh -> profiles/*_traffic.json) -- if that profile was taken on this exact workload AND on this
+    build of the library (its recorded source hash equals the running one's); else None, with the reason.  bench.py cannot run
+    the profiler on itself."""
+    why = "no committed profile of this workload"
+    for name in ("r04_traffic.json", "r04_traffic_64.json", "r03_traffic.json", "r02_traffic.json", "r01_traffic.json"):
         try:
             with open(os.path.join(ROOT, "profiles", name)) as f:
                 prof = json.load(f)
             if prof["workload"] != {"frames": frames, "size": size, "levels": levels}:
                 continue
-            return prof["kernels"][kernel]["hbm_bytes_per_launch"]
+            have = prof.get("build", {}).get("source_sha256")
+            if have != stamp.get("source_sha256"):
+                why = "profiles/%s was taken on another build of the library (source hash %s, running %s)" % (name, have, stamp.get("source_sha256"))
+                continue
+            return prof["kernels"][kernel]["hbm_bytes_per_launch"], "profiles/" + name
         except (OSError, KeyError, ValueError):
             continue
-    return None
+    return None, why
 
 
 def cpu_baseline(args, lut, gpu_check):
-    """The oracle ('port' of the reference: scalar, one thread per image) timed on this host's cores
-    over a bounded sample of the same workload.  Also re-checks the GPU result on those frames."""
+    """The oracle ('port' of the reference: scalar, one thread per image, src/encoder.rs:45-68) timed on ALL of this host's
+    cores over a bounded sample of the same workload: as many threads as this process may run on, two frames each (one each
+    beyond 128 threads), about a second of wall time.  `cores` is the number of threads used; `host_cores` what the machine
+    reports.  Also re-checks the GPU result on those frames."""
     from oracle import hgi_oracle as O
-    cores = os.cpu_count() or 1
-    threads = max(1, min(cores, 64))
-    frames = max(threads * 2, 8)
-    imgs = np.stack([O.synth(O.SYNTH_RAMP, SEED0 + 3, f, args.size, args.size) for f in range(2)])
-    imgs = np.concatenate([imgs] * ((frames + 1) // 2))[:frames]
-    r = O.bench_batch(imgs, args.levels, lut, threads)
-    for f in (0, 1):
-        assert (r["grids"][f] == gpu_check["grid"][f]).all(), "GPU encode differs from the oracle"
-        assert (r["outs"][f] == gpu_check["out"][f]).all(), "GPU decode differs from the oracle"
-    px = frames * args.size * args.size
-    return {"value": round(px / r["wall_s"] / 1e6, 1), "unit": "Mpixels/s", "cores": threads, "kind": "port",
-            "sample": "%d frames %dx%d L%d %s, encode+decode, one oracle thread per frame, %.2f s wall"
-                      % (frames, args.size, args.size, args.levels, args.quant, r["wall_s"]),
-            "one_thread_mpix_s": round(px / (r["enc_cpu_s"] + r["dec_cpu_s"]) / 1e6, 1)}
+    host_cores = os.cpu_count() or 1
+    try:
+        usable = len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        usable = host_cores
+    threads = max(1, usable)
+    base = np.stack([O.synth(O.SYNTH_RAMP, SEED0 + 3, f, args.size, args.size) for f in range(2)])
+
+    def run(nthreads):
+        frames = max(nthreads * (2 if nthreads <= 128 else 1), 8)
+        imgs = np.concatenate([base] * ((frames + 1) // 2))[:frames]
+        r = O.bench_batch(imgs, args.levels, lut, nthreads)
+        for f in (0, 1):
+            assert (r["grids"][f] == gpu_check["grid"][f]).all(), "GPU encode differs from the oracle"
+            assert (r["outs"][f] == gpu_check["out"][f]).all(), "GPU decode differs from the oracle"
+        px = frames * args.size * args.size
+        return {"value": round(px / r["wall_s"] / 1e6, 1), "threads": nthreads, "frames": frames, "wall_s": round(r["wall_s"], 3),
+                "one_thread_mpix_s": round(px / (r["enc_cpu_s"] + r["dec_cpu_s"]) / 1e6, 1)}
+
+    full = run(threads)
+    res = {"value": full["value"], "unit": "Mpixels/s", "cores": threads, "host_cores": host_cores, "threads": threads, "kind": "port",
+           "sample": "%d frames %dx%d L%d %s, encode+decode, one oracle thread per frame on %d threads (every core this process may "
+                     "run on; the host reports %d), %.2f s wall"
+                     % (full["frames"], args.size, args.size, args.levels, args.quant, threads, host_cores, full["wall_s"]),
+           "one_thread_mpix_s": full["one_thread_mpix_s"]}
+    if threads > 64:      # rounds 1-3 capped the leg at 64 threads: the same sample shape there, so that the lines compare
+        res["at_64_threads"] = run(64)
+    return res
 
 
 def parse_args(argv=None):
@@ -97,7 +148,10 @@ def parse_args(argv=None):
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--frames", type=int, default=64, help="frames per GPU per step (C3: 512 / 8)")
+    ap.add_argument("--frames", type=int, default=None,
+                    help="frames per GPU per step: WEAK scaling.  Default: none -- the batch of --global-frames is sharded over the GPUs "
+                         "(512 // N per GPU), STRONG scaling: N = 1 is BASELINE configs[3] itself")
+    ap.add_argument("--global-frames", type=int, default=512, help="frames of the whole batch when --frames is not given (C3: 512)")
     ap.add_argument("--size", type=int, default=4096)
     ap.add_argument("--levels", type=int, default=4)
     ap.add_argument("--quant", default="medium")
@@ -114,10 +168,19 @@ def parse_args(argv=None):
                          "for the counter comparison of DESIGN.md 5.1 -- deliberately all three in ONE region (planes 0, 2, 4 of five)")
     ap.add_argument("--share-gpu", action="store_true",
                     help="every rank uses cuda:0 and the collectives go over gloo (RCCL refuses two ranks on one device): "
-                         "the whole N-rank path with the real codec on a ONE-GPU box; `value` then says nothing about scaling")
+                         "the whole N-rank path with the real codec on a ONE-GPU box; `value` then says nothing about scaling "
+                         "(at most 6 ranks: the GPU boxes allow six processes on a card)")
     ap.add_argument("--rehearse", action="store_true",
                     help="CPU rehearsal of the multi-rank plumbing (gloo, no codec work, value null)")
     return ap.parse_args(argv)
+
+
+def shard_plan(args, world):
+    """("strong", frames of the whole batch) by default -- BASELINE configs[3]'s 512 frames sharded over the ranks (SURVEY 8(e):
+    "1/2/4/8 GPUs x C3") -- or ("weak", world * F) when --frames F fixes the frames per GPU."""
+    if args.frames is not None:
+        return "weak", int(world) * int(args.frames)
+    return "strong", int(args.global_frames)
 
 
 def free_port():
@@ -201,10 +264,13 @@ def run_rank(args):
     if dist is not None:
         print("bench.py: rank %d has the broadcast parameters (levels %d, max error %d)" % (rank, levels, err), file=sys.stderr)
 
-    F, S = args.frames, args.size
-    # frame f of rank r is global frame r*F + f of config C3 (ramp(3)): produced where it is used
-    first, count = batch.shard(world * F, world, rank)
-    assert count == F
+    S = args.size
+    # frame f of this rank is global frame first + f of config C3 (ramp(3)): produced where it is used
+    scaling, G = shard_plan(args, world)
+    first, F = batch.shard(G, world, rank)
+    if F < 1:
+        print("bench.py: %d frames cannot be sharded over %d ranks" % (G, world), file=sys.stderr)
+        return 2
 
     def sync():
         if not rehearse:
@@ -219,7 +285,7 @@ def run_rank(args):
     if rehearse:
         codec = None
     else:
-        codec = Codec(args, dev, local, lut, err, levels, first)
+        codec = Codec(args, dev, local, lut, err, levels, first, F)
 
     # The device's clocks ramp over the first ~25 ms of work after idle, and the encoder (75 % VALU utilisation at full
     # clock) runs up to 1.4x slower until they have (tools/ramp.py, profiles/r02_ramp.txt; the decoder, 45 %, does not
@@ -252,19 +318,19 @@ def run_rank(args):
     if rehearse:
         # what the ranks would gather: [squared error, max error, checksum] -- here the shard itself, so that the
         # launcher test can see that every rank took its own block
-        mine = torch.tensor([first, count, rank], dtype=torch.int64)
+        mine = torch.tensor([first, F, rank], dtype=torch.int64)
         allst = batch.gather_stats(dist, mine)
         # ... and the per-rank timing record of the real run (see per_rank_record): here each rank sends numbers derived
         # from its rank, so that the launcher test can see every rank's row arrive in rank order
-        per_rank = per_rank_record(batch, dist, [0.001 * (rank + 1), 1.0, 0.5 + rank, 0.25 + rank, 8.0 * (rank + 1)])
+        per_rank = per_rank_record(batch, dist, [0.001 * (rank + 1), 1.0, 0.5 + rank, 0.25 + rank, 8.0 * (rank + 1), float(F)])
         if rank == 0:
             emit(json.dumps({
                 "metric": "Mpixels/s encode+decode, 4K grayscale level=4 Medium", "value": None, "unit": "Mpixels/s",
                 "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-                "ms_per_step": round(elapsed / max(args.steps, 1) * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+                "ms_per_step": round(elapsed / max(args.steps, 1) * 1e3, 4), "higher_is_better": True, "scaling": scaling,
                 "vs_baseline": None, "dtype": "u8", "data": "none", "rehearsal": True,
                 "config": {"workload": "rehearsal of the rank plumbing on the CPU (gloo): no codec work",
-                           "frames_per_gpu": F, "global_frames": world * F, "parallelism": "frames sharded x%d" % world,
+                           "frames_per_gpu": F, "global_frames": G, "parallelism": "frames sharded x%d" % world,
                            "levels": levels, "max_error": err, "table_sum": int(np.asarray(lut, np.int64).sum()),
                            "shards": [[int(a), int(b)] for a, b, _ in allst], "per_rank": per_rank}}))
         if dist is not None:
@@ -276,7 +342,7 @@ def run_rank(args):
     copy_ms = codec.copy_ms() if rank == 0 else None
     pfine = codec.p_fine() if rank == 0 and not (args.no_pfine or args.no_extras) else None
     placement = codec.placement(compare=not args.no_extras) if rank == 0 else None
-    xgmi = codec.xgmi(dist, world, rank, fence, args.steps) if args.xgmi_scatter and not args.share_gpu else None
+    xgmi = codec.xgmi(dist, world, rank, fence, args.steps, G // world) if args.xgmi_scatter and dist is not None else None
     entropy = codec.entropy_stage() if rank == 0 and world == 1 and not args.no_extras else None
 
     c4 = codec.c4() if rank == 0 and world == 1 and not (args.no_extras or args.no_c4) else None
@@ -285,7 +351,7 @@ def run_rank(args):
     # every rank's own view of its run, so that a multi-GPU line explains itself: how long plane placement took there and
     # whether it succeeded (setup skew between ranks), and its own launch times (a slow GPU shows up by rank)
     per_rank = per_rank_record(batch, dist, [codec.setup_s, 1.0 if codec.separated else 0.0, enc_ms, dec_ms,
-                                             float(settle["steps"]) if settle else 0.0], cdev)
+                                             float(settle["steps"]) if settle else 0.0, float(F)], cdev)
     allst = batch.gather_stats(dist, codec.stats().to(cdev))
     if dist is not None:
         print("bench.py: rank %d gathered the statistics of %d ranks" % (rank, len(allst)), file=sys.stderr)
@@ -293,28 +359,33 @@ def run_rank(args):
         assert int(allst[:, 1].max()) <= err, "reconstruction error exceeds the quantizer bound"
 
     if rank == 0:
-        px_step = world * F * S * S
+        px_step = G * S * S                       # every rank's shard: the whole batch once per step
         value = px_step * args.steps / elapsed / 1e6
         dom, dom_ms = ("encode", enc_ms) if enc_ms >= dec_ms else ("decode", dec_ms)
-        alg_bytes = 2.0 * F * S * S               # 2 B/px per direction, one launch per batch
+        alg_bytes = 2.0 * F * S * S               # 2 B/px per direction, one launch per shard (rank 0's: the largest)
         achieved = alg_bytes / (dom_ms * 1e-3) / 1e9
         kernel = "k_%s_tiles" % ("enc" if dom == "encode" else "dec")
-        traffic = pmc_traffic(kernel, F, S, levels)
+        stamp = build_stamp()
+        traffic, traffic_from = pmc_traffic(kernel, F, S, levels, stamp)
+        if world == 1 and scaling == "strong" and G == 512:
+            workload = "C3: %d frames of %dx%d u8 ramp(3), level=%d %s, Crossed, encode then decode, HBM-resident, one GPU" % (G, S, S, levels, level.name)
+        else:
+            workload = ("C3%s: %d frames of %dx%d u8 ramp(3) sharded over %d GPUs (%d per GPU), level=%d %s, Crossed, encode then decode, "
+                        "HBM-resident" % (" shard" if scaling == "weak" else "", G, S, S, world, F, levels, level.name))
         line = {
             "metric": "Mpixels/s encode+decode, 4K grayscale level=4 Medium", "value": round(value, 1),
             "unit": "Mpixels/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": scaling,
             "vs_baseline": None, "dtype": "u8", "data": "synthetic",
-            "config": {"workload": "C3 shard: %d frames/GPU of %dx%d u8 ramp(3), level=%d %s, Crossed, "
-                                   "encode then decode, HBM-resident" % (F, S, S, levels, level.name),
-                       "frames_per_gpu": F, "global_frames": world * F, "parallelism": "frames sharded x%d" % world,
+            "config": {"workload": workload,
+                       "frames_per_gpu": F, "global_frames": G, "parallelism": "frames sharded x%d" % world,
                        "collectives": "none" if dist is None else "%s: broadcast(258 B) + all_reduce(max) + all_gather(24 B)" % dist.get_backend(),
                        "encode_ms": round(enc_ms, 4), "decode_ms": round(dec_ms, 4),
                        "max_abs_err": int(allst[:, 1].max()), "sq_err_sum": int(allst[:, 0].sum()),
                        "grid_checksums": [int(v) for v in allst[:, 2]]},
             "roofline": {"bound": "hbm", "kernel": kernel,
                          "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_from": traffic_from,
                          "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": round(dom_ms, 4),
                          "other_kernel": {"kernel": "k_%s_tiles" % ("dec" if dom == "encode" else "enc"),
                                           "achieved": round(alg_bytes / (min(enc_ms, dec_ms) * 1e-3) / 1e9, 1),
@@ -323,6 +394,7 @@ def run_rank(args):
                                            "avg_launch_ms": round(copy_ms, 4),
                                            "note": "16-B/lane copy kernel moving the same bytes"}},
         }
+        line["build"] = stamp
         line["config"]["placement"] = placement
         line["config"]["per_rank"] = per_rank
         line["config"]["per_step_ms"] = codec.per_step_ms()
@@ -348,14 +420,14 @@ def run_rank(args):
 
 
 def per_rank_record(batch, dist, values, device=None):
-    """All-gather of [plane-placement seconds, planes separated (0/1), encode ms, decode ms, settle steps] -> the
+    """All-gather of [plane-placement seconds, planes separated (0/1), encode ms, decode ms, settle steps, frames] -> the
     `per_rank` block of the line: every rank's numbers in rank order plus min / max of the two launch times."""
     import torch
     t = torch.tensor([float(v) for v in values], dtype=torch.float64, device=device or "cpu")
     rows = batch.gather_stats(dist, t)
     return {"planes_alloc_s": [round(float(r[0]), 4) for r in rows], "planes_separated": [bool(r[1] > 0.5) for r in rows],
             "encode_ms": [round(float(r[2]), 4) for r in rows], "decode_ms": [round(float(r[3]), 4) for r in rows],
-            "settle_steps": [int(r[4]) for r in rows],
+            "settle_steps": [int(r[4]) for r in rows], "frames": [int(r[5]) for r in rows],
             "encode_ms_min_max": [round(float(rows[:, 2].min()), 4), round(float(rows[:, 2].max()), 4)],
             "decode_ms_min_max": [round(float(rows[:, 3].min()), 4), round(float(rows[:, 3].max()), 4)]}
 
@@ -363,7 +435,7 @@ def per_rank_record(batch, dist, values, device=None):
 class Codec:
     """This rank's frames, contexts and timed steps on its GPU."""
 
-    def __init__(self, args, dev, local, lut, err, levels, first):
+    def __init__(self, args, dev, local, lut, err, levels, first, frames):
         import torch
         import rustyhgi_amd as H
         from rustyhgi_amd import _ffi
@@ -376,8 +448,8 @@ class Codec:
         torch.cuda.set_stream(self.stream)
         self.ctx = ctx = H.Context(local)
         ctx.set_stream(self.stream.cuda_stream)
-        F, S = args.frames, args.size
-        self.F, self.S = F, S
+        F, S = int(frames), args.size
+        self.F, self.S, self.first = F, S, first
         ctx.reserve(S, S, levels, F)
         # The three frame stacks.  Default: planes placed by the library (hgi_planes_alloc) so that each launch reads
         # one HBM region and writes another (+4-5 % on MI355X over planes that share a region, which is
@@ -637,24 +709,30 @@ class Codec:
         self._restore()
         return res
 
-    def xgmi(self, dist, world, rank, fence, steps):
-        """optional, separately labelled: every frame starts and ends on GPU 0.  Bound by the
-        source GPU's xGMI links, not by the codec; never part of `value`."""
+    def xgmi(self, dist, world, rank, fence, steps, fx):
+        """optional, separately labelled: every frame starts and ends on GPU 0 -- `fx` frames per rank, scattered
+        from rank 0, coded where they land, the decoded frames gathered back.  Bound by the source GPU's xGMI links, not by
+        the codec; never part of `value`.  Under --share-gpu (gloo, one device) the frames go through host memory: plumbing
+        only, no bandwidth claim.  The line carries the SHA-256 of every rank's first gathered frame, which the GPU test
+        compares with the oracle's decode(encode()) of that global frame."""
+        import hashlib
         torch, _ffi = self.torch, self._ffi
         from rustyhgi_amd import batch
-        F, S, dev = self.F, self.S, self.dev
-        allf = torch.empty((world * F, S, S), dtype=torch.uint8, device=dev) if rank == 0 else None
+        S, dev = self.S, self.dev
+        fx = int(min(fx, self.F))
+        allf = torch.empty((world * fx, S, S), dtype=torch.uint8, device=dev) if rank == 0 else None
         allo = torch.empty_like(allf) if rank == 0 else None
         if rank == 0:
             _ffi.check(_ffi.lib().hgi_synth_u8_dev(self.ctx.handle, _ffi.SYNTH_RAMP, SEED0 + 3, 0, S, S,
-                                                   allf.data_ptr(), world * F, S * S))
-        mine_in = torch.empty_like(self.imgs)
+                                                   allf.data_ptr(), world * fx, S * S))
+        mine_in = torch.empty((fx, S, S), dtype=torch.uint8, device=dev)
+        grids, outs = self.grids[:fx], self.outs[:fx]
 
         def xstep():
             batch.scatter_frames(dist, allf, mine_in)
-            self.enc.encode_batch(mine_in, out=self.grids)
-            self.dec.decode_batch(self.grids, self.levels, out=self.outs)
-            batch.gather_frames(dist, self.outs, allo)
+            self.enc.encode_batch(mine_in, out=grids)
+            self.dec.decode_batch(grids, self.levels, out=outs)
+            batch.gather_frames(dist, outs, allo)
 
         xstep()
         fence()
@@ -663,15 +741,17 @@ class Codec:
         for _ in range(nx):
             xstep()
         fence()
-        xs = batch.max_over_ranks(dist, time.perf_counter() - t1, dev) / nx
+        xs = batch.max_over_ranks(dist, time.perf_counter() - t1, torch.device("cpu") if self.args.share_gpu else dev) / nx
         res = None
         if rank == 0:
-            same = bool(torch.equal(allo[:F], self.outs)) and \
-                int((allf[:F].to(torch.int16) - allo[:F].to(torch.int16)).abs().max()) <= self.err
-            res = {"ms_per_step": round(xs * 1e3, 4), "value": round(world * F * S * S / xs / 1e6, 1), "unit": "Mpixels/s",
-                   "bytes_over_links_per_step": 2 * (world - 1) * F * S * S, "roundtrip_ok": same,
-                   "note": "frames scattered from and gathered to GPU 0 (torch.distributed scatter/gather over RCCL); "
-                           "per-link bound, reported beside the sharded number, never as it"}
+            same = bool(torch.equal(allo[:fx], outs)) and \
+                int((allf.to(torch.int16) - allo.to(torch.int16)).abs().max()) <= self.err
+            res = {"ms_per_step": round(xs * 1e3, 4), "value": round(world * fx * S * S / xs / 1e6, 1), "unit": "Mpixels/s",
+                   "frames_per_rank": fx, "bytes_over_links_per_step": 2 * (world - 1) * fx * S * S, "roundtrip_ok": same,
+                   "first_gathered_frame_sha256_by_rank": [hashlib.sha256(allo[r * fx].cpu().numpy().tobytes()).hexdigest()[:16] for r in range(world)],
+                   "transport": ("gloo through host memory, all ranks on one device: PLUMBING ONLY, not a bandwidth figure" if self.args.share_gpu
+                                 else "torch.distributed scatter / gather over RCCL (xGMI)"),
+                   "note": "frames scattered from and gathered to GPU 0; per-link bound, reported beside the sharded number, never as it"}
         del allf, allo, mine_in
         self._restore()
         return res
@@ -714,7 +794,8 @@ class Codec:
         import struct
         import time
         import zlib
-        torch, _ffi, F, S = self.torch, self._ffi, self.F, self.S
+        torch, _ffi, S = self.torch, self._ffi, self.S
+        F = min(self.F, 64)      # an extra beside the headline: the first 64 grids of the shard bound its time and its pinned buffer
         try:
             cap = S * S // 2 + 4096
             out = torch.empty((F, cap), dtype=torch.uint8, pin_memory=True)

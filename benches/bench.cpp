@@ -8,13 +8,26 @@
 // `serialization` (benches/bench.rs:112-127) and `compression` (:129-151) use the .hgi archive writer of
 // include/hgi_archive.hpp (the CLI's): they are host-side DEFLATE at the best level and dominate the codec by orders of
 // magnitude, exactly as in the reference; reported in the reference's unit (time per iteration).
-//   build: hipcc -O2 -std=c++17 -Iinclude benches/bench.cpp -Lrustyhgi_amd -lhgi_hip -lz -Wl,-rpath,$PWD/rustyhgi_amd -o bench_cpp
+//   build: hipcc -O2 -std=c++17 -Iinclude benches/bench.cpp -Lrustyhgi_amd -lhgi_hip -lz -lpthread -Wl,-rpath,$PWD/rustyhgi_amd -o bench_cpp
+//
+// bench_cpp --devices N [--frames F | --global-frames G] [--steps K] [--warmup W] [--same-device]
+//   ONE PROCESS, N DEVICES, through the C ABI alone (no torch, no torch.distributed): the multi-GPU form of BASELINE
+//   configs[3] for a caller that is not Python -- a Rust program driving `Encoder::encode` per frame (src/encoder.rs:39) has no
+//   torchrun.  One host thread and one hgi_ctx per device; the 512-frame batch is sharded by frame (512 // N per device,
+//   strong scaling; --frames F: F per device); every device generates its own frames in place (hgi_synth_u8_dev), places its
+//   three planes (hgi_planes_alloc), and codes its shard; the threads meet at a barrier before and after the K timed steps.
+//   --same-device puts all N contexts on device 0 (a one-GPU box: exercises N concurrent contexts, says nothing about scaling).
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
 #include <chrono>
+#include <condition_variable>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
+#include <mutex>
+#include <string>
+#include <thread>
 #include <vector>
 
 #include "hgi.hpp"
@@ -78,8 +91,220 @@ static void bench_encode(const char *name, Q quantizator, const GrayImage &image
     report(name, "device", sec / reps, size);
 }
 
-int main()
+// ---- one process, N devices ---------------------------------------------------------------------------------------------
+namespace multi {
+
+struct Barrier {      // (std::barrier is C++20)
+    std::mutex m;
+    std::condition_variable cv;
+    int n, waiting = 0, phase = 0;
+    explicit Barrier(int n_) : n(n_) {}
+    void wait()
+    {
+        std::unique_lock<std::mutex> lock(m);
+        const int my = phase;
+        if (++waiting == n) {
+            waiting = 0;
+            ++phase;
+            cv.notify_all();
+        } else {
+            cv.wait(lock, [&] { return phase != my; });
+        }
+    }
+};
+
+struct Shard {
+    int device = 0;
+    size_t first = 0, frames = 0;
+    // results
+    std::string error;
+    double alloc_s = 0, wall_s = 0, encode_ms = 0, decode_ms = 0;
+    int separated = 0, settle_steps = 0;
+    unsigned long long max_err = 0, sq_err = 0, checksum = 0;
+};
+
+#define MT(expr)                                                             \
+    do {                                                                     \
+        if ((expr) != HGI_OK) {                                              \
+            sh.error = std::string(#expr) + ": " + hgi_last_error();         \
+            failed = true;                                                   \
+        }                                                                    \
+    } while (0)
+
+static void worker(Shard &sh, uint32_t S, uint32_t levels, int steps, int warmup, Barrier &bar)
 {
+    bool failed = false;
+    hgi_ctx *ctx = nullptr;
+    void *planes[3] = {nullptr, nullptr, nullptr};
+    uint8_t lut[256], err = 0;
+    const size_t n = size_t(S) * S;
+    unsigned long long *d_stats = nullptr;
+    MT(hgi_ctx_create(sh.device, &ctx));
+    if (!failed) {
+        MT(hgi_linear_lut(HGI_QUANT_MEDIUM, lut, &err));
+        MT(hgi_ctx_reserve(ctx, S, S, levels, sh.frames));
+        auto t0 = clk::now();
+        MT(hgi_planes_alloc(ctx, sh.frames * n, 3, planes, &sh.separated));
+        sh.alloc_s = std::chrono::duration<double>(clk::now() - t0).count();
+    }
+    if (!failed) MT(hgi_synth_u8_dev(ctx, HGI_SYNTH_RAMP, 0x48474930u + 3, sh.first, S, S, planes[0], sh.frames, n));
+    auto step = [&] {
+        MT(hgi_encode_u8_dev(ctx, planes[0], S, S, levels, HGI_INTERP_CROSSED, lut, planes[1], sh.frames, n));
+        MT(hgi_decode_u8_dev(ctx, planes[1], S, S, levels, HGI_INTERP_CROSSED, planes[2], sh.frames, n));
+    };
+    if (!failed) {
+        // settle: the device's clocks ramp for ~25 ms after idle: untimed groups of steps until two groups agree
+        double last = 0;
+        for (int g = 0; g < 20 && !failed; ++g) {
+            float ms = 0;
+            MT(hgi_timer_start(ctx));
+            for (int i = 0; i < 8; ++i) step();
+            MT(hgi_timer_stop(ctx, &ms));
+            sh.settle_steps += 8;
+            if (g >= 2 && std::abs(ms - last) <= 0.004 * last) break;
+            last = ms;
+        }
+        for (int i = 0; i < warmup; ++i) step();
+        MT(hgi_sync(ctx));
+    }
+    bar.wait();      // ---- timed region: K steps on every device, bracketed by barriers + synchronisation ----
+    auto t0 = clk::now();
+    if (!failed) {
+        for (int i = 0; i < steps; ++i) step();
+        MT(hgi_sync(ctx));
+    }
+    bar.wait();
+    sh.wall_s = std::chrono::duration<double>(clk::now() - t0).count();
+    if (!failed) {
+        // per-launch times by events on the ctx stream, in the step's own pattern (a synchronisation per launch: not part of `value`)
+        const int reps = std::max(4, std::min(steps, 20));
+        for (int i = 0; i < reps && !failed; ++i) {
+            float ms = 0;
+            MT(hgi_timer_start(ctx));
+            MT(hgi_encode_u8_dev(ctx, planes[0], S, S, levels, HGI_INTERP_CROSSED, lut, planes[1], sh.frames, n));
+            MT(hgi_timer_stop(ctx, &ms));
+            sh.encode_ms += ms / reps;
+            MT(hgi_timer_start(ctx));
+            MT(hgi_decode_u8_dev(ctx, planes[1], S, S, levels, HGI_INTERP_CROSSED, planes[2], sh.frames, n));
+            MT(hgi_timer_stop(ctx, &ms));
+            sh.decode_ms += ms / reps;
+        }
+        // what `hgi test` prints per frame (src/main.rs:84-92), folded over the shard, + a checksum of the grids
+        if (hipSetDevice(sh.device) == hipSuccess && hipMalloc(reinterpret_cast<void **>(&d_stats), 3 * 8 * sh.frames) == hipSuccess) {
+            MT(hgi_diff_stats_dev(ctx, planes[0], planes[2], S, S, sh.frames, n, d_stats));
+            MT(hgi_sync(ctx));
+            std::vector<unsigned long long> st(3 * sh.frames);
+            (void)hipMemcpy(st.data(), d_stats, st.size() * 8, hipMemcpyDeviceToHost);
+            for (size_t f = 0; f < sh.frames; ++f) {
+                sh.sq_err += st[3 * f];
+                sh.max_err = std::max(sh.max_err, st[3 * f + 1]);
+            }
+            (void)hipFree(d_stats);
+            std::vector<uint8_t> row(S);
+            for (size_t f = 0; f < sh.frames; f += std::max<size_t>(1, sh.frames / 8)) {
+                (void)hipMemcpy(row.data(), static_cast<uint8_t *>(planes[1]) + f * n + size_t(S / 2) * S, S, hipMemcpyDeviceToHost);
+                for (uint8_t v : row) sh.checksum = sh.checksum * 1315423911ull + v;
+            }
+        }
+    }
+    if (ctx) {
+        (void)hgi_planes_free(ctx, 3, planes);
+        hgi_ctx_destroy(ctx);
+    }
+}
+#undef MT
+
+static int run(int argc, char **argv)
+{
+    int devices = 1, steps = 20, warmup = 3;
+    long frames = -1, global_frames = 512;
+    bool same = false;
+    for (int i = 1; i < argc; ++i) {
+        const std::string a = argv[i];
+        auto val = [&](long dflt) { return i + 1 < argc ? atol(argv[++i]) : dflt; };
+        if (a == "--devices") devices = (int)val(1);
+        else if (a == "--frames") frames = val(-1);
+        else if (a == "--global-frames") global_frames = val(512);
+        else if (a == "--steps") steps = (int)val(20);
+        else if (a == "--warmup") warmup = (int)val(3);
+        else if (a == "--same-device") same = true;
+        else {
+            std::fprintf(stderr, "bench_cpp: unknown argument %s\n", a.c_str());
+            return 2;
+        }
+    }
+    int have = 0;
+    if (hipGetDeviceCount(&have) != hipSuccess || have < 1) {
+        std::fprintf(stderr, "bench_cpp: no HIP device (this harness has no CPU path)\n");
+        return 2;
+    }
+    if (devices < 1 || (!same && devices > have)) {
+        std::fprintf(stderr, "bench_cpp: --devices %d but the process sees %d (use --same-device to put every context on device 0)\n", devices, have);
+        return 2;
+    }
+    const uint32_t S = 4096, levels = 4;
+    const size_t G = frames > 0 ? size_t(frames) * devices : size_t(global_frames);
+    std::vector<Shard> shards((size_t)devices);
+    for (int d = 0; d < devices; ++d) {      // contiguous blocks that differ by at most one frame (rustyhgi_amd/batch.py: shard())
+        const size_t base = G / devices, extra = G % devices;
+        shards[d].device = same ? 0 : d;
+        shards[d].first = d * base + std::min<size_t>(d, extra);
+        shards[d].frames = base + (size_t(d) < extra ? 1 : 0);
+        if (shards[d].frames == 0) {
+            std::fprintf(stderr, "bench_cpp: %zu frames cannot be sharded over %d devices\n", G, devices);
+            return 2;
+        }
+    }
+    Barrier bar(devices);
+    std::vector<std::thread> pool;
+    for (int d = 0; d < devices; ++d) pool.emplace_back(worker, std::ref(shards[d]), S, levels, steps, warmup, std::ref(bar));
+    for (auto &t : pool) t.join();
+    double wall = 0;
+    bool ok = true;
+    for (auto &sh : shards) {
+        wall = std::max(wall, sh.wall_s);
+        if (!sh.error.empty()) {
+            std::fprintf(stderr, "bench_cpp: device %d: %s\n", sh.device, sh.error.c_str());
+            ok = false;
+        }
+        if (sh.max_err > 20) {
+            std::fprintf(stderr, "bench_cpp: device %d: reconstruction error %llu exceeds the Medium bound 20\n", sh.device, sh.max_err);
+            ok = false;
+        }
+    }
+    if (!ok) return 1;
+    const double px = double(G) * S * S * steps, value = px / wall / 1e6;
+    std::printf("bench_cpp --devices %d%s: %zu frames of %ux%u u8 ramp(3), level %u Medium, Crossed; %d steps, %d warm-up; one host thread + one hgi_ctx per device\n",
+                devices, same ? " --same-device" : "", G, S, S, levels, steps, warmup);
+    for (auto &sh : shards)
+        std::printf("  device %d: frames %4zu (from %4zu)  planes %.3f s %s  settle %3d steps  encode %.4f ms  decode %.4f ms  (%.4f of 8 TB/s on the slower)  max err %llu  checksum %016llx\n",
+                    sh.device, sh.frames, sh.first, sh.alloc_s, sh.separated ? "separated" : "NOT separated", sh.settle_steps, sh.encode_ms, sh.decode_ms,
+                    2.0 * sh.frames * S * S / (std::max(sh.encode_ms, sh.decode_ms) * 1e-3) / 8e12, sh.max_err, sh.checksum);
+    std::printf("  aggregate: %.1f Mpixels/s encode+decode (%.4f ms per step, max over the device threads)\n", value, wall / steps * 1e3);
+    // one machine-readable line (the GPU test and profiles/r04_bench_cpp.txt read it)
+    std::printf("{\"harness\": \"bench_cpp --devices\", \"devices\": %d, \"same_device\": %s, \"global_frames\": %zu, \"steps\": %d, \"value\": %.1f, "
+                "\"unit\": \"Mpixels/s\", \"ms_per_step\": %.4f, \"frames\": [",
+                devices, same ? "true" : "false", G, steps, value, wall / steps * 1e3);
+    for (size_t d = 0; d < shards.size(); ++d) std::printf("%s%zu", d ? ", " : "", shards[d].frames);
+    std::printf("], \"encode_ms\": [");
+    for (size_t d = 0; d < shards.size(); ++d) std::printf("%s%.4f", d ? ", " : "", shards[d].encode_ms);
+    std::printf("], \"decode_ms\": [");
+    for (size_t d = 0; d < shards.size(); ++d) std::printf("%s%.4f", d ? ", " : "", shards[d].decode_ms);
+    std::printf("], \"separated\": [");
+    for (size_t d = 0; d < shards.size(); ++d) std::printf("%s%s", d ? ", " : "", shards[d].separated ? "true" : "false");
+    std::printf("], \"sq_err_sum\": [");
+    for (size_t d = 0; d < shards.size(); ++d) std::printf("%s%llu", d ? ", " : "", shards[d].sq_err);
+    std::printf("], \"max_abs_err\": [");
+    for (size_t d = 0; d < shards.size(); ++d) std::printf("%s%llu", d ? ", " : "", shards[d].max_err);
+    std::printf("]}\n");
+    return 0;
+}
+
+}  // namespace multi
+
+int main(int argc, char **argv)
+{
+    if (argc > 1) return multi::run(argc, argv);
     const uint32_t width = 1920, height = 1080;
     const size_t size = size_t(width) * height, levels = 4;
     GrayImage image = get_test_image(width, height);

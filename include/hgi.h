@@ -88,8 +88,14 @@ HGI_API hgi_status hgi_ctx_set_path(hgi_ctx *ctx, hgi_path path);
 /* pointing at the block it was captured with, so reserve for the largest shape the ctx    */
 /* will ever see BEFORE capturing, and do not let a later, larger call on the same ctx     */
 /* grow it while such graphs are alive.                                                    */
+/* Covers hgi_encode_u8_dev / hgi_decode_u8_dev on `batch` frames of this shape AND the       */
+/* host-pointer calls hgi_encode_u8 / hgi_decode_u8 on one such frame (their staging, the      */
+/* seed planes of a banded deep pyramid); the host-pointer BATCH calls size their own slots.   */
 HGI_API hgi_status hgi_ctx_reserve(hgi_ctx *ctx, uint32_t width, uint32_t height, uint32_t levels,
                            size_t batch);
+/* Bytes of device scratch the ctx owns right now (0 after hgi_ctx_create): memory accounting,  */
+/* and the way to see that a reserved ctx does not re-allocate.                                */
+HGI_API hgi_status hgi_ctx_scratch_bytes(hgi_ctx *ctx, size_t *bytes);
 HGI_API hgi_status hgi_sync(hgi_ctx *ctx);
 HGI_API const char *hgi_last_error(void);
 HGI_API const char *hgi_version(void);
@@ -179,7 +185,8 @@ HGI_API hgi_status hgi_deflate_grids_dev(hgi_ctx *ctx, const void *d_grids, uint
 /* out[offsets[f] .. offsets[f] + sizes[f]), offsets ascending and multiples of 64.  The sizes are */
 /* known from the histograms before anything is packed, so a group's streams lie back to back on  */
 /* the device and come down with ONE copy per group instead of one per frame (each copy costs a   */
-/* fixed ~12 us on top of its bytes).  HGI_EINVAL when `cap` does not hold them all                */
+/* fixed ~12 us on top of its bytes).  The gap between a stream's end and the next stream's start  */
+/* (at most 63 bytes) is zero.  HGI_EINVAL when `cap` does not hold them all                       */
 /* (batch * (w*h + w*h/8 + 1088) always suffices).                                                  */
 HGI_API hgi_status hgi_deflate_grids_packed_dev(hgi_ctx *ctx, const void *d_grids, uint32_t width, uint32_t height, size_t batch,
                                                 size_t frame_stride, uint8_t *out, size_t cap, size_t *offsets, size_t *sizes);
@@ -194,20 +201,27 @@ HGI_API hgi_status hgi_huffman_plan(const uint64_t hist[286], uint8_t lens[286],
                             uint8_t *header, size_t header_cap, size_t *header_bits);
 
 /* ---- plane placement (no reference counterpart: the reference's buffers are Vec<u8>) ---- */
-/* MI355X serves its HBM in large physical regions; a launch that streams one buffer in and   */
-/* another out runs 4-5 % faster when the two lie in different regions.       */
-/* hgi_planes_alloc returns `count` device buffers of `bytes` each (hipMalloc; release with   */
-/* hgi_planes_free or hipFree) such that planes[i] and planes[i+1] lie in different regions:  */
-/* image -> grid -> image chains alternate through the array.  Best effort, found by timing   */
-/* a decode launch between candidate buffers against a same-region yardstick (typically       */
-/* 30-50 ms in all; when the device's free memory is one huge block, transient allocations of */
-/* up to ~60x `bytes` and several seconds -- set HGI_NO_PLACEMENT=1 to skip the search):      */
-/* *separated (optional) is 1 when every neighbouring pair was seen to be in different        */
-/* regions, 0 when that could not be established -- the planes are valid either way.  Planes   */
-/* below 128 MiB are not probed (such streams live in the 256 MiB Infinity Cache); planes of   */
-/* 128 MiB ... 1 GiB are allocated at 1 GiB each so that they can be (a launch over two of     */
-/* them no longer fits that cache: a lone 16384 x 16384 frame gains 2-3 %).  Call it while the  */
-/* device is otherwise idle: it measures.                                                      */
+/* MI355X's HBM falls into a few classes of physical memory; a launch that streams one buffer */
+/* in and another out runs 4-8 % faster when the two lie in different classes. */
+/* hgi_planes_alloc returns `count` device buffers of at least `bytes` each such that          */
+/* planes[i] and planes[i+1] lie in different classes over their whole length: image -> grid   */
+/* -> image chains alternate through the array.  RELEASE THEM WITH hgi_planes_free ONLY.       */
+/* Best effort, found by timing a decode launch between candidates against a same-class        */
+/* yardstick; *separated (optional) is 1 when every neighbouring pair was seen to stream at    */
+/* the fast rate, 0 when that could not be established -- the planes are valid either way.     */
+/*  - planes below 128 MiB: plain hipMalloc, not probed (such streams live in the 256 MiB      */
+/*    Infinity Cache);                                                                         */
+/*  - 128 MiB up to 1 GiB: allocated at 1 GiB each so that the probe can tell (a launch over   */
+/*    two of them no longer fits that cache: a lone 16384 x 16384 frame gains 2-3 %); if the   */
+/*    device lacks the memory for that they come back at `bytes`, unplaced;                    */
+/*  - exactly 1 GiB: whole hipMalloc allocations are the candidates (typically 30-50 ms; up   */
+/*    to ten extra candidates and spacers when the first ones share a class);                  */
+/*  - above 1 GiB: each plane is one reserved address range onto which physical chunks of      */
+/*    1 GiB (hipMemCreate) are mapped, chosen chunk by chunk (size rounded up to whole GiB).   */
+/*    Bounded: at most 3 x the requested bytes are ever created; what is not handed out is     */
+/*    released before the call returns (three planes of 8 GiB: about a second).                */
+/* HGI_NO_PLACEMENT=1 in the environment skips all of it (plain allocations): the one variable */
+/* the library reads.  Call it while the device is otherwise idle: it measures.                */
 HGI_API hgi_status hgi_planes_alloc(hgi_ctx *ctx, size_t bytes, uint32_t count, void **planes, int *separated);
 HGI_API hgi_status hgi_planes_free(hgi_ctx *ctx, uint32_t count, void **planes);
 /* The probe itself: mean milliseconds of one decode launch streaming d_src -> d_dst over      */

@@ -24,6 +24,7 @@ SYMBOLS = [
     ("hgi_ctx_use_own_stream", _int, [_vp]),
     ("hgi_ctx_set_path", _int, [_vp, _int]),
     ("hgi_ctx_reserve", _int, [_vp, _u32, _u32, _u32, _sz]),
+    ("hgi_ctx_scratch_bytes", _int, [_vp, ctypes.POINTER(_sz)]),
     ("hgi_histogram_u8_dev", _int, [_vp, _vp, _u32, _u32, _sz, _sz, _vp]),
     ("hgi_encode_u8_batch", _int, [_vp, _vp, _u32, _u32, _u32, _int, _vp, _vp, _sz, _sz]),
     ("hgi_decode_u8_batch", _int, [_vp, _vp, _u32, _u32, _u32, _int, _vp, _sz, _sz]),
@@ -131,6 +132,12 @@ class Context:
 
     def reserve(self, w, h, levels, batch=1):
         check(lib().hgi_ctx_reserve(self.handle, w, h, levels, batch))
+
+    def scratch_bytes(self):
+        """Bytes of device scratch the context owns right now (hgi_ctx_scratch_bytes)."""
+        n = ctypes.c_size_t(0)
+        check(lib().hgi_ctx_scratch_bytes(self.handle, ctypes.byref(n)))
+        return n.value
 
     def sync(self):
         check(lib().hgi_sync(self.handle))

@@ -64,29 +64,51 @@ def max_over_ranks(dist, value, device):
     return float(t.item())
 
 
+def _through_host(dist, tensor):
+    """gloo moves host memory only (its CUDA support stops at broadcast and all-reduce): with that backend -- the CPU tests,
+    bench.py --share-gpu -- device frames are staged through host memory.  RCCL takes the device tensors as they are."""
+    return dist.get_backend() == "gloo" and tensor.is_cuda
+
+
 def scatter_frames(dist, all_frames, mine, src=0):
     """Rank `src` holds `all_frames` (world * F frames, rank-major); every rank receives its F frames in `mine`.
     Point-to-point under the hood (one xGMI link per peer), so the source GPU's links bound it."""
+    import torch
     if dist is None:
         mine.copy_(all_frames)
         return
     world, rank = dist.get_world_size(), dist.get_rank()
+    host = _through_host(dist, mine)
     chunks = None
     if rank == src:
         assert all_frames.shape[0] == world * mine.shape[0], "all_frames must hold world * F frames"
-        chunks = [c.contiguous() for c in all_frames.chunk(world)]
-    dist.scatter(mine, chunks, src=src)
+        chunks = [(c.cpu() if host else c).contiguous() for c in all_frames.chunk(world)]
+    if host:
+        buf = torch.empty(mine.shape, dtype=mine.dtype)
+        dist.scatter(buf, chunks, src=src)
+        mine.copy_(buf)
+    else:
+        dist.scatter(mine, chunks, src=src)
 
 
 def gather_frames(dist, mine, all_frames, dst=0):
     """Inverse of scatter_frames: rank `dst` ends up with every rank's frames, rank-major."""
+    import torch
     if dist is None:
         all_frames.copy_(mine)
         return
     world, rank = dist.get_world_size(), dist.get_rank()
+    host = _through_host(dist, mine)
+    send = mine.cpu() if host else mine
     if rank == dst:
-        parts = [c for c in all_frames.chunk(world)]
-        assert all(p.is_contiguous() for p in parts)
-        dist.gather(mine, parts, dst=dst)
+        if host:
+            parts = [torch.empty(mine.shape, dtype=mine.dtype) for _ in range(world)]
+            dist.gather(send, parts, dst=dst)
+            for p, c in zip(parts, all_frames.chunk(world)):
+                c.copy_(p)
+        else:
+            parts = [c for c in all_frames.chunk(world)]
+            assert all(p.is_contiguous() for p in parts)
+            dist.gather(send, parts, dst=dst)
     else:
-        dist.gather(mine, None, dst=dst)
+        dist.gather(send, None, dst=dst)

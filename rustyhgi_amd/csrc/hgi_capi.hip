@@ -1,5 +1,6 @@
-// C ABI of libhgi_hip.so (include/hgi.h): argument checking, scratch management, level scheduling.
-// No CPU implementation lives here: every encode/decode goes to the gfx950 kernels or fails.
+// C ABI of libhgi_hip.so (include/hgi.h), part 1: contexts, argument checking, scratch management, level scheduling, the
+// device / host / host-batch / banded entry points of the codec, harness helpers.  (Entropy stage: hgi_entropy_host.hip;
+// plane placement: hgi_planes.hip.)  No CPU implementation lives here: every encode/decode goes to the gfx950 kernels or fails.
 #include <hip/hip_runtime.h>
 #include <stdarg.h>
 #include <stdio.h>
@@ -9,14 +10,17 @@
 #include <thread>
 #include <vector>
 
-#include "../../include/hgi.h"
-#include "hgi_kernels.h"
+#include "hgi_host.h"
 
 using namespace hgi;
+using namespace hgi::host;
 
 namespace {
-
 thread_local char g_err[512] = "";
+}
+
+namespace hgi {
+namespace host {
 
 hgi_status fail(hgi_status st, const char *fmt, ...)
 {
@@ -27,60 +31,24 @@ hgi_status fail(hgi_status st, const char *fmt, ...)
     return st;
 }
 
-#define HIP_TRY(expr)                                                                       \
-    do {                                                                                    \
-        hipError_t e_ = (expr);                                                             \
-        if (e_ != hipSuccess)                                                               \
-            return fail(e_ == hipErrorOutOfMemory ? HGI_ENOMEM : HGI_EDEVICE, "%s: %s", #expr, \
-                        hipGetErrorString(e_));                                             \
-    } while (0)
+}  // namespace host
+}  // namespace hgi
 
-#define HGI_TRY(expr)                  \
-    do {                               \
-        hgi_status s_ = (expr);        \
-        if (s_ != HGI_OK) return s_;   \
-    } while (0)
+namespace {
 
-inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
-
-#ifndef HGI_ENTROPY_GROUP_MIB_DEFAULT
-#define HGI_ENTROPY_GROUP_MIB_DEFAULT 256
+// Compile-time constants of the release library (hgi_knobs.h: the knobs build reads the same names from the environment)
+#ifndef HGI_TILE16_MAX
+#define HGI_TILE16_MAX 600    // an ENCODE of at most this many 32-row tiles runs on 16-row tiles instead (profiles/r03_sizes.txt: 1920 x 1080 is 510)
 #endif
-// The shallowest pyramid that runs as four fused levels + cone (split_pyramid()).  Six: a lone frame then keeps the small tiles and
-// the short chain of a four-level launch (1920 x 1080 level 6: 10.6 / 6.5 -> 7.3 / 5.6 us), a batch is unchanged (64 x 4096^2:
-// +0.4 / -0.8 %); at five levels nothing is gained in either (profiles/r03_cone_levels.txt).
-#ifndef HGI_CONE_MIN_ENC_DEFAULT
-#define HGI_CONE_MIN_ENC_DEFAULT 6
-#endif
-#ifndef HGI_CONE_MIN_DEC_DEFAULT
-#define HGI_CONE_MIN_DEC_DEFAULT 6
-#endif
-#ifndef HGI_TILE16_MAX_DEFAULT
-#define HGI_TILE16_MAX_DEFAULT 600    // an ENCODE of at most this many 32-row tiles runs on 16-row tiles instead (profiles/r03_sizes.txt: 1920 x 1080 is 510)
-#endif
+// The shallowest pyramid that runs as four fused levels + cone (split_pyramid()).  Six: a lone frame then keeps the small tiles
+// and the short chain of a four-level launch (1920 x 1080 level 6: 10.6 / 6.5 -> 7.3 / 5.6 us), a batch is unchanged
+// (64 x 4096^2: +0.4 / -0.8 %); at five levels nothing is gained in either (profiles/r03_cone_levels.txt).
+constexpr uint32_t kConeMinLevels = 6;
 
 }  // namespace
 
-struct hgi_ctx {
-    int device;
-    hipStream_t own_stream, stream;
-    hgi_path path;
-    uint8_t *ws;
-    size_t ws_bytes, ws_used;
-    hipEvent_t ev0, ev1;      // hgi_timer_start / hgi_timer_stop, nothing else
-    hipEvent_t ev_hist[2];    // entropy stage: "histograms of group set k are down"
-    hipEvent_t ev_probe[2];   // placement probe
-    // host-pointer batch calls (created on first use): pipe[0] uploads, pipe[1] runs the kernels and downloads;
-    // three device slots, per slot one event "uploaded" and one "kernels done, input slot free"
-    hipStream_t pipe[2];
-    hipEvent_t ev_up[3], ev_free[3];
-    hipEvent_t ev_band[16];   // banded single-frame calls: "band uploaded"
-    bool have_pipe;
-    uint8_t *pin;             // pinned host memory (entropy stage: histograms and stream sizes come down without stalling the host)
-    size_t pin_bytes;
-};
-
-namespace {
+namespace hgi {
+namespace host {
 
 // Scratch is a bump allocator over one device buffer; it only grows between calls.
 hgi_status ws_ensure(hgi_ctx *c, size_t bytes)
@@ -118,34 +86,23 @@ SubGeom sub_geom(uint32_t w, uint32_t h, uint32_t k)
     return g;
 }
 
-// How a pyramid is split between the tile kernel and what has to be coded in front of it.
-//   levels <= 5 (HGI_CONE_MIN_* - 1): the tile holds the pyramid: k = levels, nothing else.
-//   6 ... 8: ONE launch at four fused levels that rebuilds the 2 ... 4 levels above a tile for itself (hgi_fused_impl.h,
-//            cone_*): k = 4, up = levels - 4.  No lattice planes, no scratch, no launch in front.
-//   deeper:  k = 4, up = 4, and the stride-256 lattice -- an HGI image with levels - 8 levels of its own (same OOB rule:
-//            x < W <=> x >> 8 < ceil(W / 256)) -- is coded first; its planes are the cone's base.
-//   HGI_CONE=0 in the environment (tests, experiments): no cone; the tile kernel takes six levels (or HGI_DEEP_K_ENC /
-//            HGI_DEEP_K_DEC = 4 | 5) and the stride-2^k lattice is coded first.  Every split gives the same bytes.
+// How a pyramid is split between the tile kernel and what has to be coded in front of it (DESIGN.md 4.4).
+//   levels <= 5: the tile holds the pyramid: k = levels, nothing else.
+//   6 ... 8:     ONE launch at four fused levels that rebuilds the 2 ... 4 levels above a tile for itself (hgi_fused_impl.h,
+//                cone_*): k = 4, up = levels - 4.  No lattice planes, no scratch, no launch in front.
+//   deeper:      k = 4, up = 4, and the stride-256 lattice -- an HGI image with levels - 8 levels of its own (same OOB rule:
+//                x < W <=> x >> 8 < ceil(W / 256)) -- is coded first; its planes are the cone's base.
+// (Frames coded band by band from host memory split differently -- six fused levels on seed planes of the stride-64 lattice:
+// host_banded() says why.  Every split gives the same bytes.)
 struct Split {
     uint32_t k, up, shift;      // fused levels, cone levels, log2 of the lattice coded in front (0: none)
 };
 
-Split split_pyramid(uint32_t levels, bool encode)
+Split split_pyramid(uint32_t levels)
 {
-    static const bool off = getenv("HGI_CONE") && atoi(getenv("HGI_CONE")) == 0;
-    static const int lo[2] = {getenv("HGI_CONE_MIN_DEC") ? atoi(getenv("HGI_CONE_MIN_DEC")) : HGI_CONE_MIN_DEC_DEFAULT,
-                              getenv("HGI_CONE_MIN_ENC") ? atoi(getenv("HGI_CONE_MIN_ENC")) : HGI_CONE_MIN_ENC_DEFAULT};
-    static const int forced[2] = {getenv("HGI_DEEP_K_DEC") ? atoi(getenv("HGI_DEEP_K_DEC")) : 0,
-                                  getenv("HGI_DEEP_K_ENC") ? atoi(getenv("HGI_DEEP_K_ENC")) : 0};
-    const int m = lo[encode ? 1 : 0] < 5 ? 5 : lo[encode ? 1 : 0];
-    if (!off && levels >= (uint32_t)m) {
-        if (levels <= 8u) return {4u, levels - 4u, 0u};
-        return {4u, 4u, 8u};
-    }
-    if (levels <= (uint32_t)kFusedMaxLevels) return {levels, 0u, 0u};
-    const int f = forced[encode ? 1 : 0];
-    const uint32_t k = (f >= kSeededMinLevels && f <= kFusedMaxLevels) ? (uint32_t)f : (uint32_t)kFusedMaxLevels;
-    return {k, 0u, k};
+    if (levels < kConeMinLevels) return {levels, 0u, 0u};
+    if (levels <= 8u) return {4u, levels - 4u, 0u};
+    return {4u, 4u, 8u};
 }
 
 // Scratch bytes one encode (or decode) of this shape takes, recursion included.  The bump allocator only resets
@@ -156,7 +113,7 @@ size_t plane_bytes(const SubGeom &g, size_t batch) { return align_up(batch * g.s
 
 size_t ws_need_decode(uint32_t w, uint32_t h, uint32_t levels, size_t batch)
 {
-    const Split sp = split_pyramid(levels, false);
+    const Split sp = split_pyramid(levels);
     if (!sp.shift) return 0;
     const SubGeom g = sub_geom(w, h, sp.shift);
     return 2 * plane_bytes(g, batch) + ws_need_decode(g.sw, g.sh, levels - sp.shift, batch);
@@ -164,7 +121,7 @@ size_t ws_need_decode(uint32_t w, uint32_t h, uint32_t levels, size_t batch)
 
 size_t ws_need_encode(uint32_t w, uint32_t h, uint32_t levels, size_t batch)
 {
-    const Split sp = split_pyramid(levels, true);
+    const Split sp = split_pyramid(levels);
     if (!sp.shift) return 0;
     const SubGeom g = sub_geom(w, h, sp.shift);
     return 3 * plane_bytes(g, batch) + ws_need_encode(g.sw, g.sh, levels - sp.shift, batch) + ws_need_decode(g.sw, g.sh, levels - sp.shift, batch);
@@ -183,18 +140,13 @@ size_t ws_need(const hgi_ctx *c, uint32_t w, uint32_t h, uint32_t levels, size_t
 // the dependent chain per wave.  Measured crossover on MI355X at level 4 (tools/size_sweep.py): equal at ~2000
 // tiles; 32-row ahead by 15-35 % below ~1200, 64-row ahead by 12 % at 4000.  A single small frame (up to about two
 // waves per CU of 32-row tiles) ends when its slowest wave does, and that wave's chain is mostly its own VALU work:
-// 128 x 16 tiles halve the finest level's share of it (profiles/r03_sizes.txt).  HGI_TILE_H=16|32|64 in the
-// environment forces one where the pyramid fits (experiments, tests); HGI_TILE16_MAX moves the lower crossover.
+// 128 x 16 tiles halve the finest level's share of it (profiles/r03_sizes.txt).  (Knobs build: HGI_TILE_H = 16 | 32 | 64
+// forces one where the pyramid fits -- the test suite runs every geometry on every shape; HGI_TILE16_MAX moves the lower
+// crossover.)
 uint32_t use_tile_rows(uint32_t w, uint32_t h, uint32_t k, size_t batch, bool encode)
 {
-    static const int forced = [] {
-        const char *e = getenv("HGI_TILE_H");
-        return e ? atoi(e) : 0;
-    }();
-    static const uint64_t tiny_max = [] {
-        const char *e = getenv("HGI_TILE16_MAX");
-        return e ? (uint64_t)atoll(e) : (uint64_t)HGI_TILE16_MAX_DEFAULT;
-    }();
+    const int forced = HGI_KNOB(HGI_TILE_H, 0);
+    const uint64_t tiny_max = (uint64_t)HGI_KNOB(HGI_TILE16_MAX, HGI_TILE16_MAX);
     if (k > (uint32_t)kFusedMaxLevelsSmall) return 64;
     const bool fits16 = k <= (uint32_t)kFusedMaxLevelsTiny;
     if (forced == 16 && fits16) return 16;
@@ -206,12 +158,13 @@ uint32_t use_tile_rows(uint32_t w, uint32_t h, uint32_t k, size_t batch, bool en
     return tiles64 < 1536 ? 32 : 64;
 }
 
-// Deep pyramids: the one-workgroup-per-frame kernel for the levels above the fused depth, when the lattice plane is
-// small (hgi_kernels.hip).  HGI_NO_LATTICE_KERNEL in the environment keeps the recursive path (tests).
+// Pyramids deeper than eight levels: the one-workgroup-per-frame kernel codes the lattice plane when it is small (at most
+// 8 192 points per frame: hgi_kernels.hip); a larger plane is an image in its own right and goes through encode_impl /
+// decode_impl.  (Knobs build: HGI_NO_LATTICE_KERNEL sends small planes down the second route too, so that the test suite
+// reaches it without a 23 000 x 23 000 frame.)
 bool use_lattice_kernel(const SubGeom &g, size_t batch)
 {
-    static const bool off = getenv("HGI_NO_LATTICE_KERNEL") != nullptr;
-    return !off && lattice_pyramid_fits(g.sw, g.sh, batch);
+    return !HGI_SWITCH(HGI_NO_LATTICE_KERNEL) && lattice_pyramid_fits(g.sw, g.sh, batch);
 }
 
 hipError_t launch_encode_fused(const uint8_t *img, uint8_t *grid, const Frames &f, uint32_t k, int interp,
@@ -250,9 +203,6 @@ bool is_identity(const uint8_t lut[256])
     return true;
 }
 
-hgi_status decode_impl(hgi_ctx *c, const uint8_t *grid, uint32_t w, uint32_t h, uint32_t levels, int interp,
-                       uint8_t *img, size_t batch, size_t stride);
-
 hgi_status encode_impl(hgi_ctx *c, const uint8_t *img, uint32_t w, uint32_t h, uint32_t levels, int interp,
                        const uint8_t lut[256], uint8_t *grid, size_t batch, size_t stride)
 {
@@ -272,7 +222,7 @@ hgi_status encode_impl(hgi_ctx *c, const uint8_t *img, uint32_t w, uint32_t h, u
             HIP_TRY(launch_encode_level(rec, grid, f, levels - level - 1, interp, l, c->stream));
         return HGI_OK;
     }
-    const Split sp = split_pyramid(levels, true);
+    const Split sp = split_pyramid(levels);
     if (sp.shift) {
         // the lattice = 0 (mod 2^shift) first: its reconstruction and residuals are what the tile launch starts from
         const SubGeom g = sub_geom(w, h, sp.shift);
@@ -314,7 +264,7 @@ hgi_status decode_impl(hgi_ctx *c, const uint8_t *grid, uint32_t w, uint32_t h, 
             HIP_TRY(launch_decode_level(grid, img, f, levels - level - 1, interp, c->stream));
         return HGI_OK;
     }
-    const Split sp = split_pyramid(levels, false);
+    const Split sp = split_pyramid(levels);
     if (sp.shift) {
         const SubGeom g = sub_geom(w, h, sp.shift);
         uint8_t *sub_grid = ws_take(c, batch * g.stride);
@@ -371,12 +321,67 @@ hgi_status check_common(hgi_ctx *c, const void *a, const void *b, uint32_t level
     return HGI_OK;
 }
 
-}  // namespace
+// Host-pointer calls on ONE frame (hgi_encode_u8 / hgi_decode_u8): are they banded, and how much scratch do they take?  One
+// formula for host_roundtrip / host_banded AND hgi_ctx_reserve, so that a reserved ctx really does not re-allocate.
+bool host_call_is_banded(const hgi_ctx *c, uint32_t w, uint32_t h, uint32_t levels)
+{
+    // large frames with a pyramid at least one level deep: band the frame so that its upload and download overlap
+    return (size_t)w * h >= (4u << 20) && levels >= 1 && c->path != HGI_PATH_LEVELWISE && h >= 256 && !HGI_SWITCH(HGI_NO_BANDS);
+}
+
+// banded calls code pyramids deeper than a tile at six fused levels on seed planes of the stride-64 lattice (host_banded)
+size_t banded_lattice_need(uint32_t w, uint32_t h, uint32_t levels)
+{
+    const uint32_t k = levels < (uint32_t)kFusedMaxLevels ? levels : (uint32_t)kFusedMaxLevels;
+    if (levels <= k) return 0;
+    const SubGeom g = sub_geom(w, h, k);
+    return 3 * plane_bytes(g, 1) + ws_need_encode(g.sw, g.sh, levels - k, 1) + ws_need_decode(g.sw, g.sh, levels - k, 1);
+}
+
+size_t host_call_need(const hgi_ctx *c, uint32_t w, uint32_t h, uint32_t levels)
+{
+    const size_t n = (size_t)w * h, slot = align_up(n, 256) + 256;      // two staging slots: the frame in, the frame out
+    if (host_call_is_banded(c, w, h, levels)) return 2 * slot + banded_lattice_need(w, h, levels) + 1024;
+    return 2 * slot + ws_need(c, w, h, levels, 1, n);
+}
+
+hgi_status pipe_ensure(hgi_ctx *c)
+{
+    if (c->have_pipe) return HGI_OK;
+    bool ok = hipStreamCreateWithFlags(&c->pipe[0], hipStreamNonBlocking) == hipSuccess;
+    ok = ok && hipStreamCreateWithFlags(&c->pipe[1], hipStreamNonBlocking) == hipSuccess;
+    for (int i = 0; i < 3 && ok; ++i)
+        ok = hipEventCreateWithFlags(&c->ev_up[i], hipEventDisableTiming) == hipSuccess &&
+             hipEventCreateWithFlags(&c->ev_free[i], hipEventDisableTiming) == hipSuccess;
+    for (int i = 0; i < 16 && ok; ++i) ok = hipEventCreateWithFlags(&c->ev_band[i], hipEventDisableTiming) == hipSuccess;
+    if (!ok) return fail(HGI_EDEVICE, "stream/event creation failed");   // (a partial set is reclaimed with the process)
+    c->have_pipe = true;
+    return HGI_OK;
+}
+
+hgi_status pin_ensure(hgi_ctx *c, size_t bytes)
+{
+    if (bytes <= c->pin_bytes) return HGI_OK;
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (c->pin) HIP_TRY(hipHostFree(c->pin));
+    c->pin = nullptr;
+    c->pin_bytes = 0;
+    HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&c->pin), bytes, hipHostMallocDefault));
+    c->pin_bytes = bytes;
+    return HGI_OK;
+}
+
+}  // namespace host
+}  // namespace hgi
 
 extern "C" {
 
 const char *hgi_last_error(void) { return g_err; }
-const char *hgi_version(void) { return "hgi-hip 0.1.0 (gfx950)"; }
+#ifdef HGI_KNOBS_ENV
+const char *hgi_version(void) { return "hgi-hip 0.2.0 (gfx950; KNOBS build: tuning constants and test switches from the environment)"; }
+#else
+const char *hgi_version(void) { return "hgi-hip 0.2.0 (gfx950)"; }
+#endif
 
 hgi_status hgi_ctx_create(int device, hgi_ctx **out)
 {
@@ -469,10 +474,16 @@ hgi_status hgi_ctx_reserve(hgi_ctx *c, uint32_t w, uint32_t h, uint32_t levels, 
     if (!c) return fail(HGI_EINVAL, "ctx is NULL");
     if (levels > 31) return fail(HGI_EINVAL, "levels %u out of range 0..=31", levels);
     HIP_TRY(hipSetDevice(c->device));
-    size_t stride = (size_t)w * h;
-    size_t need = ws_need(c, w, h, levels, batch, stride);
-    size_t host = 2 * (align_up(stride, 256) + 256);   // staging of the host-pointer entry points
-    return ws_ensure(c, need + host);
+    // the device-pointer calls on a batch of this shape, or the host-pointer calls on one frame of it, whichever takes more
+    const size_t dev = ws_need(c, w, h, levels, batch, (size_t)w * h), host = host_call_need(c, w, h, levels);
+    return ws_ensure(c, dev > host ? dev : host);
+}
+
+hgi_status hgi_ctx_scratch_bytes(hgi_ctx *c, size_t *bytes)
+{
+    if (!c || !bytes) return fail(HGI_EINVAL, "NULL argument");
+    *bytes = c->ws_bytes;
+    return HGI_OK;
 }
 
 hgi_status hgi_sync(hgi_ctx *c)
@@ -541,11 +552,9 @@ static hgi_status host_roundtrip(hgi_ctx *c, const uint8_t *in, uint8_t *out, ui
     if (encode && !lut) return fail(HGI_EINVAL, "lut is NULL");
     if (w == 0 || h == 0) return HGI_OK;
     HIP_TRY(hipSetDevice(c->device));
-    const size_t n = (size_t)w * h, slot = align_up(n, 256) + 256;
-    // large frames with a pyramid one tile deep: band the frame so that its upload and download overlap
-    if (n >= (4u << 20) && levels >= 1 && c->path != HGI_PATH_LEVELWISE && h >= 256 && !getenv("HGI_NO_BANDS"))
-        return host_banded(c, in, out, w, h, levels, interp, lut, encode);
-    HGI_TRY(ws_ensure(c, ws_need(c, w, h, levels, 1, n) + 2 * slot));
+    const size_t n = (size_t)w * h;
+    if (host_call_is_banded(c, w, h, levels)) return host_banded(c, in, out, w, h, levels, interp, lut, encode);
+    HGI_TRY(ws_ensure(c, host_call_need(c, w, h, levels)));
     c->ws_used = 0;
     uint8_t *d_in = ws_take(c, n), *d_out = ws_take(c, n);
     if (!d_in || !d_out) return fail(HGI_ENOMEM, "scratch exhausted (host staging)");
@@ -556,20 +565,6 @@ static hgi_status host_roundtrip(hgi_ctx *c, const uint8_t *in, uint8_t *out, ui
         HGI_TRY(decode_impl(c, d_in, w, h, levels, interp, d_out, 1, n));
     HIP_TRY(hipMemcpyAsync(out, d_out, n, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
-    return HGI_OK;
-}
-
-static hgi_status pipe_ensure(hgi_ctx *c)
-{
-    if (c->have_pipe) return HGI_OK;
-    bool ok = hipStreamCreateWithFlags(&c->pipe[0], hipStreamNonBlocking) == hipSuccess;
-    ok = ok && hipStreamCreateWithFlags(&c->pipe[1], hipStreamNonBlocking) == hipSuccess;
-    for (int i = 0; i < 3 && ok; ++i)
-        ok = hipEventCreateWithFlags(&c->ev_up[i], hipEventDisableTiming) == hipSuccess &&
-             hipEventCreateWithFlags(&c->ev_free[i], hipEventDisableTiming) == hipSuccess;
-    for (int i = 0; i < 16 && ok; ++i) ok = hipEventCreateWithFlags(&c->ev_band[i], hipEventDisableTiming) == hipSuccess;
-    if (!ok) return fail(HGI_EDEVICE, "stream/event creation failed");   // (a partial set is reclaimed with the process)
-    c->have_pipe = true;
     return HGI_OK;
 }
 
@@ -584,7 +579,6 @@ static hgi_status host_banded(hgi_ctx *c, const uint8_t *in, uint8_t *out, uint3
 {
     const size_t n = (size_t)w * h;
     HGI_TRY(pipe_ensure(c));
-    const size_t slot = align_up(n, 256) + 256;
     // Pyramids deeper than a tile: the stride-2^k lattice (every 64th pixel of every 64th row) is gathered on the host --
     // it is tiny -- and goes up first; its seeds are ready long before the first band is.  The split is six levels + seed
     // planes here, not split_pyramid()'s: a tile that rebuilt the levels above it for itself (the cone) would read rows
@@ -592,13 +586,8 @@ static hgi_status host_banded(hgi_ctx *c, const uint8_t *in, uint8_t *out, uint3
     // 0.1 ms of kernels), and six keeps the host-side gather at w*h / 4096 bytes.
     const uint32_t k = levels < (uint32_t)kFusedMaxLevels ? levels : (uint32_t)kFusedMaxLevels;
     const bool deep = levels > k;
-    SubGeom g = {0, 0, 0};
-    size_t lattice_need = 0;
-    if (deep) {
-        g = sub_geom(w, h, k);
-        lattice_need = 3 * plane_bytes(g, 1) + ws_need_encode(g.sw, g.sh, levels - k, 1) + ws_need_decode(g.sw, g.sh, levels - k, 1);
-    }
-    HGI_TRY(ws_ensure(c, 2 * slot + lattice_need + 1024));
+    const SubGeom g = deep ? sub_geom(w, h, k) : SubGeom{0, 0, 0};
+    HGI_TRY(ws_ensure(c, host_call_need(c, w, h, levels)));
     c->ws_used = 0;
     uint8_t *d_in = ws_take(c, n), *d_out = ws_take(c, n);
     if (!d_in || !d_out) return fail(HGI_ENOMEM, "scratch exhausted (host staging)");
@@ -649,9 +638,10 @@ static hgi_status host_banded(hgi_ctx *c, const uint8_t *in, uint8_t *out, uint3
     // Upload stream: band b goes up together with its halo rows -- the tiles of its last tile row read input rows down to
     // offset 2^k <= 64 below the band INCLUSIVE (halo row TH + 64 at k = 6), i.e. 65 rows of band b + 1 -- so that its
     // kernel waits for nothing else; band b + 1 then starts below them.
-    // HGI_TEST_BAND_HOLD (tests): d_in is poisoned with 0xFF first and band b + 1's upload is held until band b's kernel
-    // has finished, so a kernel that read a row its own upload did not cover would see poison, deterministically.
-    static const bool hold = getenv("HGI_TEST_BAND_HOLD") != nullptr;
+    // Knobs build only (HGI_TEST_BAND_HOLD; constant false, and the branches below gone, in the release library): d_in is
+    // poisoned with 0xFF first and band b + 1's upload is held until band b's kernel has finished, so a kernel that read a
+    // row its own upload did not cover would see poison, deterministically.
+    const bool hold = HGI_SWITCH(HGI_TEST_BAND_HOLD);
     constexpr size_t kHaloRows = 65;
     auto upload = [&](uint32_t b) {
         const size_t y0 = b ? (size_t)b * band + kHaloRows : 0;
@@ -849,543 +839,6 @@ hgi_status hgi_diff_stats_dev(hgi_ctx *c, const void *d_before, const void *d_af
     return HGI_OK;
 }
 
-// ---- entropy stage --------------------------------------------------------------------------------------------
-hgi_status hgi_huffman_plan(const uint64_t hist[286], uint8_t lens[286], uint16_t codes[286], uint8_t *header, size_t header_cap,
-                            size_t *header_bits)
-{
-    if (!hist || !lens || !codes || !header || !header_bits) return fail(HGI_EINVAL, "NULL argument");
-    uint64_t any = 0;
-    for (int i = 0; i < kDeflateSymbols; ++i) any |= hist[i];
-    if (!any) return fail(HGI_EINVAL, "empty histogram");
-    *header_bits = huffman_plan(hist, lens, codes, header, header_cap);
-    if (!*header_bits) return fail(HGI_EINVAL, "header buffer too small (%zu bytes)", header_cap);
-    return HGI_OK;
-}
-
-// ---- the stage itself: `batch` grids, phase by phase, so that the host waits three times per GROUP of frames, not per frame
-namespace {
-
-constexpr size_t kHistBytes = (kMatchThresholds + 1) * kDeflateSymbols * 8;      // per frame, contiguous (one download)
-
-struct DeflateGeom {
-    uint64_t n;
-    uint32_t nchunks;
-    size_t dev_cap;       // bytes of stream buffer per frame on the device
-    size_t group;         // frames whose stream buffers live in scratch at once
-    size_t need;          // scratch bytes
-};
-
-DeflateGeom deflate_geom(uint64_t n, size_t batch)
-{
-    DeflateGeom g;
-    g.n = n;
-    g.nchunks = huffman_chunks(n);
-    g.dev_cap = align_up((size_t)(n + n / 4) + 4096, 256);      // an optimal code averages < 9 bits per byte
-    // a group's stream buffers: 256 MiB by default (two groups are in flight: one being packed, one being downloaded);
-    // HGI_ENTROPY_GROUP_MIB in the environment sets another size (tools/entropy_packed_time.py: smaller groups shorten
-    // the un-overlapped head and tail of the pipeline, more groups cost more synchronisations)
-    static const size_t group_mib = [] {
-        const char *e = getenv("HGI_ENTROPY_GROUP_MIB");
-        const long v = e ? atol(e) : 0;
-        return v > 0 ? (size_t)v : (size_t)HGI_ENTROPY_GROUP_MIB_DEFAULT;
-    }();
-    size_t group = (group_mib << 20) / g.dev_cap;
-    if (group < 1) group = 1;
-    if (group > batch) group = batch ? batch : 1;
-    if (group > 256) group = 256;
-    // equal groups: the last one is not a straggler
-    const size_t ngroups = batch ? (batch + group - 1) / group : 1;
-    if (batch) group = (batch + ngroups - 1) / ngroups;
-    g.group = group;
-    const size_t sets = ngroups > 1 ? 2 : 1;
-    g.need = group * (sets * (kHistBytes + g.dev_cap) + kPlanBytes + (size_t)g.nchunks * 12 + 64) + (batch ? batch : 1) * 8 + 4096;
-    return g;
-}
-
-using huff::FramePlan;
-
-hgi_status pin_ensure(hgi_ctx *c, size_t bytes)
-{
-    if (bytes <= c->pin_bytes) return HGI_OK;
-    HIP_TRY(hipStreamSynchronize(c->stream));
-    if (c->pin) HIP_TRY(hipHostFree(c->pin));
-    c->pin = nullptr;
-    c->pin_bytes = 0;
-    HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&c->pin), bytes, hipHostMallocDefault));
-    c->pin_bytes = bytes;
-    return HGI_OK;
-}
-
-// The stage over `batch` grids, in groups of g.group frames, software-pipelined so that the device always has the next
-// thing queued while the host builds codes or waits for a download:
-//     device, c->stream :  hist(0) | hist(1) pack(0) | hist(2) pack(1) | ...
-//     host              :          | plan(0)         | plan(1)         | ...      (several threads, one frame each)
-//     device, pipe[1]   :                            | streams(0) down | streams(1) down ...
-// hist = token histograms (one launch per group), plan = codes + headers, pack = count / scan / pack (three launches per
-// group).  Stream sizes are known from the histograms, so the downloads are queued without waiting for the pack.
-// offsets == nullptr: stream f goes to out + f * out_stride (cap = room per stream).  offsets != nullptr (packed): the
-// streams of a group lie back to back on the device (64-byte aligned starts) and come down with ONE copy per group into
-// out + offsets[f]; cap = room in `out` altogether.
-hgi_status deflate_frames(hgi_ctx *c, const uint8_t *d_grids, uint32_t w, uint32_t h, size_t batch, size_t stride, uint8_t *out,
-                          size_t out_stride, size_t cap, size_t *sizes, size_t *offsets = nullptr)
-{
-    const bool packed = offsets != nullptr;
-    size_t packed_at = 0;                      // packed: where the next group starts in `out`
-    const DeflateGeom g = deflate_geom((uint64_t)w * h, batch);
-    const uint64_t n = g.n;
-    // the bincode image of Grid { buffer: Vec<u8>, width: usize } (src/grid.rs:2-5): u64 length, the bytes, u64 width
-    uint8_t prefix[8], suffix[8];
-    for (int i = 0; i < 8; ++i) {
-        prefix[i] = (uint8_t)(n >> (8 * i));
-        suffix[i] = (uint8_t)((uint64_t)w >> (8 * i));
-    }
-    // Group boundaries: equal groups.  (Small first groups that double up to the full size -- to shorten the pipeline's
-    // un-overlapped head, the first group's own histogram + plan + pack -- were tried: 9 groups instead of 6 for the C3
-    // shard cost more in synchronisations than the head gave back: packed / strided 0.92 against 0.90, profiles/r03_entropy_groups.txt.)
-    std::vector<size_t> starts;
-    for (size_t at = 0; at < batch; at += g.group) starts.push_back(at);
-    starts.push_back(batch);
-    const size_t ngroups = starts.size() - 1;
-    const bool piped = ngroups > 1;
-    if (!n) {
-        // nothing for the device to code: the front, then the tail, here
-        std::vector<uint64_t> hist0((kMatchThresholds + 1) * kDeflateSymbols, 0);
-        FramePlan p;
-        if (!huff::plan_frame(reinterpret_cast<uint64_t (*)[kDeflateSymbols]>(hist0.data()), false, prefix, suffix, p))
-            return fail(HGI_EDEVICE, "block header does not fit");
-        const size_t total_bytes = (size_t)((p.exact_bits + 7) / 8), slot = align_up(total_bytes, 64);
-        if (packed ? slot * batch > cap : total_bytes > cap)
-            return fail(HGI_EINVAL, "output buffer too small: %zu bytes needed", packed ? slot * batch : total_bytes);
-        for (size_t f = 0; f < batch; ++f) {
-            uint8_t *dst = out + (packed ? f * slot : f * out_stride);
-            if (packed) offsets[f] = f * slot;
-            std::memset(dst, 0, total_bytes);
-            std::memcpy(dst, p.block.front, p.block.front_bytes);
-            uint64_t at = p.block.base_bits;
-            const uint8_t *tail = reinterpret_cast<const uint8_t *>(p.block.tail);
-            for (uint32_t i = 0; i < p.block.tail_bits; ++i, ++at) dst[at >> 3] |= (uint8_t)(((tail[i >> 3] >> (i & 7)) & 1u) << (at & 7));
-            sizes[f] = total_bytes;
-        }
-        return HGI_OK;
-    }
-    HGI_TRY(ws_ensure(c, g.need));
-    HGI_TRY(pin_ensure(c, 2 * g.group * kHistBytes + align_up(batch * 8, 256) + 2 * g.group * kPlanBytes));
-    if (piped) HGI_TRY(pipe_ensure(c));
-    c->ws_used = 0;
-    uint8_t *d_hist[2], *d_outs[2];
-    for (int k = 0; k < 2; ++k) d_hist[k] = (k == 0 || piped) ? ws_take(c, g.group * kHistBytes) : d_hist[0];
-    uint8_t *d_plans = ws_take(c, g.group * kPlanBytes);
-    uint64_t *d_totals = reinterpret_cast<uint64_t *>(ws_take(c, batch * 8));
-    uint64_t *d_off = reinterpret_cast<uint64_t *>(ws_take(c, g.group * (size_t)g.nchunks * 8 + 8));
-    uint32_t *d_cbits = reinterpret_cast<uint32_t *>(ws_take(c, g.group * (size_t)g.nchunks * 4 + 8));
-    for (int k = 0; k < 2; ++k) d_outs[k] = (k == 0 || piped) ? ws_take(c, g.group * g.dev_cap) : d_outs[0];
-    c->ws_used = 0;
-    if (!d_hist[0] || !d_hist[1] || !d_plans || !d_totals || !d_off || !d_cbits || !d_outs[0] || !d_outs[1])
-        return fail(HGI_ENOMEM, "scratch exhausted (entropy stage)");
-    uint64_t *h_hist[2] = {reinterpret_cast<uint64_t *>(c->pin), reinterpret_cast<uint64_t *>(c->pin + g.group * kHistBytes)};
-    uint64_t *h_totals = reinterpret_cast<uint64_t *>(c->pin + 2 * g.group * kHistBytes);
-    const uint32_t dist_code = 0u | (1u << 24);      // distance symbol 0 (= distance 1): the one-bit code "0"
-    std::vector<FramePlan> plans(g.group);
-    // The plan blocks go up from pinned memory, two sets: the copy is then truly asynchronous (the host plans group gi + 1
-    // while the device still packs group gi), and a set is rewritten only after ev_hist of two groups later -- which the
-    // stream reaches behind this set's upload -- has been waited for.
-    DeflatePlan *h_plans[2];
-    h_plans[0] = reinterpret_cast<DeflatePlan *>(c->pin + 2 * g.group * kHistBytes + align_up(batch * 8, 256));
-    h_plans[1] = h_plans[0] + g.group;
-    std::vector<uint64_t> promised(batch), fixed_bits(batch);      // per frame: the stream's bits, and those that are not tokens
-    std::vector<size_t> group_at(ngroups, 0), group_bytes(ngroups, 0);      // packed: a group's place in `out` and its length
-    hipStream_t down = piped ? c->pipe[1] : c->stream;
-    hipEvent_t *ev_hist = c->ev_hist;
-    auto first_of = [&](size_t gi) { return starts[gi]; };
-    auto count_of = [&](size_t gi) { return starts[gi + 1] - starts[gi]; };
-    auto queue_hist = [&](size_t gi) -> hipError_t {
-        const int set = (int)(gi & 1);
-        hipError_t e = launch_token_histogram(d_grids + first_of(gi) * stride, n, stride, (uint32_t)count_of(gi),
-                                              reinterpret_cast<unsigned long long *>(d_hist[set]), c->stream);
-        if (e == hipSuccess) e = hipMemcpyAsync(h_hist[set], d_hist[set], count_of(gi) * kHistBytes, hipMemcpyDeviceToHost, c->stream);
-        if (e == hipSuccess) e = hipEventRecord(ev_hist[set], c->stream);
-        return e;
-    };
-    auto queue_downloads = [&](size_t gi) -> hipError_t {
-        const int set = (int)(gi & 1);
-        hipError_t e = hipSuccess;
-        if (piped) e = hipStreamWaitEvent(down, c->ev_free[set], 0);
-        if (packed) {      // the group's streams are contiguous on the device: one copy
-            if (e == hipSuccess && group_bytes[gi])
-                e = hipMemcpyAsync(out + group_at[gi], d_outs[set], group_bytes[gi], hipMemcpyDeviceToHost, down);
-        } else {
-            for (size_t f = 0; f < count_of(gi) && e == hipSuccess; ++f) {
-                const size_t frame = first_of(gi) + f;
-                e = hipMemcpyAsync(out + frame * out_stride, d_outs[set] + f * g.dev_cap, (size_t)((promised[frame] + 7) / 8), hipMemcpyDeviceToHost, down);
-            }
-        }
-        if (piped && e == hipSuccess) e = hipEventRecord(c->ev_up[set], down);
-        return e;
-    };
-    // anything that fails after work was queued: drain before the host buffers the queue refers to go away
-    auto bail = [&](hgi_status st) {
-        (void)hipStreamSynchronize(c->stream);
-        if (piped) (void)hipStreamSynchronize(down);
-        return st;
-    };
-#define DF_TRY(expr)                                                                                                             \
-    do {                                                                                                                         \
-        hipError_t e_ = (expr);                                                                                                  \
-        if (e_ != hipSuccess) return bail(fail(HGI_EDEVICE, "%s: %s", #expr, hipGetErrorString(e_)));                           \
-    } while (0)
-    DF_TRY(queue_hist(0));
-    for (size_t gi = 0; gi < ngroups; ++gi) {
-        const int set = (int)(gi & 1);
-        const size_t g0 = first_of(gi), cnt = count_of(gi);
-        DF_TRY(hipEventSynchronize(ev_hist[set]));
-        if (gi + 1 < ngroups) DF_TRY(queue_hist(gi + 1));              // the device has this to do while the host plans
-        // codes on the host, a frame per thread
-        {
-            std::vector<int> status(cnt, 0);
-            auto work = [&](size_t t, size_t nt) {
-                for (size_t f = t; f < cnt; f += nt)
-                    status[f] = huff::plan_frame(reinterpret_cast<uint64_t (*)[kDeflateSymbols]>(h_hist[set] + f * (kHistBytes / 8)), true, prefix,
-                                                 suffix, plans[f]) ? 0 : 1;
-            };
-            size_t nt = cnt / 2;
-            if (nt > 8) nt = 8;
-            if (nt <= 1) {
-                work(0, 1);
-            } else {
-                std::vector<std::thread> pool;
-                for (size_t t = 1; t < nt; ++t) pool.emplace_back(work, t, nt);
-                work(0, nt);
-                for (auto &th : pool) th.join();
-            }
-            for (size_t f = 0; f < cnt; ++f)
-                if (status[f]) return bail(fail(HGI_EDEVICE, "block header does not fit"));
-        }
-        // the histograms say exactly how long each stream will be: never start packing into a buffer it would overrun
-        size_t dev_at = 0;                     // packed: running offset inside the group's device buffer
-        for (size_t f = 0; f < cnt; ++f) {
-            const FramePlan &p = plans[f];
-            const size_t bytes = (size_t)((p.exact_bits + 7) / 8);
-            if (p.exact_bits / 8 + 64 > g.dev_cap)
-                return bail(fail(HGI_EDEVICE, "entropy stage: stream of %llu bytes exceeds its scratch", (unsigned long long)(p.exact_bits / 8)));
-            if (!packed && bytes > cap) return bail(fail(HGI_EINVAL, "output buffer too small: %zu bytes needed", bytes));
-            h_plans[set][f] = p.block;
-            const uint64_t off = packed ? dev_at : f * g.dev_cap;
-            h_plans[set][f].out_off[0] = (uint32_t)off;
-            h_plans[set][f].out_off[1] = (uint32_t)(off >> 32);
-            if (packed) {
-                offsets[g0 + f] = packed_at + dev_at;
-                dev_at += align_up(bytes, 64);
-            }
-            promised[g0 + f] = p.exact_bits;
-            fixed_bits[g0 + f] = p.block.base_bits + p.block.tail_bits;
-        }
-        if (packed) {
-            if (packed_at + dev_at > cap)
-                return bail(fail(HGI_EINVAL, "output buffer too small: %zu bytes needed for the first %zu frames", packed_at + dev_at, g0 + cnt));
-            group_at[gi] = packed_at;
-            group_bytes[gi] = dev_at;
-            packed_at += dev_at;
-        }
-        // one upload of the plans, count / scan / pack over the whole group (its stream buffers are free once the group
-        // two back has been downloaded)
-        if (piped && gi >= 2) DF_TRY(hipStreamWaitEvent(c->stream, c->ev_up[set], 0));
-        DF_TRY(hipMemcpyAsync(d_plans, h_plans[set], cnt * kPlanBytes, hipMemcpyHostToDevice, c->stream));
-        DF_TRY(launch_huffman_pack(d_grids + g0 * stride, n, stride, (uint32_t)cnt, d_plans, dist_code, d_cbits, d_off, d_totals + g0, d_outs[set],
-                                   c->stream));
-        if (piped) DF_TRY(hipEventRecord(c->ev_free[set], c->stream));
-        // downloads lag one group behind, so that the device has hist(gi + 1) and pack(gi) queued while they run
-        if (piped) {
-            if (gi >= 1) DF_TRY(queue_downloads(gi - 1));
-        } else {
-            DF_TRY(queue_downloads(gi));
-        }
-    }
-    if (piped) DF_TRY(queue_downloads(ngroups - 1));
-    DF_TRY(hipMemcpyAsync(h_totals, d_totals, batch * 8, hipMemcpyDeviceToHost, c->stream));
-    DF_TRY(hipStreamSynchronize(c->stream));
-    if (piped) DF_TRY(hipStreamSynchronize(down));
-#undef DF_TRY
-    for (size_t f = 0; f < batch; ++f) {
-        const uint64_t got = fixed_bits[f] + h_totals[f];
-        if (got != promised[f])
-            return fail(HGI_EDEVICE, "entropy stage: packed %llu bits where the histograms promised %llu", (unsigned long long)got,
-                        (unsigned long long)promised[f]);
-        sizes[f] = (size_t)((promised[f] + 7) / 8);
-    }
-    return HGI_OK;
-}
-
-}  // namespace
-
-// host-pointer form (what pairs with hgi_encode_u8): the grid goes up into scratch behind the stage's own buffers
-hgi_status hgi_deflate_grid(hgi_ctx *c, const uint8_t *grid, uint32_t w, uint32_t h, uint8_t *out, size_t cap, size_t *bytes)
-{
-    if (!c || !out || !bytes) return fail(HGI_EINVAL, "NULL argument");
-    const size_t n = (size_t)w * h;
-    if (n && !grid) return fail(HGI_EINVAL, "NULL buffer");
-    HIP_TRY(hipSetDevice(c->device));
-    const size_t front = align_up(deflate_geom(n, 1).need, 256);
-    HGI_TRY(ws_ensure(c, front + n + 256));
-    uint8_t *staged = c->ws + front;
-    if (n) HIP_TRY(hipMemcpyAsync(staged, grid, n, hipMemcpyHostToDevice, c->stream));
-    return deflate_frames(c, staged, w, h, 1, n, out, cap, cap, bytes);
-}
-
-hgi_status hgi_deflate_grid_dev(hgi_ctx *c, const void *d_grid, uint32_t w, uint32_t h, uint8_t *out, size_t cap, size_t *bytes)
-{
-    if (!c || !out || !bytes) return fail(HGI_EINVAL, "NULL argument");
-    if ((uint64_t)w * h && !d_grid) return fail(HGI_EINVAL, "NULL buffer");
-    HIP_TRY(hipSetDevice(c->device));
-    return deflate_frames(c, static_cast<const uint8_t *>(d_grid), w, h, 1, (size_t)w * h, out, cap, cap, bytes);
-}
-
-hgi_status hgi_deflate_grids_dev(hgi_ctx *c, const void *d_grids, uint32_t w, uint32_t h, size_t batch, size_t frame_stride, uint8_t *out,
-                                 size_t out_stride, size_t *sizes)
-{
-    if (!c || (batch && (!out || !sizes))) return fail(HGI_EINVAL, "NULL argument");
-    if (batch == 0) return HGI_OK;
-    const size_t n = (size_t)w * h;
-    if (n && !d_grids) return fail(HGI_EINVAL, "NULL buffer");
-    if (batch > 1 && frame_stride < n) return fail(HGI_EINVAL, "frame_stride %zu < width*height", frame_stride);
-    HIP_TRY(hipSetDevice(c->device));
-    return deflate_frames(c, static_cast<const uint8_t *>(d_grids), w, h, batch, frame_stride, out, out_stride, out_stride, sizes);
-}
-
-hgi_status hgi_deflate_grids_packed_dev(hgi_ctx *c, const void *d_grids, uint32_t w, uint32_t h, size_t batch, size_t frame_stride,
-                                        uint8_t *out, size_t cap, size_t *offsets, size_t *sizes)
-{
-    if (!c || (batch && (!out || !sizes || !offsets))) return fail(HGI_EINVAL, "NULL argument");
-    if (batch == 0) return HGI_OK;
-    const size_t n = (size_t)w * h;
-    if (n && !d_grids) return fail(HGI_EINVAL, "NULL buffer");
-    if (batch > 1 && frame_stride < n) return fail(HGI_EINVAL, "frame_stride %zu < width*height", frame_stride);
-    HIP_TRY(hipSetDevice(c->device));
-    return deflate_frames(c, static_cast<const uint8_t *>(d_grids), w, h, batch, frame_stride, out, 0, cap, sizes, offsets);
-}
-
-// ---- plane placement ------------------------------------------------------------------------------------------
-// Measured on MI355X (profiles/r02_modes*.txt): the HBM behind one device is served in large physical
-// regions (the driver's buddy blocks of up to 64 GiB never straddle one), and a kernel that streams one buffer in while
-// streaming another out runs 4-5 % faster when the two lie in DIFFERENT regions than when they share one -- for the
-// tile kernels 0.365 against 0.382 ms per GiB, for a linear copy 1.5 %.  Physical addresses are not visible from user
-// space, so the only way to tell is to run the stream: the probe below times the decode kernel from one buffer into the
-// other (its time does not depend on the bytes).  hgi_planes_alloc uses it to hand out planes whose neighbours in the
-// array lie in different regions: what an encode -> decode chain (image -> grid -> image) wants.
-namespace {
-
-// mean time of decode launches prev -> cand over min(bytes, 2 GiB), as one frame 4096 wide
-hgi_status probe_pair_ms(hgi_ctx *c, const uint8_t *prev, uint8_t *cand, size_t bytes, float *ms)
-{
-    const uint32_t w = 4096;
-    size_t rows = bytes / w;
-    if (rows > (2u << 20) / 4) rows = (2u << 20) / 4;          // 2 GiB: every byte offset stays below 2^32
-    rows &= ~(size_t)63;
-    const uint32_t h = (uint32_t)rows;
-    constexpr int kWarm = 2, kTimed = 4;
-    for (int i = 0; i < kWarm + kTimed; ++i) {
-        if (i == kWarm) HIP_TRY(hipEventRecord(c->ev_probe[0], c->stream));
-        c->ws_used = 0;
-        // LeftTop: the same memory-access structure as Crossed, and a kernel name of its own in profiles
-        // (k_dec_tiles<0, ...>), so that probe launches are never counted among the workload's k_dec_tiles<1, ...>
-        HGI_TRY(decode_impl(c, prev, w, h, 4, HGI_INTERP_LEFTTOP, cand, 1, (size_t)w * h));
-    }
-    HIP_TRY(hipEventRecord(c->ev_probe[1], c->stream));
-    HIP_TRY(hipEventSynchronize(c->ev_probe[1]));
-    HIP_TRY(hipEventElapsedTime(ms, c->ev_probe[0], c->ev_probe[1]));
-    *ms /= kTimed;
-    return HGI_OK;
-}
-
-constexpr size_t kProbeMinBytes = (size_t)512 << 20;   // below this the stream lives in the 256 MiB Infinity Cache: no signal
-constexpr float kFastRatio = 0.96f;   // a pair counts as "different regions" when it streams in < 0.96 of the same-region
-                                      // yardstick's time (measured: 0.93-0.94 across regions, 0.97-1.0 within or between
-                                      // some pairs of blocks)
-constexpr int kMaxCandidates = 10;
-
-}  // namespace
-
-hgi_status hgi_probe_pair_u8_dev(hgi_ctx *c, const void *d_src, void *d_dst, size_t bytes, float *ms)
-{
-    if (!c || !d_src || !d_dst || !ms) return fail(HGI_EINVAL, "NULL argument");
-    if (bytes < 4096 * 64) return fail(HGI_EINVAL, "probe needs at least 256 KiB");
-    const uintptr_t a = reinterpret_cast<uintptr_t>(d_src), b = reinterpret_cast<uintptr_t>(d_dst);
-    if (a < b + bytes && b < a + bytes) return fail(HGI_EINVAL, "probe buffers overlap");
-    HIP_TRY(hipSetDevice(c->device));
-    HGI_TRY(ws_ensure(c, ws_need(c, 4096, 4096, 4, 1, (size_t)4096 * 4096)));
-    return probe_pair_ms(c, static_cast<const uint8_t *>(d_src), static_cast<uint8_t *>(d_dst), bytes, ms);
-}
-
-hgi_status hgi_planes_alloc(hgi_ctx *c, size_t bytes, uint32_t count, void **planes, int *separated)
-{
-    if (!c || !planes) return fail(HGI_EINVAL, "NULL argument");
-    if (separated) *separated = 0;
-    for (uint32_t i = 0; i < count; ++i) planes[i] = nullptr;
-    if (count == 0 || bytes == 0) return HGI_OK;
-    // Planes of 128 ... 512 MiB: a launch that reads one and writes the next (2 x 256 MiB for a lone 16384^2 frame) no longer
-    // fits the 256 MiB Infinity Cache, so placement matters to it (16384^2 level 8: encode 101 -> 98.3 us, decode 99.8 -> 97.5,
-    // profiles/r03_c4_placement.txt) -- but a probe over less than 512 MiB would measure that cache, not the regions, and at
-    // exactly 512 MiB the signal is too weak to call (separated = 0 in every run).  Such planes are allocated at 1 GiB, the
-    // size the probe was calibrated on; the caller uses their first `bytes`.
-    if (bytes >= ((size_t)128 << 20) && bytes < ((size_t)1 << 30) && count > 1 && !getenv("HGI_NO_PLACEMENT")) bytes = (size_t)1 << 30;
-    HIP_TRY(hipSetDevice(c->device));
-    std::vector<void *> bufs, spacers;     // candidate planes; allocations that only push the driver onwards
-    void *ref = nullptr;                   // one allocation whose two halves are the same-region yardstick
-    auto release = [&](std::vector<void *> &v) {
-        for (void *p : v)
-            if (p) (void)hipFree(p);
-        v.clear();
-        (void)hipGetLastError();
-    };
-    auto bail = [&](hgi_status st) {
-        release(bufs);
-        release(spacers);
-        if (ref) (void)hipFree(ref);
-        for (uint32_t i = 0; i < count; ++i) planes[i] = nullptr;
-        return st;
-    };
-    for (uint32_t i = 0; i < count; ++i) {
-        void *p = nullptr;
-        if (hipMalloc(&p, bytes) != hipSuccess) return bail(fail(HGI_ENOMEM, "hipMalloc of %zu bytes failed", bytes));
-        bufs.push_back(p);
-    }
-    auto hand_out = [&](const std::vector<int> &order) {
-        std::vector<char> used(bufs.size(), 0);
-        for (uint32_t i = 0; i < count; ++i) {
-            planes[i] = bufs[(size_t)order[i]];
-            used[(size_t)order[i]] = 1;
-        }
-        for (size_t j = 0; j < bufs.size(); ++j)
-            if (!used[j]) (void)hipFree(bufs[j]);
-        bufs.clear();
-        release(spacers);
-        if (ref) (void)hipFree(ref);
-        ref = nullptr;
-        (void)hipGetLastError();
-    };
-    std::vector<int> plain(count);
-    for (uint32_t i = 0; i < count; ++i) plain[i] = (int)i;
-    const bool probing = bytes >= kProbeMinBytes && count > 1 && !getenv("HGI_NO_PLACEMENT");
-    if (!probing) {
-        hand_out(plain);
-        return HGI_OK;
-    }
-    {
-        const hgi_status st = ws_ensure(c, ws_need(c, 4096, 4096, 4, 1, (size_t)4096 * 4096));
-        if (st != HGI_OK) return bail(st);
-    }
-    // The yardstick: what a stream costs when source and destination share a region.  A power-of-two request is served
-    // as ONE block, and a block never straddles a region, so the two halves of such an allocation are a same-region pair
-    // by construction.  (Comparisons among candidates alone cannot tell "all fast" from "all slow".)
-    const size_t span = bytes < ((size_t)2 << 30) ? bytes : ((size_t)2 << 30);     // what a probe streams
-    size_t ref_bytes = 1;
-    while (ref_bytes < 2 * span) ref_bytes <<= 1;
-    if (hipMalloc(&ref, ref_bytes) != hipSuccess) {
-        (void)hipGetLastError();
-        ref = nullptr;
-        hand_out(plain);
-        return HGI_OK;
-    }
-    uint8_t *ref_lo = static_cast<uint8_t *>(ref), *ref_hi = ref_lo + ref_bytes / 2;
-    // Every pair is timed AGAINST the yardstick, interleaved with it, after the yardstick has stopped drifting: the
-    // device's clocks fall back within milliseconds of idling (an allocation in between is enough) and ramp for ~25 ms
-    // once work resumes (profiles/r02_ramp.txt), so absolute times taken at different moments do not compare.
-    auto other_region = [&](int a, int b, bool *yes) -> hgi_status {
-        float last = 0, ms = 0;
-        HGI_TRY(probe_pair_ms(c, ref_lo, ref_hi, span, &last));
-        for (int it = 0; it < 12; ++it) {
-            HGI_TRY(probe_pair_ms(c, ref_lo, ref_hi, span, &ms));
-            const bool steady = ms <= last * 1.007f && last <= ms * 1.007f;
-            last = ms;
-            if (steady) break;
-        }
-        float same = 0, pair = 0;
-        for (int rep = 0; rep < 2; ++rep) {
-            HGI_TRY(probe_pair_ms(c, ref_lo, ref_hi, span, &ms));
-            same += ms;
-            HGI_TRY(probe_pair_ms(c, static_cast<const uint8_t *>(bufs[(size_t)a]), static_cast<uint8_t *>(bufs[(size_t)b]), span, &ms));
-            pair += ms;
-        }
-        *yes = pair < same * kFastRatio;
-        return HGI_OK;
-    };
-    // Candidates are sorted into groups that share a region (a candidate joins the first group whose representative it
-    // does NOT stream fast against).  `count` planes whose neighbours differ exist as soon as no group has to supply
-    // more than every other plane.  Until then: one more candidate, behind a spacer.  The driver serves requests
-    // buddy-style from blocks of up to 64 GiB, the smallest free piece that fits first, so candidates of one size tend to
-    // come from one block until it is used up (profiles/r02_modes4.txt: runs of 16); spacers of `bytes`, 2 x, 4 x ...
-    // take that block's free buddies.  Large allocations take the driver seconds (it clears them), hence the caps.
-    std::vector<std::vector<int>> groups;
-    size_t classified = 0;
-    int spacer_shift = 0;
-    std::vector<int> order;
-    for (;;) {
-        for (; classified < bufs.size(); ++classified) {
-            bool placed = false;
-            for (auto &g : groups) {
-                bool other = false;
-                const hgi_status st = other_region(g[0], (int)classified, &other);
-                if (st != HGI_OK) return bail(st);
-                if (!other) {
-                    g.push_back((int)classified);
-                    placed = true;
-                    break;
-                }
-            }
-            if (!placed) groups.push_back(std::vector<int>{(int)classified});
-        }
-        // greedy arrangement: always take from the largest remaining group that is not the one just used
-        std::vector<size_t> left(groups.size());
-        for (size_t g = 0; g < groups.size(); ++g) left[g] = groups[g].size();
-        order.clear();
-        int prev = -1;
-        while (order.size() < count) {
-            int pick = -1;
-            for (size_t g = 0; g < groups.size(); ++g)
-                if ((int)g != prev && left[g] > 0 && (pick < 0 || left[g] > left[(size_t)pick])) pick = (int)g;
-            if (pick < 0) break;
-            order.push_back(groups[(size_t)pick][groups[(size_t)pick].size() - left[(size_t)pick]]);
-            --left[(size_t)pick];
-            prev = pick;
-        }
-        if (order.size() == count) break;                                   // neighbours all in different regions
-        if (bufs.size() >= (size_t)count + kMaxCandidates) break;           // give up
-        size_t free_b = 0, total_b = 0;
-        const size_t want = bytes << (spacer_shift < 5 ? spacer_shift : 5);      // 1, 2, 4, 8, 16, then 32 x bytes each time
-        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && want <= free_b / 3) {
-            void *fill = nullptr;
-            if (hipMalloc(&fill, want) == hipSuccess) spacers.push_back(fill);
-            (void)hipGetLastError();
-            ++spacer_shift;
-        }
-        void *cand = nullptr;
-        if (hipMalloc(&cand, bytes) != hipSuccess) {
-            (void)hipGetLastError();
-            break;
-        }
-        bufs.push_back(cand);
-    }
-    const bool ok = order.size() == count;
-    if (!ok) {      // could not be established: still alternate between the two largest groups as far as they go
-        std::vector<char> used(bufs.size(), 0);
-        for (int j : order) used[(size_t)j] = 1;
-        for (size_t j = 0; j < bufs.size() && order.size() < count; ++j)
-            if (!used[j]) order.push_back((int)j);
-    }
-    hand_out(order);
-    if (separated) *separated = ok ? 1 : 0;
-    return HGI_OK;
-}
-
-hgi_status hgi_planes_free(hgi_ctx *c, uint32_t count, void **planes)
-{
-    if (!c || (!planes && count)) return fail(HGI_EINVAL, "NULL argument");
-    HIP_TRY(hipSetDevice(c->device));
-    for (uint32_t i = 0; i < count; ++i) {
-        if (planes[i]) HIP_TRY(hipFree(planes[i]));
-        planes[i] = nullptr;
-    }
-    return HGI_OK;
-}
 
 hgi_status hgi_timer_start(hgi_ctx *c)
 {

@@ -22,6 +22,7 @@
 #include <vector>
 
 #include "hgi_kernels.h"
+#include "hgi_knobs.h"
 
 namespace hgi {
 
@@ -581,7 +582,8 @@ u32 resident_workgroups(K kernel)
         (void)hipGetLastError();
         return 4u * 256u;
     }
-    if (const char *e = getenv("HGI_ENTROPY_WGS_PER_CU")) per_cu = atoi(e) > 0 ? atoi(e) : per_cu;      // experiments
+    const int forced = HGI_KNOB(HGI_ENTROPY_WGS_PER_CU, 0);      // (knobs build: experiments)
+    if (forced > 0) per_cu = forced;
     return (u32)per_cu * (u32)prop.multiProcessorCount;
 }
 

@@ -30,6 +30,7 @@
 // All arithmetic is u8/integer; there is no MFMA-shaped work on this path.
 #include "hgi_dev.h"
 #include "hgi_fastdiv.h"
+#include "hgi_knobs.h"
 
 namespace hgi {
 namespace {
@@ -43,18 +44,7 @@ using namespace dev;
 #define HGI_CAT2(a, b) a##_##b
 #define HGI_CAT(a, b) HGI_CAT2(a, b)
 #define HGI_TILED(name) HGI_CAT(name, HGI_TILE_H)   // launch_decode_fused -> launch_decode_fused_64
-// Experiment build -DHGI_PAIR=1 (never shipped; tools/ab.py): a workgroup is TWO waves owning two x-adjacent
-// tiles.  The left wave takes its halo column from the right wave's LDS slice (one s_barrier after staging) instead of
-// loading it from memory, so the right tile's even-row lines are read by nobody else and can be loaded `nt`.
-#ifndef HGI_PAIR
-#define HGI_PAIR 0
-#endif
-#if HGI_PAIR
-#define HGI_LANE ((int)(threadIdx.x & 63u))
-#else
-#define HGI_LANE ((int)threadIdx.x)
-#endif
-constexpr int NWAVES = HGI_PAIR ? 2 : 1;
+#define HGI_LANE ((int)threadIdx.x)   // the workgroup is one wave
 constexpr int TW = kTileW;
 constexpr int TH = HGI_TILE_H;
 constexpr int MAXK = TH == 64 ? kFusedMaxLevels : TH == 32 ? kFusedMaxLevelsSmall : kFusedMaxLevelsTiny;   // deepest pyramid one tile holds
@@ -112,10 +102,6 @@ static_assert(TH != 64 || 18 * (buf_bytes(4) + rbuf_bytes(4) + 256) <= 160 * 102
 #ifndef HGI_STORE_AUX
 #define HGI_STORE_AUX 2   // cache policy of the output stores: nt (streamed once; measured 2-3 % faster than default)
 #endif
-#ifndef HGI_ABL
-#define HGI_ABL 0   // timing experiments: 1 no coarse levels, 2 no fine arithmetic, 4 no halo cells, 8 no sub==2 level,
-                    // 16 no halo-column loads, 32 no halo-row loads
-#endif
 #ifndef HGI_ODD_LATE
 #define HGI_ODD_LATE 1      // interior tiles request their odd rows after the even rows are committed (stage_issue_odd); 0: with them
 #endif
@@ -125,8 +111,14 @@ static_assert(TH != 64 || 18 * (buf_bytes(4) + rbuf_bytes(4) + 256) <= 160 * 102
 #ifndef HGI_DEC_SHALLOW_WAVES
 #define HGI_DEC_SHALLOW_WAVES 20  // resident tiles per CU asked for on decodes 1-8 rounds deep (launch_decode_fused)
 #endif
+#ifndef HGI_DEC_DEEP_WAVES
+#define HGI_DEC_DEEP_WAVES 16     // ... and on deeper ones
+#endif
 #ifndef HGI_XCD_MODE
-#define HGI_XCD_MODE 1      // default of the XCD dealing policy (block_role); HGI_XCD_MODE in the environment overrides it
+#define HGI_XCD_MODE -1     // the XCD dealing policy (block_role): 0 contiguous eighths, 1 whole bands round-robin, -1 by size (xcd_mode())
+#endif
+#ifndef HGI_XCD_EIGHTHS_FROM_GIB
+#define HGI_XCD_EIGHTHS_FROM_GIB 6   // launches whose interior tiles span at least this many GiB deal contiguous eighths
 #endif
 #ifndef HGI_DEC_REVERSE_DEFAULT
 #define HGI_DEC_REVERSE_DEFAULT 0
@@ -802,11 +794,8 @@ struct Stage {
 // RAGGED tiles that finish in the generic fine level fetch their odd rows there; bottom-ragged tiles
 // (ODD_CHECKED) keep the fast fine level and load them here, row offsets in voffset like the even rows.
 template <bool RAGGED, bool ODD_CHECKED = false>
-__device__ __forceinline__ void stage_issue(Stage &st, const Buf &b, Tile tl, int k, int nh, u32 wv = 0)
+__device__ __forceinline__ void stage_issue(Stage &st, const Buf &b, Tile tl, int k, int nh)
 {
-    // pair build, interior tiles: the right wave's lines have no other reader (nt); the left wave's halo column comes from
-    // the right wave's LDS slice, not from memory
-    const bool right_nt = HGI_PAIR && !RAGGED && wv == 1, skip_col = HGI_PAIR && !RAGGED && wv == 0;
     const int lane = HGI_LANE, c = lane & (CH - 1), r = lane >> LCH;
     const u32 W = __builtin_amdgcn_readfirstlane(b.W);   // soffset operands must be provably uniform
     const u32 voff = b.base + 2 * r * W + 16 * c;                       // even rows 2 * (r + 8 j)
@@ -828,8 +817,6 @@ __device__ __forceinline__ void stage_issue(Stage &st, const Buf &b, Tile tl, in
         if (RAGGED) {
             if (cin) st.e[j] = __builtin_amdgcn_raw_buffer_load_b128(b.rs, voff + j * 16 * W, 0, 0);
             if (narrow) st.e[j] &= cm;
-        } else if (right_nt) {
-            st.e[j] = __builtin_amdgcn_raw_buffer_load_b128(b.rs, voff, j * 16 * W, 2);
         } else {
             st.e[j] = __builtin_amdgcn_raw_buffer_load_b128(b.rs, voff, j * 16 * W, HGI_LOAD_AUX);
         }
@@ -844,7 +831,7 @@ __device__ __forceinline__ void stage_issue(Stage &st, const Buf &b, Tile tl, in
     };
     auto issue_halo = [&]() __attribute__((always_inline)) {
     st.hv = v4u{0, 0, 0, 0};
-    if (!(HGI_ABL & 32) && lane < nh * CH && cin) st.hv = __builtin_amdgcn_raw_buffer_load_b128(b.rs, b.base + (TH + hoff(r)) * W + 16 * c, 0, 0);
+    if (lane < nh * CH && cin) st.hv = __builtin_amdgcn_raw_buffer_load_b128(b.rs, b.base + (TH + hoff(r)) * W + 16 * c, 0, 0);
     if (narrow) st.hv &= cm;
     const int hy = lane < TH / 2 ? 2 * lane : TH + hoff(lane - TH / 2);
     const u32 xo = b.base + hy * W + TW;
@@ -852,7 +839,7 @@ __device__ __forceinline__ void stage_issue(Stage &st, const Buf &b, Tile tl, in
     st.x0 = v3u{0, 0, 0};
     st.d16 = st.d32 = st.d64 = 0;
     st.zero4 = st.zero8 = false;
-    if (!(HGI_ABL & 16) && !skip_col && lane < TH / 2 + nh) {
+    if (lane < TH / 2 + nh) {
         if (xr < W) st.x0 = __builtin_amdgcn_raw_buffer_load_b96(b.rs, xo, 0, 0);
         // offsets 4 / 8 can lie beyond the image when the width is not a multiple of 16: cleared when the column is
         // committed (stage_commit), not here -- touching the loaded registers now would wait for every load issued so far
@@ -904,7 +891,7 @@ __device__ __forceinline__ v2u even_bytes(v4u a)
 // same registers.  Points of finer lattices hold originals until their level codes them; nothing reads
 // them earlier.
 template <bool LATTICE>
-__device__ __forceinline__ void stage_commit(u8 *buf, u8 *rbuf, const Stage &st, int nh, bool skip_col = false)
+__device__ __forceinline__ void stage_commit(u8 *buf, u8 *rbuf, const Stage &st, int nh)
 {
     const int lane = HGI_LANE, c = lane & (CH - 1), r = lane >> LCH;
 #pragma unroll
@@ -916,7 +903,7 @@ __device__ __forceinline__ void stage_commit(u8 *buf, u8 *rbuf, const Stage &st,
         *reinterpret_cast<v4u *>(buf + (TH / 2 + r) * S + 16 * c) = st.hv;
         if (LATTICE) *reinterpret_cast<v2u *>(rbuf + (TH / 2 + r) * S2 + 8 * c) = even_bytes(st.hv);
     }
-    if (!skip_col && lane < TH / 2 + nh) {
+    if (lane < TH / 2 + nh) {
         // transposed halo columns: slot {0..5} <- offsets {0, 4, 8, 16, 32, 64}, one byte per LDS row
         const u32 v[HR] = {st.x0.x, st.zero4 ? 0u : st.x0.y, st.zero8 ? 0u : st.x0.z, st.d16, st.d32, st.d64};
         u8 *h = buf + HCOL + lane, *h2 = rbuf + RCOL + lane;
@@ -924,26 +911,6 @@ __device__ __forceinline__ void stage_commit(u8 *buf, u8 *rbuf, const Stage &st,
         for (int i = 0; i < HR; ++i) {
             h[i * HP] = (u8)v[i];
             if (LATTICE) h2[i * HP2] = (u8)v[i];
-        }
-    }
-}
-
-// pair build: the right wave hands the left wave its halo column -- bytes 0 / 4 / 8 / 16 / 32 / 64 of each of its staged
-// rows (halo rows included) -- by writing them into the left wave's transposed column slots; one workgroup barrier
-// follows.  Nothing of the right tile has been coded yet: these are the staged values, what the left wave would have
-// loaded from memory.
-template <bool LATTICE>
-__device__ __forceinline__ void pair_push_column(const u8 *mine, u8 *left_buf, u8 *left_rbuf, int nh)
-{
-    const int lane = HGI_LANE;
-    if (lane < TH / 2 + nh) {
-        const u8 *row = mine + lane * S;
-        const u32 lo = *reinterpret_cast<const u32 *>(row), m4 = *reinterpret_cast<const u32 *>(row + 4), m8 = *reinterpret_cast<const u32 *>(row + 8);
-        const u32 v[HR] = {lo, m4, m8, row[16], row[32], row[64]};
-#pragma unroll
-        for (int i = 0; i < HR; ++i) {
-            left_buf[HCOL + i * HP + lane] = (u8)v[i];
-            if (LATTICE) left_rbuf[RCOL + i * HP2 + lane] = (u8)v[i];
         }
     }
 }
@@ -1194,9 +1161,7 @@ __device__ __forceinline__ void enc_fine_fast(const u8 *buf, const u8 *rbuf, con
             u32 P0, P1;
             pred8<INTERP>(c, c8, fl, f8, P0, P1);
             u32 e0 = E.x, e1 = E.y, e2 = E.z, e3 = E.w, g0 = O.x, g1 = O.y, g2 = O.z, g3 = O.w;
-            if (HGI_ABL & 2) {
-                e0 ^= P0; g0 ^= P1;
-            } else if (IDENT) {
+            if (IDENT) {
                 const u32 odd = 0xFF00FF00u;
                 const u32 pp0 = __builtin_amdgcn_perm(P0, P0, 0x01010000u), pp1 = __builtin_amdgcn_perm(P0, P0, 0x03030202u);
                 const u32 pp2 = __builtin_amdgcn_perm(P1, P1, 0x01010000u), pp3 = __builtin_amdgcn_perm(P1, P1, 0x03030202u);
@@ -1267,7 +1232,7 @@ struct TileGrid {
     u32 band;               // tile rows per band of the column-major walk (fast_tile)
     u32 xmode;              // how the band-ordered tile list is dealt to the XCDs (block_role)
     // derived by finish_grid() on the host, so that the kernels neither divide nor re-derive launch constants:
-    u32 ex, nf;             // interior tile columns / interior tiles the walk runs on (pair build: pairs)
+    u32 ex, nf;             // interior tile columns / interior tiles the walk runs on
     u32 tpf, P, nfull, rem_rows;   // tiles per frame; per band; in a frame's whole bands; rows of its last, shorter band
     u32 rr_own, rr_tail0;   // round-robin dealing: blocks per XCD that belong to whole rounds of eight bands; first tile behind them
     FastDiv fd_tpf, fd_P, fd_band, fd_rem, fd_ex;
@@ -1276,10 +1241,8 @@ struct TileGrid {
 #endif
 };
 
-__device__ __forceinline__ Tile fast_tile(u32 t, const TileGrid &g, u32 wv = 0)
+__device__ __forceinline__ Tile fast_tile(u32 t, const TileGrid &g)
 {
-    // (pair build: t counts PAIRS of x-adjacent tiles; the walk runs on a grid half as wide -- g.ex, g.nf -- and wave `wv`
-    // takes the left (0) or right (1) tile of the pair)
     t = __builtin_amdgcn_readfirstlane(g.reverse ? g.nf - 1u - t : t);
     Tile tl;
     tl.frame = fdiv(t, g.fd_tpf);
@@ -1308,7 +1271,7 @@ __device__ __forceinline__ Tile fast_tile(u32 t, const TileGrid &g, u32 wv = 0)
         ty = row0 + (r - tx * rows);
     }
 #endif
-    tl.X0 = (HGI_PAIR ? 2 * tx + wv : tx) * TW;
+    tl.X0 = tx * TW;
     tl.Y0 = ty * TH;
     return tl;
 }
@@ -1358,10 +1321,10 @@ __device__ __forceinline__ void args_early(const u8 *src, const u8 *dst, const F
 #endif
 }
 
-__device__ __forceinline__ TileCtx fast_ctx(u32 t, const u8 *src, u8 *dst, const Frames &f, const TileGrid &g, u32 tail, u32 wv = 0)
+__device__ __forceinline__ TileCtx fast_ctx(u32 t, const u8 *src, u8 *dst, const Frames &f, const TileGrid &g, u32 tail)
 {
     TileCtx c;
-    c.tl = fast_tile(t, g, wv);
+    c.tl = fast_tile(t, g);
     c.b = make_buf(src + (size_t)c.tl.frame * f.frame_stride, dst + (size_t)c.tl.frame * f.frame_stride, f.width,
                    f.height, c.tl, tail);
     return c;
@@ -1568,11 +1531,11 @@ __device__ __forceinline__ void dec_tile_fast(u8 *buf, const TileCtx &cur, const
 {
     // straight-line chain, the level a compile-time constant in each link (see enc_tile_fast)
 #define HGI_DEC_COARSE(SUB)                                                                    \
-    if (k > HGI_LOG2(SUB) && !(HGI_ABL & 1)) {                                                 \
+    if (k > HGI_LOG2(SUB)) {                                                                   \
         HGI_MARK("coarse");                                                                    \
         dec_cells<INTERP, false>(buf, SUB, cur.tl, W, H);                                      \
         HGI_MARK("halo");                                                                      \
-        if (!(HGI_ABL & 4)) dec_halo_cells<INTERP>(buf, SUB, cur.tl, W, H);                    \
+        dec_halo_cells<INTERP>(buf, SUB, cur.tl, W, H);                                        \
         LDS_ORDER();                                                                           \
     }
     if (MAXK >= 6) HGI_DEC_COARSE(32)
@@ -1580,11 +1543,11 @@ __device__ __forceinline__ void dec_tile_fast(u8 *buf, const TileCtx &cur, const
     HGI_DEC_COARSE(8)
     HGI_DEC_COARSE(4)
 #undef HGI_DEC_COARSE
-    if (k >= 2 && !(HGI_ABL & 1)) {
+    if (k >= 2) {
         HGI_MARK("level2");
-        if (!(HGI_ABL & 8)) dec_level2_fast<INTERP>(buf);
+        dec_level2_fast<INTERP>(buf);
         HGI_MARK("halo");
-        if (!(HGI_ABL & 4)) dec_halo_cells<INTERP>(buf, 2, cur.tl, W, H);
+        dec_halo_cells<INTERP>(buf, 2, cur.tl, W, H);
         LDS_ORDER();
     }
     HGI_MARK("fine");
@@ -1669,7 +1632,7 @@ __device__ __forceinline__ BlockRole block_role(const TileGrid &g)
 // per CU: the cone's lane state is live while the staging loads fly, and the decoder's rate does not depend on occupancy
 // down to 16 tiles per CU, profiles/r03_waves_sweep.txt.)
 template <int INTERP, int SEEDED, int TILE_ROWS>   // TILE_ROWS == TH: only there to name the build in profiles
-__global__ __launch_bounds__(NL * NWAVES) __attribute__((amdgpu_waves_per_eu(SEEDED == 2 ? HGI_DEC_WAVES_PER_EU - 2 : HGI_DEC_WAVES_PER_EU))) void k_dec_tiles(const u8 *__restrict__ src, u8 *__restrict__ dst, Frames f, u32 k,
+__global__ __launch_bounds__(NL) __attribute__((amdgpu_waves_per_eu(SEEDED == 2 ? HGI_DEC_WAVES_PER_EU - 2 : HGI_DEC_WAVES_PER_EU))) void k_dec_tiles(const u8 *__restrict__ src, u8 *__restrict__ dst, Frames f, u32 k,
                                                   Seeds sd, TileGrid g, u32 aligned)
 {
     HGI_TL_ENTRY();
@@ -1679,8 +1642,7 @@ __global__ __launch_bounds__(NL * NWAVES) __attribute__((amdgpu_waves_per_eu(SEE
     k = HGI_ANALYZE_K;
 #endif
     const int nh = k >= 2 ? (int)k : 1;
-    const u32 wv = HGI_PAIR ? __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) : 0u;      // which tile of the pair
-    u8 *buf = smem + wv * buf_bytes(nh) - HCOL;
+    u8 *buf = smem - HCOL;
     const u32 W = f.width, H = f.height;
 #ifdef HGI_ANALYZE_K
     BlockRole role = block_role(g);
@@ -1688,9 +1650,9 @@ __global__ __launch_bounds__(NL * NWAVES) __attribute__((amdgpu_waves_per_eu(SEE
 #else
     const BlockRole role = block_role(g);
 #endif
-    if (role.idle || (HGI_PAIR && role.edge && wv)) return;
+    if (role.idle) return;
     if (!role.edge) {
-        TileCtx cur = fast_ctx(role.index, src, dst, f, g, (aligned & 4u) ? 3u : 0u, wv);
+        TileCtx cur = fast_ctx(role.index, src, dst, f, g, (aligned & 4u) ? 3u : 0u);
         Stage st;
         SeedRegs seeds;
         HGI_MARK("stage_issue");
@@ -1699,22 +1661,18 @@ __global__ __launch_bounds__(NL * NWAVES) __attribute__((amdgpu_waves_per_eu(SEE
 #if HGI_DEC_CONE_FIRST
         if (SEEDED == 2) cone = cone_issue<false>(src + (size_t)cur.tl.frame * f.frame_stride, W, H, sd, cur.tl);
 #endif
-        stage_issue<false>(st, cur.b, cur.tl, (int)k, nh, wv);
+        stage_issue<false>(st, cur.b, cur.tl, (int)k, nh);
         if (SEEDED == 1) seeds = seed_issue<false>(sd, cur.tl, k);
 #if !HGI_DEC_CONE_FIRST
         if (SEEDED == 2) cone = cone_issue<false>(src + (size_t)cur.tl.frame * f.frame_stride, W, H, sd, cur.tl);
 #endif
         HGI_MARK("stage_commit");
-        stage_commit<false>(buf, nullptr, st, nh, HGI_PAIR && wv == 0);
+        stage_commit<false>(buf, nullptr, st, nh);
         LDS_ORDER();
         HGI_TL_STAGED();      // (timeline build: waits for everything requested so far -- in front of the odd rows' request)
         if (HGI_ODD_LATE) stage_issue_odd(st, cur.b);
         if (SEEDED == 2) seeds = cone_finish<INTERP, false, true>(cone, buf, nullptr, sd.up, nullptr);
         LDS_ORDER();
-        if (HGI_PAIR) {
-            if (wv) pair_push_column<false>(buf, smem - HCOL, nullptr, nh);
-            __syncthreads();
-        }
         if (SEEDED) dec_seed_commit(buf, seeds, k);
         dec_tile_fast<INTERP>(buf, cur, st.o, k, W, H);
         HGI_MARK("end");
@@ -1800,7 +1758,7 @@ __device__ __forceinline__ void enc_tile_fast(u8 *buf, u8 *rbuf, const u8 *slut,
     // is entered): every LDS address of a level is then `lane-dependent base + immediate`, instead of shifts by a
     // run-time log2(step) -- the address arithmetic was a third of the kernel's VALU instructions.
 #define HGI_ENC_COARSE(SUB)                                                                    \
-    if (k > HGI_LOG2(SUB) && !(HGI_ABL & 1)) {                                                 \
+    if (k > HGI_LOG2(SUB)) {                                                                   \
         HGI_MARK("coarse");                                                                    \
         enc_level_coarse_fast<INTERP, IDENT>(buf, rbuf, slut, SUB, cur.tl, W, H);              \
         LDS_ORDER();                                                                           \
@@ -1810,7 +1768,7 @@ __device__ __forceinline__ void enc_tile_fast(u8 *buf, u8 *rbuf, const u8 *slut,
     HGI_ENC_COARSE(8)
     HGI_ENC_COARSE(4)
 #undef HGI_ENC_COARSE
-    if (k >= 2 && !(HGI_ABL & 1)) {
+    if (k >= 2) {
         HGI_MARK("level2");
         enc_level2_fast<INTERP, IDENT>(buf, rbuf, slut, cur.tl, W, H);
         LDS_ORDER();
@@ -1826,7 +1784,7 @@ __device__ __forceinline__ void enc_tile_fast(u8 *buf, u8 *rbuf, const u8 *slut,
 #endif
 // SEEDED: as in k_dec_tiles
 template <int INTERP, bool IDENT, int SEEDED, int TILE_ROWS>
-__global__ __launch_bounds__(NL * NWAVES) __attribute__((amdgpu_waves_per_eu(IDENT ? HGI_ENC_WAVES_PER_EU - 1 : HGI_ENC_WAVES_PER_EU))) void k_enc_tiles(const u8 *__restrict__ src, u8 *__restrict__ dst, Frames f, u32 k,
+__global__ __launch_bounds__(NL) __attribute__((amdgpu_waves_per_eu(IDENT ? HGI_ENC_WAVES_PER_EU - 1 : HGI_ENC_WAVES_PER_EU))) void k_enc_tiles(const u8 *__restrict__ src, u8 *__restrict__ dst, Frames f, u32 k,
                                                   Lut256 lut, Seeds sd, TileGrid g, u32 aligned)
 {
     HGI_TL_ENTRY();
@@ -1840,11 +1798,9 @@ __global__ __launch_bounds__(NL * NWAVES) __attribute__((amdgpu_waves_per_eu(IDE
     // planes behind it have a size that depends on k).  Dynamic LDS starts at 0 because the kernel has no static LDS:
     // launch_encode_fused verifies that on the host (hipFuncGetAttributes) before the first launch of each
     // instantiation and refuses to launch otherwise -- nothing on the device can abort.
-    const u32 wv = HGI_PAIR ? __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) : 0u;      // which tile of the pair
-    const u32 slice = buf_bytes(nh) + ((rbuf_bytes(nh) + 15) & ~15);                       // one wave's planes
     u8 *slut = smem;
-    u8 *buf = smem + 256 + wv * slice - HCOL;
-    u8 *rbuf = smem + 256 + wv * slice + buf_bytes(nh) - RCOL;
+    u8 *buf = smem + 256 - HCOL;
+    u8 *rbuf = smem + 256 + buf_bytes(nh) - RCOL;
     const u32 W = f.width, H = f.height;
 #ifdef HGI_ANALYZE_K
     BlockRole role = block_role(g);
@@ -1852,34 +1808,30 @@ __global__ __launch_bounds__(NL * NWAVES) __attribute__((amdgpu_waves_per_eu(IDE
 #else
     const BlockRole role = block_role(g);
 #endif
-    if (role.idle || (HGI_PAIR && role.edge && wv)) return;
+    if (role.idle) return;
     // The table entry of this lane is a VECTOR load from the kernel-argument segment (the index is the lane): a trip to L2
     // or beyond.  Done first, the whole prologue stalled on it (the timeline build showed 1.4-1.8 us of prologue per
     // encode tile against 0.5-0.7 for decode: tools/timeline.py).  It is issued BEHIND the tile's staging loads instead
     // and lands with them -- the table is first needed after staging has been committed to LDS anyway.
     u32 lutv = 0;
     if (!role.edge) {
-        TileCtx cur = fast_ctx(role.index, src, dst, f, g, (aligned & 4u) ? 3u : 0u, wv);
+        TileCtx cur = fast_ctx(role.index, src, dst, f, g, (aligned & 4u) ? 3u : 0u);
         Stage st;
         SeedRegs seeds;
         ConeLane cone;
         HGI_MARK("stage_issue");
         HGI_TL_START();
-        stage_issue<false>(st, cur.b, cur.tl, (int)k, nh, wv);
+        stage_issue<false>(st, cur.b, cur.tl, (int)k, nh);
         if (SEEDED == 1) seeds = seed_issue<true>(sd, cur.tl, k);
         if (SEEDED == 2) cone = cone_issue<true>(src + (size_t)cur.tl.frame * f.frame_stride, W, H, sd, cur.tl);
-        if (!IDENT) lutv = lut.w[HGI_LANE];      // (pair build: both waves write the same table)
+        if (!IDENT) lutv = lut.w[HGI_LANE];
         HGI_MARK("stage_commit");
-        stage_commit<true>(buf, rbuf, st, nh, HGI_PAIR && wv == 0);
+        stage_commit<true>(buf, rbuf, st, nh);
         if (!IDENT) reinterpret_cast<u32 *>(slut)[HGI_LANE] = lutv;
         LDS_ORDER();
         HGI_TL_STAGED();
         if (HGI_ODD_LATE) stage_issue_odd(st, cur.b);
         if (SEEDED == 2) seeds = cone_finish<INTERP, true, IDENT>(cone, buf, rbuf, sd.up, slut);
-        if (HGI_PAIR) {
-            if (wv) pair_push_column<true>(buf, smem + 256 - HCOL, smem + 256 + buf_bytes(nh) - RCOL, nh);
-            __syncthreads();
-        }
         enc_seed_commit<SEEDED>(buf, rbuf, seeds, k);
         enc_tile_fast<INTERP, IDENT>(buf, rbuf, slut, cur, st.o, k, W, H);
         HGI_MARK("end");
@@ -1951,7 +1903,7 @@ FusedGeom fused_geom(const void *a, const void *b, const Frames &f, u32 row_limi
     // Otherwise the read descriptors get 3 extra records -- if the caller's memory allows it: the over-read of every
     // frame but the last lands in the next frame (or the stride padding), that of the last frame must stay in the
     // 4-KiB page that holds the frame's last byte.
-    static const bool force_checked = getenv("HGI_FORCE_CHECKED") != nullptr;   // tests: run every tile through the checked path
+    const bool force_checked = HGI_SWITCH(HGI_FORCE_CHECKED);   // knobs build (tests): every tile through the byte-checked path
     const uintptr_t end = reinterpret_cast<uintptr_t>(a) + (uintptr_t)(f.batch - 1) * f.frame_stride + (uintptr_t)f.width * f.height;
     const bool dword_rows = f.width % 4 == 0;
     const bool tail_ok = ((end - 1) >> 12) == ((end + 2) >> 12) && (f.batch == 1 || f.frame_stride >= (u64)f.width * f.height);
@@ -1983,11 +1935,11 @@ FusedGeom fused_geom(const void *a, const void *b, const Frames &f, u32 row_limi
 // eight and 366.0 / 353.9 at two); on a 16384-wide frame the encoder still wants four (102 us; two: 109) and the decoder
 // two (98 us; four: 104) -- and with round 2's eight-row decoder bands and contiguous eighths that decode took 135 us,
 // which round 2 mistook for a read-after-write penalty.  Hence: four rows, capped at 4 MiB (encode) / 2 MiB (decode) of
-// address space.  HGI_ENC_BAND / HGI_DEC_BAND in the environment force a height (experiments).
+// address space.  (Knobs build: HGI_ENC_BAND / HGI_DEC_BAND force a height -- tools/band_sweep.sh.)
 inline u32 band_rows(const Frames &f, bool encode)
 {
-    static const int forced[2] = {getenv("HGI_DEC_BAND") ? atoi(getenv("HGI_DEC_BAND")) : 0, getenv("HGI_ENC_BAND") ? atoi(getenv("HGI_ENC_BAND")) : 0};
-    if (forced[encode ? 1 : 0] > 0) return (u32)forced[encode ? 1 : 0];
+    const int forced = encode ? HGI_KNOB(HGI_ENC_BAND, 0) : HGI_KNOB(HGI_DEC_BAND, 0);
+    if (forced > 0) return (u32)forced;
     const u64 cap = encode ? (4u << 20) : (2u << 20);
     u32 rows = HGI_TILE_BAND;
     while (rows > 1 && (u64)rows * TH * f.width > cap) rows >>= 1;
@@ -1997,8 +1949,8 @@ inline u32 band_rows(const Frames &f, bool encode)
 // Everything the kernels would otherwise derive per block from the launch's constants (and the divisions by them).
 inline void finish_grid(TileGrid &g)
 {
-    g.ex = HGI_PAIR ? g.full_x >> 1 : g.full_x;
-    g.nf = HGI_PAIR ? g.nfast >> 1 : g.nfast;
+    g.ex = g.full_x;
+    g.nf = g.nfast;
     if (g.band < 1) g.band = 1;
     g.tpf = g.ex * g.full_y;
     g.P = g.band * g.ex;
@@ -2010,7 +1962,7 @@ inline void finish_grid(TileGrid &g)
     g.fd_rem = make_fastdiv(g.rem_rows);
     g.fd_ex = make_fastdiv(g.ex);
     g.rr_own = g.rr_tail0 = 0;
-    if (g.xmode != 1 || HGI_PAIR || g.rem_rows != 0 || g.P == 0 || g.nf == 0) {
+    if (g.xmode != 1 || g.rem_rows != 0 || g.P == 0 || g.nf == 0) {
         g.xmode = 0;
     } else {
         const u32 nb8 = (g.nf / g.P) & ~7u;          // bands in whole rounds of eight
@@ -2021,7 +1973,7 @@ inline void finish_grid(TileGrid &g)
 
 // Dynamic LDS of a launch padded so that at most `waves` blocks fit a CU (160 KiB of LDS): a launch only a few rounds of
 // resident tiles deep pays a tile LIFETIME for filling and draining the chip, and the lifetime is resident tiles / rate
-// (Little) -- fewer resident tiles at the same rate shorten it.  Experiments: HGI_DEC_WAVES / HGI_ENC_WAVES.
+// (Little) -- fewer resident tiles at the same rate shorten it.  (Knobs build: HGI_DEC_WAVES / HGI_ENC_WAVES, tools/waves_sweep.sh.)
 inline size_t lds_for_waves(size_t lds, int waves)
 {
     if (waves <= 0) return lds;
@@ -2029,10 +1981,18 @@ inline size_t lds_for_waves(size_t lds, int waves)
     return cap > lds ? cap : lds;
 }
 
-inline u32 xcd_mode()
+// How the band-ordered tile list is dealt to the eight XCDs (block_role).  Whole bands round-robin -- the chip works on eight
+// CONSECUTIVE bands -- is what a launch up to a few GiB wants: contiguous eighths put the XCDs' eight working points a
+// power-of-two distance of 32 ... 256 MiB apart, and those streams beat against each other in the memory system (16384^2:
+// +10 %; 64 and 128 x 4096^2: +2.5 ... +6 %; profiles/r03_ab_xcd.txt, r04_c3_xcd_sweep.txt).  Once the eighths are 768 MiB and
+// more apart that is over and eight separate fronts are FASTER than one: 384 ... 768 x 4096^2 encode -5 ... -6 %, decode
+// 0 ... -6 %; equal at 256 and at 1024 frames (profiles/r04_c3_xcd_sweep.txt, r04_c3_dec_sweep.txt).  Hence by size: contiguous
+// eighths from 6 GiB of interior tiles per plane.  (Knobs build: HGI_XCD_MODE = 0 | 1 forces one.)
+inline u32 xcd_mode(const TileGrid &g)
 {
-    static const int forced = getenv("HGI_XCD_MODE") ? atoi(getenv("HGI_XCD_MODE")) : -1;      // experiments
-    return forced >= 0 ? (u32)forced : (u32)HGI_XCD_MODE;
+    const int forced = HGI_KNOB(HGI_XCD_MODE, HGI_XCD_MODE);
+    if (forced >= 0) return (u32)forced;
+    return (u64)g.nfast * TW * TH >= ((u64)HGI_XCD_EIGHTHS_FROM_GIB << 30) ? 0u : 1u;
 }
 
 }  // namespace
@@ -2043,43 +2003,43 @@ hipError_t HGI_TILED(launch_decode_fused)(const uint8_t *grid, uint8_t *img, con
 {
     FusedGeom r = fused_geom(grid, img, f, row_limit);
     if (!r.ok || k < 1 || k > (u32)MAXK) return hipErrorInvalidValue;
-    // The decoder walks the tile list BACKWARDS: in an encode -> decode chain the grid bytes the encoder wrote last are
-    // the ones still in the 256 MiB Infinity Cache, so reading them first takes them from there instead of evicting them
-    // unread (measured on 16384^2 and on the 64 x 4096^2 shard: tools/ab_reverse.py).  Order never changes
-    // the bytes.  HGI_DEC_REVERSE=0|1 in the environment forces it (experiments).
-    static const int dec_reverse = [] {
-        const char *e = getenv("HGI_DEC_REVERSE");
-        return e ? atoi(e) : HGI_DEC_REVERSE_DEFAULT;
-    }();
-    r.g.reverse = dec_reverse ? 1u : 0u;
+    // The decoder walks the tile list FORWARDS, like the encoder.  Walking it backwards -- so that in an encode -> decode chain
+    // the grid bytes the encoder wrote last, the ones still in the 256 MiB Infinity Cache, are read first -- was built and
+    // measured on 16384^2 and on the 64 x 4096^2 shard: no difference (92.5-92.8 us either way, profiles/r03_ab_reverse.txt,
+    // DESIGN.md 6.1), so it is not shipped; g.reverse stays for the knobs build (HGI_DEC_REVERSE=1).  Order never changes the bytes.
+    r.g.reverse = HGI_KNOB(HGI_DEC_REVERSE, HGI_DEC_REVERSE_DEFAULT) ? 1u : 0u;
     r.g.band = band_rows(f, false);
-    r.g.xmode = xcd_mode();
+    r.g.xmode = xcd_mode(r.g);
     finish_grid(r.g);
     const TileGrid &g = r.g;
     if (seeds && k < (uint32_t)kSeededMinLevels) return hipErrorInvalidValue;      // one lane per lattice point (seed_issue)
     Seeds sd = seeds ? *seeds : Seeds{nullptr, nullptr, 0, 0, 0, 0};
     // sd.up levels above the tile are rebuilt by the kernel (cone_*): four fused levels, one lane per cone point
     const bool cone = seeds && seeds->up != 0;
-    if (cone && (k != 4 || sd.up > (u32)kConeMaxUp || HGI_PAIR)) return hipErrorInvalidValue;
+    if (cone && (k != 4 || sd.up > (u32)kConeMaxUp)) return hipErrorInvalidValue;
     if (seeds && !cone && !seeds->rec) return hipErrorInvalidValue;
-    const dim3 b(NL * NWAVES);
+    const dim3 b(NL);
     const int nh = k >= 2 ? (int)k : 1;
     // A decode between one and eight rounds of resident tiles deep (8 192 ... 65 536 tiles: a lone 16384^2 frame has 32 768)
     // runs with 20 tiles per CU instead of the 32 its LDS allows: the rate is the same down to 16 (round 1, and
     // profiles/r03_waves_sweep.txt: 101.3 us at 32, 99.1 at 20, 98.5 at 16, 109.8 at 12), the tile lifetime -- what filling
-    // and draining the chip costs -- shorter.  (The encoder needs all 20 it can get: 98 us, 106 at 16.)
-    static const int dec_waves_forced = getenv("HGI_DEC_WAVES") ? atoi(getenv("HGI_DEC_WAVES")) : -1;
+    // and draining the chip costs -- shorter.  (The encoder needs all 20 it can get: 98 us, 106 at 16.)  Deeper launches run
+    // with 16: the longer the launch, the more 32 resident tiles per CU cost it (round 4, profiles/r04_c3_dec_sweep.txt:
+    // 64 x 4096^2 348.9 -> 346.8 us, 256 x 1432 -> 1393, 512 x 2883 -> 2792: with twice the L2's worth of tiles in flight per XCD
+    // the halo rows of a band are fetched again, 1.06 x the algorithmic bytes in round 1's counters; at 16 they are not).
+    const int dec_waves_forced = HGI_KNOB(HGI_DEC_WAVES, -1);
     const u64 tiles = (u64)g.nfast + g.nedge;
-    const int dec_waves = dec_waves_forced >= 0 ? dec_waves_forced : (tiles >= 8192 && tiles < 65536 ? HGI_DEC_SHALLOW_WAVES : 0);
-    const size_t lds = lds_for_waves((size_t)buf_bytes(nh) * NWAVES, dec_waves);
-    if (HGI_PAIR && (g.full_x & 1u)) return hipErrorInvalidValue;      // the experiment build pairs x-adjacent interior tiles
-    const dim3 blocks(((g.nedge + 7u) & ~7u) + g.nfast / NWAVES);
+    const int dec_waves = dec_waves_forced >= 0 ? dec_waves_forced : tiles >= 65536 ? HGI_DEC_DEEP_WAVES : tiles >= 8192 ? HGI_DEC_SHALLOW_WAVES : 0;
+    const size_t lds = lds_for_waves((size_t)buf_bytes(nh), dec_waves);
+    const dim3 blocks(((g.nedge + 7u) & ~7u) + g.nfast);
 #define HGI_DEC(I, SE) hipLaunchKernelGGL((k_dec_tiles<I, SE, TH>), blocks, b, lds, s, grid, img, f, k, sd, g, r.aligned)
+    // (seed PLANES without a cone -- SEEDED == 1 -- exist for 64-row tiles only: six fused levels, hgi_capi.hip host_banded)
 #define HGI_DEC_I(I)                                                     \
     do {                                                                 \
         if (!seeds) HGI_DEC(I, 0);                                       \
-        else if (!cone) HGI_DEC(I, 1);                                   \
-        else HGI_DEC(I, 2);                                              \
+        else if (cone) HGI_DEC(I, 2);                                    \
+        else if constexpr (TH == 64) HGI_DEC(I, 1);                      \
+        else return hipErrorInvalidValue;                                \
     } while (0)
     if (interp == kInterpCrossed) HGI_DEC_I(kInterpCrossed); else HGI_DEC_I(kInterpLeftTop);
 #undef HGI_DEC_I
@@ -2106,21 +2066,20 @@ hipError_t HGI_TILED(launch_encode_fused)(const uint8_t *img, uint8_t *grid, con
     FusedGeom r = fused_geom(img, grid, f, row_limit);
     if (!r.ok || k < 1 || k > (u32)MAXK) return hipErrorInvalidValue;
     r.g.band = band_rows(f, true);
-    r.g.xmode = xcd_mode();
+    r.g.xmode = xcd_mode(r.g);
     finish_grid(r.g);
     const TileGrid &g = r.g;
     if (seeds && k < (uint32_t)kSeededMinLevels) return hipErrorInvalidValue;      // one lane per lattice point (seed_issue)
     Seeds sd = seeds ? *seeds : Seeds{nullptr, nullptr, 0, 0, 0, 0};
     // sd.up levels above the tile are rebuilt by the kernel (cone_*): four fused levels, one lane per cone point
     const bool cone = seeds && seeds->up != 0;
-    if (cone && (k != 4 || sd.up > (u32)kConeMaxUp || HGI_PAIR)) return hipErrorInvalidValue;
+    if (cone && (k != 4 || sd.up > (u32)kConeMaxUp)) return hipErrorInvalidValue;
     if (seeds && (!seeds->rec != !seeds->q || (!cone && !seeds->rec))) return hipErrorInvalidValue;
-    const dim3 b(NL * NWAVES);
+    const dim3 b(NL);
     const int nh = k >= 2 ? (int)k : 1;
-    static const int enc_waves = getenv("HGI_ENC_WAVES") ? atoi(getenv("HGI_ENC_WAVES")) : 0;
-    const size_t lds = lds_for_waves(((size_t)buf_bytes(nh) + ((rbuf_bytes(nh) + 15) & ~15)) * NWAVES + 256, enc_waves);
-    if (HGI_PAIR && (g.full_x & 1u)) return hipErrorInvalidValue;      // the experiment build pairs x-adjacent interior tiles
-    const dim3 blocks(((g.nedge + 7u) & ~7u) + g.nfast / NWAVES);
+    const int enc_waves = HGI_KNOB(HGI_ENC_WAVES, 0);
+    const size_t lds = lds_for_waves((size_t)buf_bytes(nh) + ((rbuf_bytes(nh) + 15) & ~15) + 256, enc_waves);
+    const dim3 blocks(((g.nedge + 7u) & ~7u) + g.nfast);
     // lut_at() addresses the table from LDS offset 0: only valid while the kernel has no static LDS in front of its
     // dynamic segment.  Checked once per instantiation on the host; a build that breaks it fails here, not on the device.
 #define HGI_ENC(I, ID, SE)                                                                                        \
@@ -2129,13 +2088,21 @@ hipError_t HGI_TILED(launch_encode_fused)(const uint8_t *img, uint8_t *grid, con
         if (lds0 != hipSuccess) return lds0;                                                                      \
         hipLaunchKernelGGL((k_enc_tiles<I, ID, SE, TH>), blocks, b, lds, s, img, grid, f, k, lut, sd, g, r.aligned); \
     } while (0)
+    // (seed PLANES without a cone -- SEEDED == 1 -- exist for 64-row tiles only: six fused levels, hgi_capi.hip host_banded)
+#define HGI_ENC_ID(I, ID)                                                     \
+    do {                                                                      \
+        if (cone) HGI_ENC(I, ID, 2);                                          \
+        else if (!seeds) HGI_ENC(I, ID, 0);                                   \
+        else if constexpr (TH == 64) HGI_ENC(I, ID, 1);                       \
+        else return hipErrorInvalidValue;                                     \
+    } while (0)
 #define HGI_ENC_I(I)                                                          \
     do {                                                                      \
-        if (ident) { if (cone) HGI_ENC(I, true, 2); else if (seeds) HGI_ENC(I, true, 1); else HGI_ENC(I, true, 0); } \
-        else       { if (cone) HGI_ENC(I, false, 2); else if (seeds) HGI_ENC(I, false, 1); else HGI_ENC(I, false, 0); } \
+        if (ident) HGI_ENC_ID(I, true); else HGI_ENC_ID(I, false);            \
     } while (0)
     if (interp == kInterpCrossed) HGI_ENC_I(kInterpCrossed); else HGI_ENC_I(kInterpLeftTop);
 #undef HGI_ENC_I
+#undef HGI_ENC_ID
 #undef HGI_ENC
     return hipGetLastError();
 }

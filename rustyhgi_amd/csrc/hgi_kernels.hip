@@ -11,8 +11,10 @@
 // strided; kept as the on-device cross-check and for measuring single passes.
 // All arithmetic is u8/integer; there is no MFMA-shaped work on this path.
 #include <stdlib.h>
+#include <atomic>
 
 #include "hgi_dev.h"
+#include "hgi_knobs.h"
 
 namespace hgi {
 namespace {
@@ -332,10 +334,7 @@ bool lattice_pyramid_fits(uint32_t sw, uint32_t sh, size_t batch)
     // One workgroup per frame: worth it for small planes only (64 x 64 per 4K frame: three launches become one).  At
     // 256 x 256 -- a lone 16384^2 frame -- the single workgroup takes longer than the tile kernels it would replace
     // (measured 164 / 140 us against 139 / 114 us for the whole call), so larger planes keep the host recursion.
-    static const uint64_t limit = [] {
-        const char *e = getenv("HGI_LATTICE_MAX");     // experiments: largest plane (points) the kernel takes
-        return e ? (uint64_t)atoll(e) : (uint64_t)8192;
-    }();
+    const uint64_t limit = (uint64_t)HGI_KNOB(HGI_LATTICE_MAX, 8192);     // largest plane (points) the kernel takes
     return (uint64_t)sw * sh <= limit && (uint64_t)sw * sh <= 64 * 1024 && batch <= 0x7FFFFFFFull;
 }
 
@@ -345,14 +344,17 @@ hipError_t launch_lattice_pyramid(const uint8_t *src, const Frames &f, uint32_t 
 {
     const size_t n_al = ((size_t)sw * sh + 15) & ~(size_t)15, lds = 2 * n_al + 256;
     const dim3 grid(f.batch), block(1024);
+    // more than 64 KiB of dynamic LDS has to be asked for once per kernel AND PER DEVICE (one process may drive several:
+    // include/hgi.h, "distinct ctxs are independent"); a bit per device ordinal, set after the attribute call succeeded
 #define HGI_LATTICE(I, E)                                                                                                  \
     do {                                                                                                                    \
-        static bool big_lds = false;   /* more than 64 KiB of dynamic LDS has to be asked for once per kernel */             \
-        if (lds > 64 * 1024 && !big_lds) {                                                                                  \
+        static std::atomic<unsigned long long> big_lds{0};                                                                  \
+        int dev_ = 0;                                                                                                       \
+        if (lds > 64 * 1024 && hipGetDevice(&dev_) == hipSuccess && !((big_lds.load() >> (dev_ & 63)) & 1ull)) {            \
             hipError_t e_ = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_lattice_pyramid<I, E>),                   \
                                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                    \
             if (e_ != hipSuccess) return e_;                                                                                \
-            big_lds = true;                                                                                                 \
+            big_lds.fetch_or(1ull << (dev_ & 63));                                                                          \
         }                                                                                                                   \
         hipLaunchKernelGGL((k_lattice_pyramid<I, E>), grid, block, lds, s, src, f, k, up, lut, ident ? 1u : 0u, out_q, out_rec, \
                            sw, sh, dst_stride);                                                                             \

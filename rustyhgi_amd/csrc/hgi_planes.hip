@@ -1,0 +1,635 @@
+// C ABI of libhgi_hip.so (include/hgi.h), part 3: plane placement -- hgi_planes_alloc / hgi_planes_free / hgi_probe_pair_u8_dev.
+// No reference counterpart: the reference's buffers are Vec<u8> (src/grid.rs:2-5).
+//
+// Measured on MI355X (profiles/r02_modes*.txt, profiles/r04_regions.txt): the HBM behind one device falls into
+// a few CLASSES of physical memory (at least three on a 288 GiB part), and a kernel that streams one buffer in while streaming
+// another out runs 4-8 % faster when the two lie in DIFFERENT classes than when they share one -- for the tile kernels 0.340
+// against 0.367 ms per GiB in the probe below, 0.353 against 0.367 ms per 64 frames of 4096^2 in the codec, 1.5 % for a linear
+// copy.  Physical addresses are not visible from user space, a class is not a contiguous range of an allocation (one 160 GiB
+// hipMalloc changes class every 8 ... 52 GiB along its length), so the only way to tell is to run the stream: the probe times
+// the decode kernel from one buffer into the other (its time does not depend on the bytes).  hgi_planes_alloc uses it to hand
+// out planes whose neighbours in the array lie in different classes over their whole length: what an encode -> decode chain
+// (image -> grid -> image) wants.  Two constructions:
+//   * planes up to 1 GiB: whole hipMalloc allocations are the candidates (round 2; alloc_whole);
+//   * larger planes (the 512-frame C3 batch has three of 8 GiB): no single allocation of that size can be relied on to stay
+//     in one class, so a plane is COMPOSED -- physical chunks of 1 GiB (hipMemCreate) are classified one by one and mapped
+//     behind one another into one reserved address range per plane (hipMemAddressReserve / hipMemMap) such that at every
+//     offset neighbouring planes sit on chunks of different classes (round 4; alloc_composed).  The search is bounded by
+//     bytes: at most 3 x the requested chunks are ever created, everything not handed out is released.
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <mutex>
+#include <vector>
+
+#include "hgi_host.h"
+
+using namespace hgi;
+using namespace hgi::host;
+
+namespace {
+
+// mean time of decode launches prev -> cand over min(bytes, 2 GiB), as one frame 4096 wide
+hgi_status probe_pair_ms(hgi_ctx *c, const uint8_t *prev, uint8_t *cand, size_t bytes, float *ms)
+{
+    const uint32_t w = 4096;
+    size_t rows = bytes / w;
+    if (rows > (2u << 20) / 4) rows = (2u << 20) / 4;          // 2 GiB: every byte offset stays below 2^32
+    rows &= ~(size_t)63;
+    const uint32_t h = (uint32_t)rows;
+    constexpr int kWarm = 2, kTimed = 4;
+    for (int i = 0; i < kWarm + kTimed; ++i) {
+        if (i == kWarm) HIP_TRY(hipEventRecord(c->ev_probe[0], c->stream));
+        c->ws_used = 0;
+        // LeftTop: the same memory-access structure as Crossed, and a kernel name of its own in profiles
+        // (k_dec_tiles<0, ...>), so that probe launches are never counted among the workload's k_dec_tiles<1, ...>
+        HGI_TRY(decode_impl(c, prev, w, h, 4, HGI_INTERP_LEFTTOP, cand, 1, (size_t)w * h));
+    }
+    HIP_TRY(hipEventRecord(c->ev_probe[1], c->stream));
+    HIP_TRY(hipEventSynchronize(c->ev_probe[1]));
+    HIP_TRY(hipEventElapsedTime(ms, c->ev_probe[0], c->ev_probe[1]));
+    *ms /= kTimed;
+    return HGI_OK;
+}
+
+constexpr size_t kGiB = (size_t)1 << 30;
+// A pair counts as "different classes" when it streams in less than kFastRatio of the same-class yardstick's time.  Measured
+// with 1 GiB probes on the round-4 kernels (profiles/r04_planes_trace.txt): 0.945-0.962 across classes, 0.98-1.02 within one
+// (in absolute terms 0.341 against 0.359-0.367 ms: the yardstick's two halves, neighbours in one block, are the fastest
+// same-class pair there is).  A ratio inside the band between the two populations is measured again, four more rounds.
+constexpr float kFastRatio = 0.972f, kUnsureLo = 0.962f, kUnsureHi = 0.985f;
+constexpr int kMaxCandidates = 10;    // whole-plane construction: candidates beyond `count`
+constexpr size_t kComposeAbove = kGiB;      // planes larger than one chunk are composed of chunks
+constexpr size_t kChunk = kGiB;       // chunk of a composed plane: uniform in class (transitions were seen at multiples of 4 GiB
+                                      // along an allocation) and large enough for the probe to tell (8 % between the classes)
+
+// The yardstick: what a stream costs when source and destination share a class.  A power-of-two request of a few GiB is
+// served as ONE buddy block, so its two halves are a same-class pair by construction.  (Comparisons among candidates alone
+// cannot tell "all fast" from "all slow".)  Every pair is timed AGAINST the yardstick, interleaved with it, after the yardstick
+// has stopped drifting: the device's clocks fall back within milliseconds of idling (an allocation in between is enough)
+// and ramp for ~25 ms once work resumes (profiles/r02_ramp.txt), so absolute times taken at different moments do not compare.
+struct Yardstick {
+    void *ref = nullptr;
+    uint8_t *lo = nullptr, *hi = nullptr;
+    size_t span = 0;          // bytes one probe streams
+
+    hgi_status make(size_t span_bytes)
+    {
+        span = span_bytes;
+        size_t ref_bytes = 1;
+        while (ref_bytes < 2 * span) ref_bytes <<= 1;
+        if (hipMalloc(&ref, ref_bytes) != hipSuccess) {
+            (void)hipGetLastError();
+            ref = nullptr;
+            return HGI_ENOMEM;
+        }
+        lo = static_cast<uint8_t *>(ref);
+        hi = lo + ref_bytes / 2;
+        return HGI_OK;
+    }
+    void drop()
+    {
+        if (ref) (void)hipFree(ref);
+        ref = nullptr;
+        (void)hipGetLastError();
+    }
+    // does a -> b stream faster than the same-class pair?
+    hgi_status other_class(hgi_ctx *c, const uint8_t *a, uint8_t *b, bool *yes, float *ratio = nullptr) const
+    {
+        float last = 0, ms = 0;
+        HGI_TRY(probe_pair_ms(c, lo, hi, span, &last));
+        for (int it = 0; it < 12; ++it) {
+            HGI_TRY(probe_pair_ms(c, lo, hi, span, &ms));
+            const bool steady = ms <= last * 1.007f && last <= ms * 1.007f;
+            last = ms;
+            if (steady) break;
+        }
+        float same = 0, pair = 0;
+        for (int rep = 0; rep < 6; ++rep) {
+            HGI_TRY(probe_pair_ms(c, lo, hi, span, &ms));
+            same += ms;
+            HGI_TRY(probe_pair_ms(c, a, b, span, &ms));
+            pair += ms;
+            if (rep == 1 && (pair < same * kUnsureLo || pair > same * kUnsureHi)) break;      // clear after two rounds
+        }
+        *yes = pair < same * kFastRatio;
+        if (ratio) *ratio = pair / same;
+        return HGI_OK;
+    }
+};
+
+// Candidates sorted into groups that share a class: a candidate joins the first group whose representative it does NOT
+// stream fast against (the group tried first is `hint`, normally the group of the candidate allocated just before: the
+// driver hands out neighbours in runs).  Returns the group index.
+template <typename Ptr>
+hgi_status classify(hgi_ctx *c, const Yardstick &y, std::vector<std::vector<int>> &groups, int cand, int hint, Ptr ptr_of, int *group)
+{
+    std::vector<int> order;
+    if (hint >= 0 && hint < (int)groups.size()) order.push_back(hint);
+    for (int g = 0; g < (int)groups.size(); ++g)
+        if (g != hint) order.push_back(g);
+    for (int g : order) {
+        bool other = false;
+        float ratio = 0;
+        HGI_TRY(y.other_class(c, ptr_of(groups[(size_t)g][0]), ptr_of(cand), &other, &ratio));
+        if (HGI_SWITCH(HGI_PLANES_TRACE)) fprintf(stderr, "hgi_planes_alloc: candidate %d against group %d (its member %d): %.3f of the yardstick -> %s\n", cand, g, groups[(size_t)g][0], ratio, other ? "other class" : "same class");
+        if (!other) {
+            groups[(size_t)g].push_back(cand);
+            *group = g;
+            return HGI_OK;
+        }
+    }
+    groups.push_back(std::vector<int>{cand});
+    *group = (int)groups.size() - 1;
+    return HGI_OK;
+}
+
+// Greedy arrangement of `count` members such that neighbours come from different groups: always take from the largest
+// remaining group that is not the one just used.  `left[g]` = members of group g still available (updated).  Returns the group
+// of every position, or an empty vector if it cannot be done.
+std::vector<int> arrange(std::vector<size_t> &left, uint32_t count)
+{
+    std::vector<int> seq;
+    std::vector<size_t> trial = left;
+    int prev = -1;
+    while (seq.size() < count) {
+        int pick = -1;
+        for (size_t g = 0; g < trial.size(); ++g)
+            if ((int)g != prev && trial[g] > 0 && (pick < 0 || trial[g] > trial[(size_t)pick])) pick = (int)g;
+        if (pick < 0) return {};
+        seq.push_back(pick);
+        --trial[(size_t)pick];
+        prev = pick;
+    }
+    left = trial;
+    return seq;
+}
+
+// ---- composed planes: bookkeeping of what hgi_planes_free has to undo ---------------------------------------------------
+struct Composed {
+    void *va;
+    size_t bytes;
+    int device;
+    std::vector<hipMemGenericAllocationHandle_t> chunks;
+};
+std::mutex g_mu;
+std::vector<Composed> g_composed;
+
+void release_composed(Composed &p)
+{
+    if (p.va) {
+        (void)hipMemUnmap(p.va, p.bytes);
+        (void)hipMemAddressFree(p.va, p.bytes);
+    }
+    for (auto h : p.chunks) (void)hipMemRelease(h);
+    p.chunks.clear();
+    p.va = nullptr;
+    (void)hipGetLastError();
+}
+
+// plain allocations, no placement
+hgi_status alloc_plain(size_t bytes, uint32_t count, void **planes)
+{
+    for (uint32_t i = 0; i < count; ++i) {
+        void *p = nullptr;
+        if (hipMalloc(&p, bytes) != hipSuccess) {
+            (void)hipGetLastError();
+            for (uint32_t j = 0; j < i; ++j) {
+                (void)hipFree(planes[j]);
+                planes[j] = nullptr;
+            }
+            return fail(HGI_ENOMEM, "hipMalloc of %zu bytes failed", bytes);
+        }
+        planes[i] = p;
+    }
+    return HGI_OK;
+}
+
+// ---- planes up to 1 GiB: whole allocations as candidates -----------------------------------------------------------------
+hgi_status alloc_whole(hgi_ctx *c, size_t bytes, uint32_t count, void **planes, int *separated)
+{
+    std::vector<void *> bufs, spacers;     // candidate planes; allocations that only push the driver onwards
+    Yardstick y;
+    auto release = [&](std::vector<void *> &v) {
+        for (void *p : v)
+            if (p) (void)hipFree(p);
+        v.clear();
+        (void)hipGetLastError();
+    };
+    auto bail = [&](hgi_status st) {
+        release(bufs);
+        release(spacers);
+        y.drop();
+        for (uint32_t i = 0; i < count; ++i) planes[i] = nullptr;
+        return st;
+    };
+    for (uint32_t i = 0; i < count; ++i) {
+        void *p = nullptr;
+        if (hipMalloc(&p, bytes) != hipSuccess) return bail(fail(HGI_ENOMEM, "hipMalloc of %zu bytes failed", bytes));
+        bufs.push_back(p);
+    }
+    auto hand_out = [&](const std::vector<int> &order) {
+        std::vector<char> used(bufs.size(), 0);
+        for (uint32_t i = 0; i < count; ++i) {
+            planes[i] = bufs[(size_t)order[i]];
+            used[(size_t)order[i]] = 1;
+        }
+        for (size_t j = 0; j < bufs.size(); ++j)
+            if (!used[j]) (void)hipFree(bufs[j]);
+        bufs.clear();
+        release(spacers);
+        y.drop();
+    };
+    std::vector<int> plain(count);
+    for (uint32_t i = 0; i < count; ++i) plain[i] = (int)i;
+    {
+        const hgi_status st = ws_ensure(c, ws_need(c, 4096, 4096, 4, 1, (size_t)4096 * 4096));
+        if (st != HGI_OK) return bail(st);
+    }
+    if (y.make(bytes) != HGI_OK) {      // no room for the yardstick: the planes are still good
+        hand_out(plain);
+        return HGI_OK;
+    }
+    // `count` planes whose neighbours differ exist as soon as no group has to supply more than every other plane.  Until
+    // then: one more candidate, behind a spacer.  The driver serves requests buddy-style, the smallest free piece that fits
+    // first, so candidates of one size tend to come from one block until it is used up (profiles/r02_modes4.txt: runs of 16);
+    // spacers of `bytes`, 2 x, 4 x ... take that block's free buddies.  Large allocations take the driver seconds (it clears
+    // them), hence the caps.
+    std::vector<std::vector<int>> groups;
+    size_t classified = 0;
+    int spacer_shift = 0, last_group = -1;
+    std::vector<int> order;
+    auto ptr_of = [&](int j) { return static_cast<uint8_t *>(bufs[(size_t)j]); };
+    for (;;) {
+        for (; classified < bufs.size(); ++classified) {
+            const hgi_status st = classify(c, y, groups, (int)classified, last_group, ptr_of, &last_group);
+            if (st != HGI_OK) return bail(st);
+        }
+        std::vector<size_t> left(groups.size());
+        for (size_t g = 0; g < groups.size(); ++g) left[g] = groups[g].size();
+        const std::vector<int> seq = arrange(left, count);
+        order.clear();
+        if (!seq.empty()) {
+            std::vector<size_t> next(groups.size(), 0);
+            for (int g : seq) order.push_back(groups[(size_t)g][next[(size_t)g]++]);
+            break;                                                          // neighbours all in different classes
+        }
+        if (bufs.size() >= (size_t)count + kMaxCandidates) break;           // give up
+        size_t free_b = 0, total_b = 0;
+        const size_t want = bytes << (spacer_shift < 5 ? spacer_shift : 5);      // 1, 2, 4, 8, 16, then 32 x bytes each time
+        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && want <= free_b / 3) {
+            void *fill = nullptr;
+            if (hipMalloc(&fill, want) == hipSuccess) spacers.push_back(fill);
+            (void)hipGetLastError();
+            ++spacer_shift;
+        }
+        void *cand = nullptr;
+        if (hipMalloc(&cand, bytes) != hipSuccess) {
+            (void)hipGetLastError();
+            break;
+        }
+        bufs.push_back(cand);
+    }
+    const bool ok = order.size() == count;
+    if (!ok) {      // could not be established: alternate between the groups as far as they go, then whatever is left
+        std::vector<size_t> left(groups.size());
+        for (size_t g = 0; g < groups.size(); ++g) left[g] = groups[g].size();
+        std::vector<size_t> next(groups.size(), 0);
+        std::vector<char> used(bufs.size(), 0);
+        int prev = -1;
+        while (order.size() < count) {
+            int pick = -1;
+            for (size_t g = 0; g < groups.size(); ++g)
+                if ((int)g != prev && left[g] > 0 && (pick < 0 || left[g] > left[(size_t)pick])) pick = (int)g;
+            if (pick < 0) break;
+            const int j = groups[(size_t)pick][next[(size_t)pick]++];
+            order.push_back(j);
+            used[(size_t)j] = 1;
+            --left[(size_t)pick];
+            prev = pick;
+        }
+        for (size_t j = 0; j < bufs.size() && order.size() < count; ++j)
+            if (!used[j]) order.push_back((int)j);
+    }
+    hand_out(order);
+    if (separated) *separated = ok ? 1 : 0;
+    return HGI_OK;
+}
+
+// ---- larger planes: composed of classified 1 GiB chunks -------------------------------------------------------------------
+hgi_status alloc_composed(hgi_ctx *c, size_t bytes, uint32_t count, void **planes, int *separated)
+{
+    const size_t n = (bytes + kChunk - 1) / kChunk;            // chunks per plane
+    const size_t need = n * count;
+    size_t free_b = 0, total_b = 0;
+    HIP_TRY(hipMemGetInfo(&free_b, &total_b));
+    // the search is bounded by bytes: never more than three times what was asked for, never more than the device has free
+    // beyond the yardstick and a margin
+    size_t max_chunks = 3 * need;
+    const size_t room = free_b > 6 * kGiB ? (free_b - 6 * kGiB) / kChunk : 0;
+    if (max_chunks > room) max_chunks = room;
+    if (max_chunks < need) return fail(HGI_ENOMEM, "%u planes of %zu bytes do not fit the device's %zu free bytes", count, bytes, free_b);
+
+    hipMemAllocationProp prop = {};
+    prop.type = hipMemAllocationTypePinned;
+    prop.location.type = hipMemLocationTypeDevice;
+    prop.location.id = c->device;
+    hipMemAccessDesc acc = {};
+    acc.location = prop.location;
+    acc.flags = hipMemAccessFlagsProtReadWrite;
+
+    std::vector<hipMemGenericAllocationHandle_t> spacers;      // physical memory held only to push the driver onwards (never mapped)
+    std::vector<hipMemGenericAllocationHandle_t> h;     // every chunk created, in creation order
+    std::vector<char> mapped;                           // ... whether it is mapped at its staging slot
+    std::vector<char> owned;                            // ... and whether a finished plane (`made`) owns it by now
+    uint8_t *stage = nullptr;                           // staging range: chunk j at stage + j * kChunk while it is being classified
+    Yardstick y;
+    std::vector<Composed> made;
+    auto cleanup = [&](bool keep_made) {
+        if (stage) {
+            for (size_t j = 0; j < h.size(); ++j)
+                if (mapped[j]) (void)hipMemUnmap(stage + j * kChunk, kChunk);
+            (void)hipMemAddressFree(stage, max_chunks * kChunk);
+        }
+        stage = nullptr;
+        y.drop();
+        for (auto sp : spacers) (void)hipMemRelease(sp);
+        spacers.clear();
+        if (!keep_made) {
+            for (auto &p : made) release_composed(p);
+            made.clear();
+        }
+        (void)hipGetLastError();
+    };
+    auto bail = [&](hgi_status st) {
+        cleanup(false);      // (releases the chunks the finished planes own)
+        for (size_t j = 0; j < h.size(); ++j)
+            if (!owned[j]) (void)hipMemRelease(h[j]);
+        h.clear();
+        for (uint32_t i = 0; i < count; ++i) planes[i] = nullptr;
+        (void)hipGetLastError();
+        return st;
+    };
+#define PL_TRY(expr)                                                                                                     \
+    do {                                                                                                                 \
+        hipError_t e_ = (expr);                                                                                          \
+        if (e_ != hipSuccess)                                                                                            \
+            return bail(fail(e_ == hipErrorOutOfMemory ? HGI_ENOMEM : HGI_EDEVICE, "%s: %s", #expr, hipGetErrorString(e_))); \
+    } while (0)
+    {
+        const hgi_status st = ws_ensure(c, ws_need(c, 4096, 4096, 4, 1, (size_t)4096 * 4096));
+        if (st != HGI_OK) return bail(st);
+    }
+    if (y.make(kChunk) != HGI_OK) return bail(fail(HGI_ENOMEM, "no room for the placement yardstick (2 GiB)"));
+    PL_TRY(hipMemAddressReserve(reinterpret_cast<void **>(&stage), max_chunks * kChunk, 0, nullptr, 0));
+
+    // create, map, classify -- until at every chunk offset `count` chunks can be lined up with neighbours of different classes.
+    // The driver hands out physical memory in runs of one class (8 ... 52 GiB long in one 160 GiB allocation; longer right after
+    // another process has released a large part of the device), so when the chunks keep arriving in the class there is already
+    // too much of, a SPACER is created in front of the next ones -- physical memory of 4, 8, 16, 32 GiB that is never mapped and
+    // only takes the rest of the run away; released with everything else that is not handed out.
+    std::vector<std::vector<int>> groups;
+    int last_group = -1;
+    auto ptr_of = [&](int j) { return stage + (size_t)j * kChunk; };
+    std::vector<std::vector<int>> lineup;      // [offset][plane] -> chunk
+    bool ok = false;
+    size_t spacer_gib = 4, spacer_total = 0;
+    const size_t spacer_budget = room > max_chunks ? (room - max_chunks < 96 ? room - max_chunks : 96) : 0;      // GiB (kChunk is one)
+    const bool trace = HGI_SWITCH(HGI_PLANES_TRACE);
+    for (;;) {
+        if (h.size() >= need && groups.size() >= 1) {
+            // the last chunks all went to the largest group: skip ahead
+            size_t big = 0;
+            for (size_t g = 1; g < groups.size(); ++g)
+                if (groups[g].size() > groups[big].size()) big = g;
+            const size_t look = n < 4 ? n : 4;
+            bool stalled = groups[big].size() >= look;
+            for (size_t t = 0; t < look && stalled; ++t) stalled = groups[big][groups[big].size() - 1 - t] == (int)(h.size() - 1 - t);
+            if (stalled && spacer_total + spacer_gib <= spacer_budget) {
+                hipMemGenericAllocationHandle_t sp;
+                if (hipMemCreate(&sp, spacer_gib * kGiB, &prop, 0) == hipSuccess) {
+                    spacers.push_back(sp);
+                    spacer_total += spacer_gib;
+                    if (trace) fprintf(stderr, "hgi_planes_alloc: the last %zu chunks joined group %zu (%zu of %zu chunks): spacer of %zu GiB\n", look, big, groups[big].size(), h.size(), spacer_gib);
+                    if (spacer_gib < 32) spacer_gib *= 2;
+                } else {
+                    (void)hipGetLastError();
+                }
+            }
+        }
+        const size_t target = h.size() < need ? need : h.size() + (n < 4 ? n : 4);
+        while (h.size() < target && h.size() < max_chunks) {
+            hipMemGenericAllocationHandle_t hh;
+            if (hipMemCreate(&hh, kChunk, &prop, 0) != hipSuccess) {
+                (void)hipGetLastError();
+                max_chunks = h.size();      // the device is full: work with what there is
+                break;
+            }
+            h.push_back(hh);
+            mapped.push_back(0);
+            owned.push_back(0);
+            const size_t j = h.size() - 1;
+            PL_TRY(hipMemMap(stage + j * kChunk, kChunk, 0, hh, 0));
+            mapped[j] = 1;
+            PL_TRY(hipMemSetAccess(stage + j * kChunk, kChunk, &acc, 1));
+            const hgi_status st = classify(c, y, groups, (int)j, last_group, ptr_of, &last_group);
+            if (st != HGI_OK) return bail(st);
+        }
+        if (h.size() < need) return bail(fail(HGI_ENOMEM, "hipMemCreate: the device ran out of memory after %zu of %zu chunks", h.size(), need));
+        // line-up per offset
+        std::vector<size_t> left(groups.size());
+        for (size_t g = 0; g < groups.size(); ++g) left[g] = groups[g].size();
+        std::vector<size_t> next(groups.size(), 0);
+        lineup.clear();
+        ok = true;
+        for (size_t m = 0; m < n && ok; ++m) {
+            const std::vector<int> seq = arrange(left, count);
+            if (seq.empty()) {
+                ok = false;
+                break;
+            }
+            std::vector<int> row;
+            for (int g : seq) row.push_back(groups[(size_t)g][next[(size_t)g]++]);
+            lineup.push_back(row);
+        }
+        if (ok || h.size() >= max_chunks) break;
+    }
+    if (!ok) {
+        // could not be established within the budget: the offsets that did line up stay as they are (a partly separated stream
+        // is still faster), the others take what is left, in creation order
+        std::vector<char> used(h.size(), 0);
+        for (auto &row : lineup)
+            for (int j : row) used[(size_t)j] = 1;
+        size_t at = 0;
+        while (lineup.size() < n) {
+            std::vector<int> row;
+            while (row.size() < count) {
+                while (used[at]) ++at;
+                used[at] = 1;
+                row.push_back((int)at);
+            }
+            lineup.push_back(row);
+        }
+    }
+    if (trace) {
+        fprintf(stderr, "hgi_planes_alloc: %zu chunks created, %zu GiB of spacers, %zu groups:", h.size(), spacer_total, groups.size());
+        for (auto &g : groups) fprintf(stderr, " %zu", g.size());
+        fprintf(stderr, " -> line-up %s\n", ok ? "complete" : "INCOMPLETE");
+    }
+    // What the probes said chunk against group representative, checked pair by pair as the planes will hold them: at every
+    // chunk offset every neighbouring pair must stream at the fast rate (this is what the caller is promised).  A pair that
+    // does not (a noisy classification; pairs of some classes are only half as far apart as others) is repaired once: the
+    // second chunk is exchanged for an unused one of another group that passes against both its neighbours.
+    if (ok) {
+        std::vector<int> group_of(h.size(), -1);
+        for (size_t g = 0; g < groups.size(); ++g)
+            for (int j : groups[g]) group_of[(size_t)j] = (int)g;
+        std::vector<char> used(h.size(), 0);
+        for (auto &row : lineup)
+            for (int j : row) used[(size_t)j] = 1;
+        auto fast = [&](int a, int b, bool *yes) -> hgi_status {
+            float ratio = 0;
+            const hgi_status st = y.other_class(c, ptr_of(a), ptr_of(b), yes, &ratio);
+            if (trace && st == HGI_OK) fprintf(stderr, "hgi_planes_alloc: check, chunks %d -> %d: %.3f of the yardstick\n", a, b, ratio);
+            return st;
+        };
+        for (size_t m = 0; m < n && ok; ++m)
+            for (uint32_t i = 0; i + 1 < count && ok; ++i) {
+                bool yes = false;
+                hgi_status st = fast(lineup[m][i], lineup[m][i + 1], &yes);
+                if (st != HGI_OK) return bail(st);
+                if (yes) continue;
+                int tries = 0;
+                for (size_t u = 0; u < h.size() && !yes && tries < 4; ++u) {
+                    if (used[u] || group_of[u] == group_of[(size_t)lineup[m][i]] || group_of[u] == group_of[(size_t)lineup[m][i + 1]]) continue;
+                    if (i + 2 < count && group_of[u] == group_of[(size_t)lineup[m][i + 2]]) continue;
+                    ++tries;
+                    bool a = false, b = true;
+                    st = fast(lineup[m][i], (int)u, &a);
+                    if (st == HGI_OK && a && i + 2 < count) st = fast((int)u, lineup[m][i + 2], &b);
+                    if (st != HGI_OK) return bail(st);
+                    if (a && b) {
+                        if (trace) fprintf(stderr, "hgi_planes_alloc: offset %zu, plane %u: chunk %d exchanged for %zu\n", m, i + 1, lineup[m][i + 1], u);
+                        used[(size_t)lineup[m][i + 1]] = 0;
+                        used[u] = 1;
+                        lineup[m][i + 1] = (int)u;
+                        yes = true;
+                    }
+                }
+                ok = yes;
+            }
+    }
+    // move the chosen chunks from their staging slots into one range per plane
+    for (uint32_t i = 0; i < count; ++i) {
+        Composed p;
+        p.va = nullptr;
+        p.bytes = n * kChunk;
+        p.device = c->device;
+        void *va = nullptr;
+        PL_TRY(hipMemAddressReserve(&va, p.bytes, 0, nullptr, 0));
+        p.va = va;
+        made.push_back(p);
+        for (size_t m = 0; m < n; ++m) {
+            const size_t j = (size_t)lineup[m][i];
+            if (mapped[j]) {
+                hipError_t e = hipMemUnmap(stage + j * kChunk, kChunk);
+                if (e != hipSuccess) return bail(fail(HGI_EDEVICE, "hipMemUnmap: %s", hipGetErrorString(e)));
+                mapped[j] = 0;
+            }
+            hipError_t e = hipMemMap(static_cast<uint8_t *>(va) + m * kChunk, kChunk, 0, h[j], 0);
+            if (e != hipSuccess) return bail(fail(HGI_EDEVICE, "hipMemMap: %s", hipGetErrorString(e)));
+            made.back().chunks.push_back(h[j]);
+            owned[j] = 1;
+        }
+        hipError_t e = hipMemSetAccess(va, p.bytes, &acc, 1);
+        if (e != hipSuccess) return bail(fail(HGI_EDEVICE, "hipMemSetAccess: %s", hipGetErrorString(e)));
+    }
+#undef PL_TRY
+    // release what was not handed out
+    for (size_t j = 0; j < h.size(); ++j)
+        if (!owned[j]) {
+            if (mapped[j]) (void)hipMemUnmap(stage + j * kChunk, kChunk);
+            mapped[j] = 0;
+            (void)hipMemRelease(h[j]);
+        }
+    cleanup(true);
+    {
+        std::lock_guard<std::mutex> lock(g_mu);
+        for (uint32_t i = 0; i < count; ++i) {
+            planes[i] = made[i].va;
+            g_composed.push_back(made[i]);
+        }
+    }
+    if (separated) *separated = ok ? 1 : 0;
+    return HGI_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+hgi_status hgi_probe_pair_u8_dev(hgi_ctx *c, const void *d_src, void *d_dst, size_t bytes, float *ms)
+{
+    if (!c || !d_src || !d_dst || !ms) return fail(HGI_EINVAL, "NULL argument");
+    if (bytes < 4096 * 64) return fail(HGI_EINVAL, "probe needs at least 256 KiB");
+    const uintptr_t a = reinterpret_cast<uintptr_t>(d_src), b = reinterpret_cast<uintptr_t>(d_dst);
+    if (a < b + bytes && b < a + bytes) return fail(HGI_EINVAL, "probe buffers overlap");
+    HIP_TRY(hipSetDevice(c->device));
+    HGI_TRY(ws_ensure(c, ws_need(c, 4096, 4096, 4, 1, (size_t)4096 * 4096)));
+    return probe_pair_ms(c, static_cast<const uint8_t *>(d_src), static_cast<uint8_t *>(d_dst), bytes, ms);
+}
+
+hgi_status hgi_planes_alloc(hgi_ctx *c, size_t bytes, uint32_t count, void **planes, int *separated)
+{
+    if (!c || !planes) return fail(HGI_EINVAL, "NULL argument");
+    if (separated) *separated = 0;
+    for (uint32_t i = 0; i < count; ++i) planes[i] = nullptr;
+    if (count == 0 || bytes == 0) return HGI_OK;
+    HIP_TRY(hipSetDevice(c->device));
+    const bool placing = count > 1 && !getenv("HGI_NO_PLACEMENT");
+    if (!placing || bytes < ((size_t)128 << 20)) return alloc_plain(bytes, count, planes);
+    if (bytes > kComposeAbove) return alloc_composed(c, bytes, count, planes, separated);
+    // Planes of 128 MiB up to (not including) 1 GiB: a launch that reads one and writes the next (2 x 256 MiB for a lone 16384^2
+    // frame) no longer fits the 256 MiB Infinity Cache, so placement matters to it (16384^2 level 8: encode 101 -> 98.3 us,
+    // decode 99.8 -> 97.5, profiles/r03_c4_placement.txt) -- but a probe over less than 512 MiB would measure that cache, not the
+    // classes, and at exactly 512 MiB the signal is too weak to call (separated = 0 in every run).  Such planes are allocated
+    // at 1 GiB, the size the probe was calibrated on; the caller uses their first `bytes`.  That is up to 8 x what was asked
+    // for: if the device does not have it, the planes come back at their own size, unplaced.
+    if (bytes < kGiB) {
+        const hgi_status st = alloc_whole(c, kGiB, count, planes, separated);
+        if (st != HGI_ENOMEM) return st;
+        if (separated) *separated = 0;
+        return alloc_plain(bytes, count, planes);
+    }
+    return alloc_whole(c, bytes, count, planes, separated);
+}
+
+hgi_status hgi_planes_free(hgi_ctx *c, uint32_t count, void **planes)
+{
+    if (!c || (!planes && count)) return fail(HGI_EINVAL, "NULL argument");
+    HIP_TRY(hipSetDevice(c->device));
+    for (uint32_t i = 0; i < count; ++i) {
+        if (!planes[i]) continue;
+        Composed mine;
+        mine.va = nullptr;
+        {
+            std::lock_guard<std::mutex> lock(g_mu);
+            for (size_t k = 0; k < g_composed.size(); ++k)
+                if (g_composed[k].va == planes[i]) {
+                    mine = g_composed[k];
+                    g_composed.erase(g_composed.begin() + (long)k);
+                    break;
+                }
+        }
+        if (mine.va) {
+            HIP_TRY(hipDeviceSynchronize());      // (hipFree synchronises by itself; unmapping does not)
+            release_composed(mine);
+        } else {
+            HIP_TRY(hipFree(planes[i]));
+        }
+        planes[i] = nullptr;
+    }
+    return HGI_OK;
+}
+
+}  // extern "C"

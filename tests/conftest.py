@@ -14,6 +14,7 @@ SEED0 = 0x48474930   # seeds are SEED0 + config index
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "perf: asserts a throughput floor on the device (deselect with -m 'gpu and not perf' on a shared or throttled box)")
 
 
 @pytest.fixture(scope="session")

@@ -37,6 +37,32 @@ def test_library_exports_nothing_but_the_header():
     assert exported == header_symbols(), sorted(set(exported) ^ set(header_symbols()))
 
 
+def test_release_library_reads_one_environment_variable_only():
+    """The shipped library is not an experiment bench: every tuning constant and test switch is a compile-time constant
+    (csrc/hgi_knobs.h), and the one variable it does read -- HGI_NO_PLACEMENT, documented with hgi_planes_alloc in
+    include/hgi.h -- is the only HGI_* name in its strings.  The KNOBS build of the same sources (what the forced-path GPU tests
+    load through HGI_LIB_PATH) carries the names and exports the identical ABI."""
+    import subprocess
+
+    def names(path):
+        out = subprocess.check_output(["strings", "-n", "5", path], text=True)
+        return sorted(set(l.strip() for l in out.splitlines() if re.fullmatch(r"HGI_[A-Z0-9_]+", l.strip())))
+
+    assert names(_ffi.LIB_PATH) == ["HGI_NO_PLACEMENT"], names(_ffi.LIB_PATH)
+    knobs = os.path.join(os.path.dirname(_ffi.LIB_PATH), "libhgi_hip_knobs.so")
+    assert os.path.exists(knobs), "`make -C rustyhgi_amd/csrc knobs` (or __graft_entry__.build()) builds it"
+    assert {"HGI_TILE_H", "HGI_FORCE_CHECKED", "HGI_NO_LATTICE_KERNEL", "HGI_TEST_BAND_HOLD", "HGI_NO_BANDS"} <= set(names(knobs))
+    out = subprocess.check_output(["nm", "-D", "--defined-only", knobs], text=True)
+    assert sorted(line.split()[-1] for line in out.splitlines() if line.strip()) == header_symbols()
+    # no source file of the library calls getenv outside hgi_knobs.h and the documented exception
+    csrc = os.path.join(ROOT, "rustyhgi_amd", "csrc")
+    for fn in sorted(os.listdir(csrc)):
+        if fn.endswith((".hip", ".h")) and fn != "hgi_knobs.h":
+            for line in open(os.path.join(csrc, fn)):
+                if "getenv(" in line:
+                    assert "HGI_NO_PLACEMENT" in line, "%s: %s" % (fn, line.strip())
+
+
 def test_version_and_error_strings():
     assert b"gfx950" in _ffi.lib().hgi_version()
     assert isinstance(_ffi.lib().hgi_last_error(), bytes)

@@ -34,7 +34,7 @@ def test_plain_command_launches_two_ranks():
                        env=_env(), capture_output=True, text=True, timeout=280)
     assert r.returncode == 0, r.stderr[-2000:]
     d = _one_line(r.stdout)
-    assert d["n_gpus"] == 2 and d["rehearsal"] is True and d["value"] is None and d["scaling"] == "weak"
+    assert d["n_gpus"] == 2 and d["rehearsal"] is True and d["value"] is None and d["scaling"] == "weak"      # --frames: weak
     assert d["config"]["global_frames"] == 10 and d["config"]["shards"] == [[0, 5], [5, 5]]
     assert d["config"]["levels"] == 4 and d["config"]["max_error"] == 20       # the broadcast reached rank 0's line
     for rank in (0, 1):
@@ -44,7 +44,55 @@ def test_plain_command_launches_two_ranks():
     pr = d["config"]["per_rank"]
     assert pr["planes_alloc_s"] == [0.001, 0.002] and pr["planes_separated"] == [True, True]
     assert pr["encode_ms"] == [0.5, 1.5] and pr["decode_ms"] == [0.25, 1.25] and pr["settle_steps"] == [8, 16]
-    assert pr["encode_ms_min_max"] == [0.5, 1.5] and pr["decode_ms_min_max"] == [0.25, 1.25]
+    assert pr["encode_ms_min_max"] == [0.5, 1.5] and pr["decode_ms_min_max"] == [0.25, 1.25] and pr["frames"] == [5, 5]
+
+
+def test_strong_scaling_shard_table():
+    """Default: BASELINE configs[3]'s 512 frames sharded over the ranks, "scaling": "strong" -- N = 1 is the literal config,
+    N = 8 the 64-frame shards ("1/2/4/8 GPUs x C3"); --frames F fixes the frames per GPU instead ("weak")."""
+    import bench
+    from rustyhgi_amd import batch
+    for world, per in ((1, 512), (2, 256), (4, 128), (8, 64)):
+        args = bench.parse_args(["--gpus", str(world)])
+        scaling, G = bench.shard_plan(args, world)
+        assert (scaling, G) == ("strong", 512)
+        table = [batch.shard(G, world, r) for r in range(world)]
+        assert table == [(r * per, per) for r in range(world)]
+    # a rank count that does not divide the batch (what a 6-rank rehearsal on one device runs): blocks differ by one frame,
+    # nothing is dropped, nothing is coded twice
+    table = [batch.shard(512, 6, r) for r in range(6)]
+    assert [c for _, c in table] == [86, 86, 85, 85, 85, 85] and table[0][0] == 0
+    assert all(table[r + 1][0] == table[r][0] + table[r][1] for r in range(5)) and table[5][0] + table[5][1] == 512
+    args = bench.parse_args(["--gpus", "4", "--frames", "64"])
+    assert bench.shard_plan(args, 4) == ("weak", 256)
+    args = bench.parse_args(["--gpus", "2", "--global-frames", "48"])
+    assert bench.shard_plan(args, 2) == ("strong", 48)
+
+
+@pytest.mark.timeout(600)
+def test_default_command_is_strong_scaling_over_512_frames():
+    """`python bench.py --gpus 2` as the driver runs it (no --frames): two ranks, 256 frames each, one line."""
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--rehearse", "--steps", "1", "--warmup", "0"],
+                       env=_env(), capture_output=True, text=True, timeout=280)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = _one_line(r.stdout)
+    assert d["scaling"] == "strong" and d["config"]["global_frames"] == 512 and d["config"]["shards"] == [[0, 256], [256, 256]]
+    assert d["config"]["per_rank"]["frames"] == [256, 256]
+
+
+@pytest.mark.timeout(900)
+def test_eight_rank_rehearsal():
+    """The N = 8 form of the command, rehearsed on the CPU (gloo): eight ranks join, take the 64-frame shards of the 512-frame
+    batch in rank order, every collective of the real run completes, rank 0 prints the one line."""
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "8", "--rehearse", "--steps", "1", "--warmup", "0"],
+                       env=_env(), capture_output=True, text=True, timeout=850)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = _one_line(r.stdout)
+    assert d["n_gpus"] == 8 and d["scaling"] == "strong" and d["config"]["global_frames"] == 512
+    assert d["config"]["shards"] == [[64 * k, 64] for k in range(8)]
+    assert d["config"]["per_rank"]["planes_alloc_s"] == [round(0.001 * (k + 1), 4) for k in range(8)]
+    for rank in range(8):
+        assert "rank %d/8 joined (gloo)" % rank in r.stderr
 
 
 @pytest.mark.timeout(300)
@@ -98,3 +146,29 @@ def test_two_ranks_with_the_real_codec_on_one_device():
     assert one.returncode == 0, one.stderr[-3000:]
     whole = _one_line(one.stdout)["config"]
     assert whole["sq_err_sum"] == c["sq_err_sum"]
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(900)
+def test_six_ranks_share_one_device_with_scatter_and_gather(oracle):
+    """The N-rank path of the strong-scaling command with the real codec, as many ranks as a GPU box allows on one card (six;
+    the boxes refuse more processes on a device), on an uneven shard table (50 frames over 6 ranks: 9, 9, 8, 8, 8, 8), plus the
+    labelled scatter -> code -> gather variant (`--xgmi-scatter`; here gloo through host memory: plumbing only).  The decoded
+    frames that arrive back on rank 0 must be what the oracle makes of those global frames."""
+    import hashlib
+    from conftest import SEED0
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "6", "--share-gpu", "--steps", "2", "--warmup", "1", "--global-frames", "50",
+                        "--size", "512", "--no-cpu", "--no-extras", "--placement", "torch", "--xgmi-scatter"],
+                       env=_env(), capture_output=True, text=True, timeout=860)
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = _one_line(r.stdout)
+    c = d["config"]
+    assert d["n_gpus"] == 6 and d["scaling"] == "strong" and c["global_frames"] == 50 and c["per_rank"]["frames"] == [9, 9, 8, 8, 8, 8]
+    assert len(set(c["grid_checksums"])) == 6 and c["max_abs_err"] <= 20
+    x = d["xgmi_scatter_gather"]
+    assert x["roundtrip_ok"] is True and x["frames_per_rank"] == 8 and "PLUMBING ONLY" in x["transport"]
+    lut = oracle.linear_lut(2)[0]
+    for rank, got in enumerate(x["first_gathered_frame_sha256_by_rank"]):
+        img = oracle.synth(oracle.SYNTH_RAMP, SEED0 + 3, rank * 8, 512, 512)      # the scatter leg deals 8 frames per rank from frame 0
+        want = oracle.decode(oracle.encode(img, 4, lut), 4)
+        assert got == hashlib.sha256(want.tobytes()).hexdigest()[:16], "rank %d: the gathered frame is not the oracle's" % rank

@@ -2,11 +2,12 @@
 (libhgi_hip.so) and is compared bit for bit with the CPU oracle and the committed golden vectors."""
 import ctypes
 import hashlib
+import os
 
 import numpy as np
 import pytest
 
-from conftest import SEED0
+from conftest import ROOT, SEED0
 
 pytestmark = pytest.mark.gpu
 
@@ -590,32 +591,203 @@ def test_hip_graph_capture_and_replay(H, ctxs, oracle):
     ctx.close()
 
 
-@pytest.mark.parametrize("mode", ["HGI_FORCE_CHECKED=1", "HGI_TILE_H=64", "HGI_TILE_H=32", "HGI_TILE_H=16", "HGI_NO_LATTICE_KERNEL=1",
-                                  "HGI_DEC_REVERSE=1", "HGI_CONE_MIN_ENC=5,HGI_CONE_MIN_DEC=5", "HGI_CONE_MIN_ENC=5,HGI_CONE_MIN_DEC=5,HGI_TILE_H=16",
-                                  "HGI_CONE_MIN_ENC=5,HGI_CONE_MIN_DEC=5,HGI_TILE_H=32", "HGI_CONE_MIN_ENC=5,HGI_CONE_MIN_DEC=5,HGI_TILE_H=64",
-                                  "HGI_CONE_MIN_ENC=5,HGI_CONE_MIN_DEC=5,HGI_FORCE_CHECKED=1", "HGI_NO_LATTICE_KERNEL=1,HGI_FORCE_CHECKED=1",
-                                  "HGI_CONE=0", "HGI_CONE=0,HGI_NO_LATTICE_KERNEL=1", "HGI_CONE=0,HGI_DEEP_K_ENC=4,HGI_DEEP_K_DEC=4,HGI_NO_LATTICE_KERNEL=1",
-                                  "HGI_CONE=0,HGI_DEEP_K_ENC=4,HGI_DEEP_K_DEC=4", "HGI_CONE=0,HGI_DEEP_K_ENC=5,HGI_DEEP_K_DEC=5"])
-def test_forced_code_paths_in_a_child_process(mode):
-    """The library picks tile geometry and code path per launch: 128x16, 128x32 or 128x64 tiles, and the fully checked path only
-    for widths that are not multiples of 4 or frames beyond 32-bit offsets.  Each switch is read once per process, so a
-    child process re-runs the shape-heavy parity cases with one of them forced: aligned shapes through the checked
-    path, small shapes through 64-row tiles, large ones through 32-row and (pyramids up to four levels) 16-row tiles, the
-    decoder walking its tile list backwards.  Pyramids of six to eight levels run as ONE launch that rebuilds the levels
-    above a four-level tile for itself (the cone), deeper ones code the stride-256 lattice first -- in the one-workgroup
-    lattice kernel, or (HGI_NO_LATTICE_KERNEL) by host recursion: gather, encode, decode -- and start the cone from its
-    planes.  HGI_CONE_MIN_*=5 sends five-level pyramids through the cone too, on every tile height and through the
-    fully checked path; HGI_CONE=0 switches the cone off: six fused levels (or four / five: HGI_DEEP_K_*) on seed planes of
-    the stride-2^k lattice, which is also what frames coded band by band from host memory use.  The bytes must not
-    depend on any of it."""
-    import os
+def test_two_contexts_from_two_host_threads_at_once(H, oracle):
+    """include/hgi.h: "a ctx is not thread-safe; distinct ctxs are independent" -- the contract a caller with one host thread
+    per stream or per device relies on (benches/bench.cpp --devices N; a Rust caller of src/encoder.rs:39 with a thread per
+    frame queue).  Two host threads, each with its own ctx on device 0, run different work at the same time for a few hundred
+    calls: thread A a batch of ragged 1920 x 1080 frames (level 4, Medium) through the device entry points; thread B a
+    nine-level pyramid (scratch planes: the stride-256 lattice in front of the cone), a thirteen-level host-pointer call on a
+    frame large enough to be banded (the ctx's two internal streams, registered host memory) and a level-wise pass.  Every
+    result of every iteration is compared with the oracle; ctypes releases the GIL inside the calls, so the two really overlap."""
+    import threading
+    import torch
+    from rustyhgi_amd import _ffi
+    L = _ffi.lib()
+    lut2, lut1 = oracle.linear_lut(2)[0], oracle.linear_lut(1)[0]
+    # thread A's work
+    a_host = np.stack([oracle.synth(oracle.SYNTH_NOISE, SEED0 + 41, f, 1920, 1080) for f in range(3)])
+    a_want = np.stack([oracle.encode(x, 4, lut2) for x in a_host])
+    a_back = np.stack([oracle.decode(g, 4) for g in a_want])
+    # thread B's work
+    b_host = oracle.synth(oracle.SYNTH_RAMP, SEED0 + 42, 0, 2048, 2048)
+    b_want = oracle.encode(b_host, 9, lut1)
+    b_back = oracle.decode(b_want, 9)
+    c_host = oracle.synth(oracle.SYNTH_NOISE, SEED0 + 43, 0, 4096, 1100)
+    c_want = oracle.encode(c_host, 13, lut2)
+    d_host = oracle.synth(oracle.SYNTH_XY, 0, 0, 640, 480)
+    d_want = oracle.encode(d_host, 5, lut1)
+    a_src, b_src, d_src = torch.from_numpy(a_host).cuda(), torch.from_numpy(b_host).cuda(), torch.from_numpy(d_host).cuda()
+    a_grid, a_out = torch.empty_like(a_src), torch.empty_like(a_src)
+    b_grid, b_out, d_grid = torch.empty_like(b_src), torch.empty_like(b_src), torch.empty_like(d_src)
+    torch.cuda.synchronize()
+    errors, rounds = [], {"A": 0, "B": 0}
+    start = threading.Barrier(2)
+
+    def guard(fn):
+        def run():
+            try:
+                start.wait(timeout=60)
+                fn()
+            except Exception as e:      # (surfaces in the main thread below)
+                errors.append("%s: %s" % (type(e).__name__, e))
+        return run
+
+    def thread_a():
+        ctx = H.Context(0)
+        for it in range(120):
+            _ffi.check(L.hgi_encode_u8_dev(ctx.handle, a_src.data_ptr(), 1920, 1080, 4, 1, lut2.ctypes.data, a_grid.data_ptr(), 3, 1920 * 1080))
+            _ffi.check(L.hgi_decode_u8_dev(ctx.handle, a_grid.data_ptr(), 1920, 1080, 4, 1, a_out.data_ptr(), 3, 1920 * 1080))
+            ctx.sync()
+            if it % 8 == 0:
+                assert (a_grid.cpu().numpy() == a_want).all(), "thread A: encode differs in round %d" % it
+                assert (a_out.cpu().numpy() == a_back).all(), "thread A: decode differs in round %d" % it
+                a_grid.zero_()
+                a_out.zero_()
+                torch.cuda.synchronize()
+            rounds["A"] = it + 1
+        ctx.close()
+
+    def thread_b():
+        ctx, lw = H.Context(0), H.Context(0)
+        lw.set_path(_ffi.PATH_LEVELWISE)
+        for it in range(12):
+            _ffi.check(L.hgi_encode_u8_dev(ctx.handle, b_src.data_ptr(), 2048, 2048, 9, 1, lut1.ctypes.data, b_grid.data_ptr(), 1, 2048 * 2048))
+            _ffi.check(L.hgi_decode_u8_dev(ctx.handle, b_grid.data_ptr(), 2048, 2048, 9, 1, b_out.data_ptr(), 1, 2048 * 2048))
+            ctx.sync()
+            assert (b_grid.cpu().numpy() == b_want).all(), "thread B: nine-level encode differs in round %d" % it
+            assert (b_out.cpu().numpy() == b_back).all(), "thread B: nine-level decode differs in round %d" % it
+            assert (gpu_encode(ctx, c_host, 13, lut2) == c_want).all(), "thread B: banded host encode differs in round %d" % it
+            _ffi.check(L.hgi_encode_u8_dev(lw.handle, d_src.data_ptr(), 640, 480, 5, 1, lut1.ctypes.data, d_grid.data_ptr(), 1, 640 * 480))
+            lw.sync()
+            assert (d_grid.cpu().numpy() == d_want).all(), "thread B: level-wise encode differs in round %d" % it
+            rounds["B"] = it + 1
+        ctx.close()
+        lw.close()
+
+    threads = [threading.Thread(target=guard(thread_a)), threading.Thread(target=guard(thread_b))]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=600)
+    assert not any(t.is_alive() for t in threads), "a thread did not finish"
+    assert not errors, errors
+    assert rounds == {"A": 120, "B": 12}
+
+
+@pytest.mark.perf
+def test_throughput_floor_c3_shard_and_c4(H, oracle, golden):
+    """A performance regression must not pass the GPU suite unnoticed: the 64-frame C3 shard (64 x 4096^2, level 4, Medium) and
+    C4 (one 16384^2 frame, level 8, High) through the C ABI, timed by hgi_timer_* after the clocks have settled, must reach
+    0.65 of the 8 TB/s HBM peak at 2 B/px in BOTH directions -- a loose floor: the bench line stands at 0.72-0.76 (BASELINE.md
+    section 4's bar is 0.70; profiles/r04_summary.md), so this trips on a ~10 % slowdown, not on box-to-box noise.  The best of
+    three measurement rounds counts; planes come from hgi_planes_alloc and the floor holds whether or not it could separate them
+    (plain placement costs 2-5 %).  Also re-checks C4's grid against the golden hash, so the timed launches are the right ones."""
+    import hashlib
+    import torch
+    from rustyhgi_amd import _ffi
+    L = _ffi.lib()
+    ctx = H.Context(0)
+    PEAK = 8e12
+
+    def measure(w, h, levels, q, frames, kind, seed):
+        n = w * h
+        planes = H.Planes(ctx, frames * n, 3)
+        img, grid, out = planes.pointers
+        lut = oracle.linear_lut(q)[0]
+        _ffi.check(L.hgi_synth_u8_dev(ctx.handle, kind, seed, 0, w, h, img, frames, n))
+        ctx.reserve(w, h, levels, frames)
+
+        def enc():
+            _ffi.check(L.hgi_encode_u8_dev(ctx.handle, img, w, h, levels, 1, lut.ctypes.data, grid, frames, n))
+
+        def dec():
+            _ffi.check(L.hgi_decode_u8_dev(ctx.handle, grid, w, h, levels, 1, out, frames, n))
+
+        def timed(fn):
+            ctx.timer_start()
+            fn()
+            return ctx.timer_stop()
+
+        # settle: the clocks ramp for ~25 ms after idle (DESIGN.md 6) -- untimed steps until two groups agree
+        last = None
+        for _ in range(40):
+            ctx.timer_start()
+            for _ in range(8):
+                enc()
+                dec()
+            ms = ctx.timer_stop()
+            if last is not None and abs(ms - last) <= 0.005 * last:
+                break
+            last = ms
+        best_e = best_d = float("inf")
+        for _ in range(3):
+            es, ds = [], []
+            for _ in range(10):
+                es.append(timed(enc))
+                ds.append(timed(dec))
+            best_e, best_d = min(best_e, float(np.mean(es))), min(best_d, float(np.mean(ds)))
+        ctx.sync()
+        view = planes.torch(1, (frames, h, w))
+        sha = hashlib.sha256(view[0].cpu().numpy().tobytes()).hexdigest()
+        del view
+        sep = planes.separated
+        planes.close()
+        alg = 2.0 * frames * n
+        return alg / (best_e * 1e-3) / PEAK, alg / (best_d * 1e-3) / PEAK, sep, sha
+
+    e, d, sep, _ = measure(4096, 4096, 4, 2, 64, _ffi.SYNTH_RAMP, SEED0 + 3)
+    print("C3 shard: encode %.3f decode %.3f of 8 TB/s (planes separated: %s)" % (e, d, sep))
+    assert e >= 0.65 and d >= 0.65, "C3 shard below the floor: encode %.3f decode %.3f of 8 TB/s" % (e, d)
+    e, d, sep, sha = measure(16384, 16384, 8, 3, 1, _ffi.SYNTH_RAMP, SEED0 + 4)
+    print("C4: encode %.3f decode %.3f of 8 TB/s (planes separated: %s)" % (e, d, sep))
+    assert sha == golden["ramp4_16384/L8/q3/i1"]["sha_grid"], "C4 grid differs from the golden hash"
+    assert e >= 0.65 and d >= 0.65, "C4 below the floor: encode %.3f decode %.3f of 8 TB/s" % (e, d)
+    ctx.close()
+
+
+def knobs_env(**switches):
+    """Environment of a child process that runs on the KNOBS build of the library (`make knobs`: the same sources with every
+    tuning constant and test switch of csrc/hgi_knobs.h read from the environment; the release library reads none of them).
+    HGI_LIB_PATH is read by the Python binding, not by the library."""
+    from rustyhgi_amd import _ffi
+    knobs = os.path.join(os.path.dirname(_ffi.LIB_PATH), "libhgi_hip_knobs.so")
+    assert os.path.exists(knobs), "libhgi_hip_knobs.so is missing: __graft_entry__.build() / `make -C rustyhgi_amd/csrc knobs` builds it"
+    return dict(os.environ, HGI_LIB_PATH=knobs, **switches)
+
+
+def test_release_library_ignores_the_switches_and_the_knobs_build_is_what_the_children_load():
+    """The forced-path tests below only mean something if (a) their children really run on the knobs build and (b) the
+    release library cannot be steered from the environment: a switch that would change its answer must not."""
     import subprocess
     import sys
-    env = dict(os.environ, **dict(kv.split("=") for kv in mode.split(",")))
+    probe = ("import os, sys; sys.path.insert(0, %r); from rustyhgi_amd import _ffi; "
+             "print(_ffi.lib().hgi_version().decode())" % ROOT)
+    out = subprocess.run([sys.executable, "-c", probe], env=knobs_env(), capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and "KNOBS build" in out.stdout, out.stdout + out.stderr
+    out = subprocess.run([sys.executable, "-c", probe], env=dict(os.environ, HGI_TILE_H="32"), capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and "KNOBS" not in out.stdout and "gfx950" in out.stdout, out.stdout + out.stderr
+
+
+@pytest.mark.parametrize("mode", ["HGI_FORCE_CHECKED=1", "HGI_TILE_H=64", "HGI_TILE_H=32", "HGI_TILE_H=16", "HGI_NO_LATTICE_KERNEL=1",
+                                  "HGI_DEC_REVERSE=1", "HGI_NO_LATTICE_KERNEL=1,HGI_FORCE_CHECKED=1", "HGI_NO_LATTICE_KERNEL=1,HGI_TILE_H=16",
+                                  "HGI_NO_BANDS=1"])
+def test_forced_code_paths_in_a_child_process(mode):
+    """The library picks tile geometry and code path per launch: 128x16, 128x32 or 128x64 tiles, and the fully checked path only
+    for widths that are not multiples of 4 or frames beyond 32-bit offsets.  A child process on the KNOBS build re-runs the
+    shape-heavy parity cases with one of those choices forced: aligned shapes through the checked path, small shapes through
+    64-row tiles, large ones through 32-row and (pyramids up to four levels) 16-row tiles, the decoder walking its tile list
+    backwards, large host frames without bands.  Pyramids of six to eight levels run as ONE launch that rebuilds the levels
+    above a four-level tile for itself (the cone) -- on every tile height; deeper ones code the stride-256 lattice first -- in
+    the one-workgroup lattice kernel, or, for planes beyond 8 192 points (here: HGI_NO_LATTICE_KERNEL), by host recursion:
+    gather, encode, decode -- and start the cone from its planes.  The bytes must not depend on any of it."""
+    import subprocess
+    import sys
+    env = knobs_env(**dict(kv.split("=") for kv in mode.split(",")))
     here = os.path.dirname(os.path.abspath(__file__))
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(here, "test_parity_gpu.py"), "-m", "gpu", "-q", "-x",
                         "-p", "no:cacheprovider", "-k",
-                        "small_golden or lena_and_fullhd or random_shapes or smooth_images or batch_layouts or fuzz or extreme or deep_pyramid"],
+                        "small_golden or lena_and_fullhd or random_shapes or smooth_images or batch_layouts or fuzz or extreme or deep_pyramid"
+                        + (" or banded_host_frames" if "NO_BANDS" in mode else "")],
                        env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, mode + "\n" + r.stdout[-3000:] + r.stderr[-1000:]
 
@@ -624,7 +796,7 @@ def test_forced_code_paths_in_a_child_process(mode):
 def test_deep_pyramid_plane_of_whole_tiles(H, oracle, w, h, levels, batch):
     """Frames of whole tiles whose pyramids are deeper than a tile, in batches: six to eight levels in one launch (the cone
     on interior tiles only), nine through the stride-256 lattice first; the forced-path child processes re-run them with
-    the cone off and the lattice kernel off.  Bytes must not depend on it."""
+    every tile height forced and the lattice kernel off.  Bytes must not depend on it."""
     import torch
     from rustyhgi_amd import _ffi
     L = _ffi.lib()
@@ -837,20 +1009,31 @@ def test_banded_deep_pyramid_first_call_on_fresh_context(H, oracle, w, h, levels
     ctx = H.Context(0)
     assert_same(gpu_decode(ctx, want, levels), oracle.decode(want, levels), "first call, banded decode %dx%d L%d" % (w, h, levels))
     ctx.close()
+    # ... and hgi_ctx_reserve covers it (include/hgi.h: a reserved ctx does not re-allocate its scratch, which captured graphs
+    # that use scratch rely on): the host-pointer calls after reserve() leave the scratch exactly as reserve() sized it
+    ctx = H.Context(0)
+    assert ctx.scratch_bytes() == 0
+    ctx.reserve(w, h, levels, 1)
+    reserved = ctx.scratch_bytes()
+    assert reserved > 0
+    assert_same(gpu_encode(ctx, img, levels, lut), want, "reserved ctx, banded encode %dx%d L%d" % (w, h, levels))
+    assert_same(gpu_decode(ctx, want, levels), oracle.decode(want, levels), "reserved ctx, banded decode %dx%d L%d" % (w, h, levels))
+    assert ctx.scratch_bytes() == reserved, "a host-pointer call grew the scratch of a reserved ctx (%d -> %d)" % (reserved, ctx.scratch_bytes())
+    ctx.close()
 
 
 def test_banded_bands_never_read_rows_of_the_next_upload():
     """Deterministic form of the band / halo dependency (a tile of a band's last tile row reads input rows down to
-    offset 2^k = 64 below the band INCLUSIVE at levels = 6: 65 rows, not 64).  HGI_TEST_BAND_HOLD poisons the device
-    input with 0xFF and holds band b + 1's upload until band b's kernel has finished, so a kernel that depended on a row
-    outside its own upload reads poison every time instead of almost never.  One child process, run once."""
-    import os
+    offset 2^k = 64 below the band INCLUSIVE at levels = 6: 65 rows, not 64).  The hook exists in the KNOBS build only
+    (HGI_TEST_BAND_HOLD; compiled out of the release library): it poisons the device input with 0xFF and holds band b + 1's
+    upload until band b's kernel has finished, so a kernel that depended on a row outside its own upload reads poison every
+    time instead of almost never.  One child process, run once."""
     import subprocess
     import sys
     here = os.path.dirname(os.path.abspath(__file__))
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(here, "test_parity_gpu.py"), "-m", "gpu", "-q", "-x",
                         "-p", "no:cacheprovider", "-k", "test_banded_host_frames"],
-                       env=dict(os.environ, HGI_TEST_BAND_HOLD="1"), capture_output=True, text=True, timeout=900)
+                       env=knobs_env(HGI_TEST_BAND_HOLD="1"), capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-1000:]
 
 
@@ -1016,6 +1199,17 @@ def test_device_entropy_stage_batch(H, oracle, lena):
     assert offs[0] == 0 and all(o % 64 == 0 for o in offs) and all(offs[f + 1] >= offs[f] + sizes[f] for f in range(4))
     for f in range(5):
         assert buf[offs[f]:offs[f] + sizes[f]].tobytes() == streams[f], f
+    # the alignment gaps between the streams are part of what came down with a group's one copy: they must not carry stale
+    # device scratch into the caller's buffer -- zero, whatever ran before (here: the call above, on other data, and a buffer
+    # pre-filled with 0xA5)
+    other = torch.from_numpy(np.ascontiguousarray(grids[::-1])).cuda()
+    for data in (other, d):
+        fill = np.full(5 * (w * h + w * h // 8 + 1088), 0xA5, np.uint8)
+        b2, o2, s2 = entropy.deflate_grids_packed(data, out=fill)
+        for f in range(5):
+            gap = b2[o2[f] + s2[f]:o2[f] + (s2[f] + 63) // 64 * 64]
+            assert not gap.any(), "frame %d: %d stale bytes behind its stream" % (f, int(np.count_nonzero(gap)))
+        assert (b2[o2[4] + (s2[4] + 63) // 64 * 64:] == 0xA5).all()      # ... and nothing beyond the packed region is touched
     small = np.empty(offs[4] + sizes[4] - 1, np.uint8)          # one byte short of what the five streams need
     with pytest.raises(_ffi_error()):
         entropy.deflate_grids_packed(d, out=small)

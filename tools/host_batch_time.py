@@ -28,7 +28,7 @@ for (B, W, Hh) in [(32, 1920, 1080), (16, 4096, 4096), (64, 4096, 4096), (256, 5
     print("%3d x %4dx%4d host frames: encode one by one %8.2f ms (%5.1f GB/s in)  batch call %8.2f ms (%5.1f GB/s in, %.2fx)  decode batch %8.2f ms" % (
         B, W, Hh, t1 * 1e3, gb / t1, t2 * 1e3, gb / t2, t1 / t2, t3 * 1e3))
 
-# one large frame at a time: the banded host path (HGI_NO_BANDS=1 in the environment turns it off)
+# one large frame at a time: the banded host path (on the KNOBS build -- HGI_LIB_PATH=rustyhgi_amd/libhgi_hip_knobs.so -- HGI_NO_BANDS=1 turns it off)
 for (W, Hh, LV) in [(1920, 1080, 4), (4096, 4096, 4), (8192, 8192, 4), (16384, 16384, 4), (16384, 16384, 8)]:
     src = np.random.default_rng(2).integers(0, 256, (Hh, W), dtype=np.uint8); dst = np.empty_like(src); back = np.empty_like(src)
     te = best(lambda: _ffi.check(L.hgi_encode_u8(ctx.handle, src.ctypes.data, W, Hh, LV, 1, lut.ctypes.data, dst.ctypes.data)))
