@@ -45,4 +45,19 @@ extern "C" {
     /// include/hgi.h: per-frame byte histogram of a grid batch on the device (d_hist: 256 * batch u64)
     pub fn hgi_histogram_u8_dev(ctx: *mut HgiCtx, d_grid: *const c_void, width: u32, height: u32, batch: usize,
                                 frame_stride: usize, d_hist: *mut c_void) -> c_int;
+    // ---- what a caller that owns device memory needs (examples/multi_device.rs: one thread + one ctx per GPU) ----
+    /// pre-size the ctx's scratch for `batch` frames of this shape (nothing is allocated by later calls)
+    pub fn hgi_ctx_reserve(ctx: *mut HgiCtx, width: u32, height: u32, levels: u32, batch: usize) -> c_int;
+    pub fn hgi_ctx_scratch_bytes(ctx: *mut HgiCtx, bytes: *mut usize) -> c_int;
+    /// `count` device planes of at least `bytes`, neighbours in different HBM classes (release with hgi_planes_free only)
+    pub fn hgi_planes_alloc(ctx: *mut HgiCtx, bytes: usize, count: u32, planes: *mut *mut c_void, separated: *mut c_int) -> c_int;
+    pub fn hgi_planes_free(ctx: *mut HgiCtx, count: u32, planes: *mut *mut c_void) -> c_int;
+    /// synthetic frames generated in place (kind 0 xy = benches/bench.rs:26-28, 1 noise, 2 ramp; frame f uses index first_frame + f)
+    pub fn hgi_synth_u8_dev(ctx: *mut HgiCtx, kind: c_int, seed: u64, first_frame: u64, width: u32, height: u32,
+                            d_out: *mut c_void, batch: usize, frame_stride: usize) -> c_int;
+    /// per-frame [sum of squared differences, max |difference|, differing pixels] of before / after pairs (src/main.rs:84-92)
+    pub fn hgi_diff_stats_dev(ctx: *mut HgiCtx, d_before: *const c_void, d_after: *const c_void, width: u32, height: u32,
+                              batch: usize, frame_stride: usize, d_out: *mut c_void) -> c_int;
+    pub fn hgi_timer_start(ctx: *mut HgiCtx) -> c_int;
+    pub fn hgi_timer_stop(ctx: *mut HgiCtx, elapsed_ms: *mut f32) -> c_int;
 }

@@ -43,7 +43,7 @@ extern crate serde;
 #[macro_use]
 extern crate serde_derive;
 
-mod ffi;
+pub mod ffi;      // (public: examples/multi_device.rs drives the device entry points directly)
 
 use image::GrayImage;
 use std::cell::RefCell;

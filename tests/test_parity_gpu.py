@@ -1075,6 +1075,56 @@ def test_planes_alloc_places_neighbours_in_different_regions(H, oracle):
     ctx.close()
 
 
+def test_planes_larger_than_a_chunk_are_composed_and_released(H, oracle):
+    """Planes above 1 GiB (the literal C3 batch has three of 8 GiB) are not single allocations: each is one reserved address
+    range onto which 1 GiB physical chunks are mapped, chosen so that neighbouring planes sit on chunks of different memory
+    classes at every offset (include/hgi.h, hgi_planes_alloc; csrc/hgi_planes.hip).  To a caller they must behave like any device
+    buffer: torch views them, the codec is bit-exact across the chunk boundaries, a download works, and hgi_planes_free gives
+    every byte back (twice is harmless: the pointers are cleared)."""
+    import ctypes
+    import torch
+    from rustyhgi_amd import _ffi
+    L = _ffi.lib()
+    ctx = H.Context(0)
+    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    free0 = torch.cuda.mem_get_info()[0]
+    F, S = 160, 4096                                     # 2.5 GiB per plane: three chunks each, the last one partly used
+    planes = H.Planes(ctx, F * S * S, 3)
+    assert len(set(planes.pointers)) == 3 and all(planes.pointers)
+    assert torch.cuda.mem_get_info()[0] <= free0 - 3 * (3 << 30) + (64 << 20)      # whole GiB chunks are what is held
+    img, grid, out = (planes.torch(i, (F, S, S)) for i in range(3))
+    _ffi.check(L.hgi_synth_u8_dev(ctx.handle, _ffi.SYNTH_RAMP, SEED0 + 3, 0, S, S, img.data_ptr(), F, S * S))
+    lut = oracle.linear_lut(2)[0]
+    _ffi.check(L.hgi_encode_u8_dev(ctx.handle, img.data_ptr(), S, S, 4, 1, lut.ctypes.data, grid.data_ptr(), F, S * S))
+    _ffi.check(L.hgi_decode_u8_dev(ctx.handle, grid.data_ptr(), S, S, 4, 1, out.data_ptr(), F, S * S))
+    torch.cuda.synchronize()
+    for f in (0, 63, 64, 127, 128, F - 1):                # frames on both sides of the two chunk boundaries (64 frames per GiB)
+        want = oracle.encode(oracle.synth(oracle.SYNTH_RAMP, SEED0 + 3, f, S, S), 4, lut)
+        assert_same(grid[f].cpu().numpy(), want, "encode on composed planes, frame %d" % f)
+        assert_same(out[f].cpu().numpy(), oracle.decode(want, 4), "decode on composed planes, frame %d" % f)
+    # a torch kernel that runs across a boundary, and a device-to-device copy out of a plane
+    assert int(grid[60:68].to(torch.int64).sum()) == int(grid[60:68].cpu().to(torch.int64).sum())
+    clone = out[126:130].clone()
+    assert torch.equal(clone, out[126:130])
+    if planes.separated:      # then every GiB offset of both neighbouring pairs streams at the fast rate
+        for _ in range(6):
+            planes.probe_ms(0, 1)
+        ms = ctypes.c_float(0)
+        t = {}
+        for a, b in ((0, 1), (1, 2)):
+            for m in range(2):
+                _ffi.check(L.hgi_probe_pair_u8_dev(ctx.handle, planes.pointers[a] + (m << 30), planes.pointers[b] + (m << 30), 1 << 30, ctypes.byref(ms)))
+                t[(a, b, m)] = ms.value
+        assert max(t.values()) <= 1.04 * min(t.values()), t
+    del img, grid, out, clone
+    planes.close()
+    planes.close()
+    torch.cuda.synchronize()
+    assert torch.cuda.mem_get_info()[0] >= free0 - (64 << 20), "hgi_planes_free did not return the chunks"
+    ctx.close()
+
+
 @pytest.mark.parametrize("w,h,levels,q", [(256, 256, 4, 2), (256, 256, 4, 0), (1920, 1080, 4, 2), (13, 7, 3, 1), (1, 1, 0, 0),
                                           (4096, 4096, 4, 2), (1001, 999, 5, 3), (3, 1, 1, 0), (1920, 1080, 4, 3), (1025, 3, 1, 3)])
 def test_device_entropy_stage_writes_ordinary_deflate(H, oracle, lena, w, h, levels, q):

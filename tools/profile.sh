@@ -1,12 +1,15 @@
 #!/bin/bash
 # rocprofv3 collection for bench.py on the GPU box.  Writes raw output under gpurun_out/prof/<tag>/
 # and a compact summary gpurun_out/prof/<tag>/summary.md (copy that into profiles/).
-#   tools/profile.sh <tag> [bench args...]
+#   tools/profile.sh <tag> [bench args...]           FRAMES=512 (default: the literal C3 on one GPU) or FRAMES=64 (its 8-GPU shard)
+# The traffic record (traffic.json -> profiles/<tag>_traffic.json) carries the build stamp of the library it was taken on
+# (bench.build_stamp(): hash of the library's sources + of the loaded .so + git HEAD); bench.py refuses a record of another build.
 # Passes are separate on purpose: kernel-trace/stats alone, then one --pmc pass per counter group
 # (FETCH_SIZE and WRITE_SIZE do not fit one TCC pass; never mix --pmc with API tracing).
 set -u
 TAG=${1:-r01}; shift || true
-ARGS=${@:---steps 20 --warmup 3 --no-cpu --no-extras}
+FRAMES=${FRAMES:-512}
+ARGS=${@:---steps 20 --warmup 3 --no-cpu --no-extras --frames $FRAMES}
 PASSES=${PASSES:-trace fetch write sq1 sq2 tcc pfine}
 OUT=$PWD/gpurun_out/prof/$TAG
 mkdir -p "$OUT"
@@ -30,7 +33,7 @@ case " $PASSES " in *" pfine "*)
 esac
 # C4 (one 16384^2 frame, level 8) has a script of its own: tools/c4_profile.sh <tag>_c4 -> gpurun_out/prof/<tag>_c4/summary.md
 case " $PASSES " in *" c4 "*) tools/c4_profile.sh "${TAG}_c4" > "$OUT/c4.log" 2>&1; echo "c4 rc=$?" >> "$OUT/passes.log";; esac
-python3 tools/summarize_prof.py "$OUT" > "$OUT/summary.md" 2>"$OUT/summarize.err"
-python3 tools/summarize_prof.py "$OUT" --traffic 64 4096 4 > "$OUT/traffic.json" 2>>"$OUT/summarize.err"
+HGI_PROF_FRAMES=$FRAMES python3 tools/summarize_prof.py "$OUT" > "$OUT/summary.md" 2>"$OUT/summarize.err"
+python3 tools/summarize_prof.py "$OUT" --traffic $FRAMES 4096 4 > "$OUT/traffic.json" 2>>"$OUT/summarize.err"
 cat "$OUT/passes.log"
 tail -60 "$OUT/summary.md"

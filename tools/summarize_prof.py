@@ -16,8 +16,27 @@ def short(name):
     return name.split("(")[0][:70]
 
 
+def stamp():
+    """The build the profile was taken on: bench.build_stamp() (source hash, .so hash, version) + git HEAD when there is one."""
+    import subprocess
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    st = bench.build_stamp()
+    try:
+        st["git_head"] = subprocess.check_output(["git", "rev-parse", "--short=12", "HEAD"], cwd=bench.ROOT, text=True,
+                                                 stderr=subprocess.DEVNULL).strip()
+    except Exception:
+        st["git_head"] = None      # (the GPU box receives a snapshot without .git)
+    return st
+
+
 def main(out):
+    frames = int(os.environ.get("HGI_PROF_FRAMES", "512"))
     print("# rocprofv3 summary: %s\n" % os.path.basename(out))
+    st = stamp()
+    print("workload: `bench.py --frames %d` (%d x 4096^2 u8 ramp(3), level 4, Medium, Crossed); algorithmic bytes per launch %d\n"
+          % (frames, frames, 2 * frames * 4096 * 4096))
+    print("build: source %s, %s %s, %s\n" % (st.get("source_sha256"), st.get("lib"), st.get("lib_sha256"), st.get("version")))
     traces = glob.glob(os.path.join(out, "trace", "**", "*kernel_trace.csv"), recursive=True)
     dur = defaultdict(list)
     for path in traces:
@@ -29,6 +48,13 @@ def main(out):
     for k, v in sorted(dur.items(), key=lambda kv: -sum(kv[1])):
         print("| %s | %d | %.2f | %.2f | %.2f | %.3f |" % (k, len(v), sum(v) / len(v) / 1e3, min(v) / 1e3,
                                                            max(v) / 1e3, sum(v) / 1e6))
+    alg = 2.0 * frames * 4096 * 4096
+    print("\nagainst the roofline (2 B/px per direction, 8 TB/s), the workload's launches only (Crossed: `k_*_tiles<1, ...>`; warm-up and"
+          " settle launches included):\n")
+    for k, v in sorted(dur.items()):
+        if k.startswith(("k_enc_tiles<1", "k_dec_tiles<1")):
+            avg = sum(v) / len(v)
+            print("- `%s`: %.2f us average -> %.0f GB/s = **%.3f** of 8 TB/s" % (k, avg / 1e3, alg / avg, alg / avg / 8000))
     pf = defaultdict(list)
     for path in glob.glob(os.path.join(out, "pfine", "**", "*kernel_trace.csv"), recursive=True):
         for row in csv.DictReader(open(path)):
@@ -107,7 +133,7 @@ def traffic_json(out, frames, size, levels):
         if k.startswith("k_") and "FETCH_SIZE" in c and "WRITE_SIZE" in c:
             kernels[k] = {"fetch_kb_raw": c["FETCH_SIZE"], "write_kb": c["WRITE_SIZE"],
                           "hbm_bytes_per_launch": int((2 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024)}
-    print(json.dumps({"workload": {"frames": frames, "size": size, "levels": levels},
+    print(json.dumps({"workload": {"frames": frames, "size": size, "levels": levels}, "build": stamp(),
                       "method": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes), bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024",
                       "kernels": kernels}, indent=1))
 
