@@ -218,8 +218,9 @@ HGI_API hgi_status hgi_huffman_plan(const uint64_t hist[286], uint8_t lens[286],
 /*    to ten extra candidates and spacers when the first ones share a class);                  */
 /*  - above 1 GiB: each plane is one reserved address range onto which physical chunks of      */
 /*    1 GiB (hipMemCreate) are mapped, chosen chunk by chunk (size rounded up to whole GiB).   */
-/*    Bounded: at most 3 x the requested bytes are ever created; what is not handed out is     */
-/*    released before the call returns (three planes of 8 GiB: about a second).                */
+/*    Bounded: at most 3 x the requested bytes are ever created as candidates, plus at most    */
+/*    96 GiB of never-mapped spacers when the driver keeps handing out one class; what is not  */
+/*    handed out is released before the call returns (three planes of 8 GiB: 0.5-2 s).         */
 /* HGI_NO_PLACEMENT=1 in the environment skips all of it (plain allocations): the one variable */
 /* the library reads.  Call it while the device is otherwise idle: it measures.                */
 HGI_API hgi_status hgi_planes_alloc(hgi_ctx *ctx, size_t bytes, uint32_t count, void **planes, int *separated);

@@ -15,7 +15,8 @@
 //     in one class, so a plane is COMPOSED -- physical chunks of 1 GiB (hipMemCreate) are classified one by one and mapped
 //     behind one another into one reserved address range per plane (hipMemAddressReserve / hipMemMap) such that at every
 //     offset neighbouring planes sit on chunks of different classes (round 4; alloc_composed).  The search is bounded by
-//     bytes: at most 3 x the requested chunks are ever created, everything not handed out is released.
+//     bytes: at most 3 x the requested chunks are ever created (plus at most 96 GiB of never-mapped spacers when the driver
+//     keeps handing out one class), every pair is checked before the planes are built, everything not handed out is released.
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 #include <stdlib.h>
