@@ -20,7 +20,9 @@
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 #include <stdlib.h>
+#include <array>
 #include <mutex>
+#include <utility>
 #include <vector>
 
 #include "hgi_host.h"
@@ -393,7 +395,7 @@ hgi_status alloc_composed(hgi_ctx *c, size_t bytes, uint32_t count, void **plane
     int last_group = -1;
     auto ptr_of = [&](int j) { return stage + (size_t)j * kChunk; };
     std::vector<std::vector<int>> lineup;      // [offset][plane] -> chunk
-    bool ok = false;
+    bool ok = false, sided = false;
     size_t spacer_gib = 4, spacer_total = 0;
     const size_t spacer_budget = room > max_chunks ? (room - max_chunks < 96 ? room - max_chunks : 96) : 0;      // GiB (kChunk is one)
     const bool trace = HGI_SWITCH(HGI_PLANES_TRACE);
@@ -437,11 +439,60 @@ hgi_status alloc_composed(hgi_ctx *c, size_t bytes, uint32_t count, void **plane
             if (st != HGI_OK) return bail(st);
         }
         if (h.size() < need) return bail(fail(HGI_ENOMEM, "hipMemCreate: the device ran out of memory after %zu of %zu chunks", h.size(), need));
-        // line-up per offset
+        // Line-up, first choice: TWO SIDES.  The groups are split into a side for the even planes (image, image') and a side for
+        // the odd ones (grid), so that EVERY chunk of a plane differs in class from EVERY chunk of its neighbours, not only the
+        // one at the same offset.  That is what a launch dealt to the XCDs as contiguous eighths needs (hgi_fused_impl.h,
+        // xcd_mode(): from 6 GiB per plane the eight XCDs work on eight different chunks of each plane at one time): with a
+        // per-offset line-up whose sides flip along the plane, one XCD reads class A and writes B while another reads B and
+        // writes A, and the encoder loses 2-5 % (2.67 -> 2.71 ... 2.81 ms per 512 frames, profiles/r04_planes_sides.txt).
+        lineup.clear();
+        ok = false;
+        sided = false;
+        const size_t G = groups.size(), need_even = n * ((count + 1) / 2), need_odd = n * (count / 2);
+        if (G >= 2 && G <= 16) {
+            size_t best = 0, best_score = 0;
+            for (size_t mask = 1; mask + 1 < ((size_t)1 << G); ++mask) {
+                size_t x = 0, y = 0, xmax = 0, ymax = 0;
+                for (size_t g = 0; g < G; ++g) {
+                    const size_t sz = groups[g].size();
+                    if ((mask >> g) & 1) {
+                        x += sz;
+                        xmax = sz > xmax ? sz : xmax;
+                    } else {
+                        y += sz;
+                        ymax = sz > ymax ? sz : ymax;
+                    }
+                }
+                // feasible, and as uniform as can be: the largest group of each side should carry as much of it as possible
+                const size_t score = (xmax < need_even ? xmax : need_even) + (ymax < need_odd ? ymax : need_odd);
+                if (x >= need_even && y >= need_odd && score > best_score) {
+                    best = mask;
+                    best_score = score;
+                }
+            }
+            if (best) {
+                std::vector<size_t> by_size(G);
+                for (size_t g = 0; g < G; ++g) by_size[g] = g;
+                for (size_t a = 0; a < G; ++a)
+                    for (size_t b = a + 1; b < G; ++b)
+                        if (groups[by_size[b]].size() > groups[by_size[a]].size()) std::swap(by_size[a], by_size[b]);
+                std::vector<int> side[2];      // [0] even planes, [1] odd planes; members of the larger groups first
+                for (size_t g : by_size)
+                    for (int j : groups[g]) side[(best >> g) & 1 ? 0 : 1].push_back(j);
+                for (size_t m = 0; m < n; ++m) {
+                    std::vector<int> row;
+                    for (uint32_t i = 0; i < count; ++i) row.push_back(side[i & 1][(size_t)(i / 2) * n + m]);
+                    lineup.push_back(row);
+                }
+                ok = sided = true;
+            }
+        }
+        if (ok) break;
+        if (h.size() < max_chunks) continue;      // more chunks (and spacers) first
+        // second choice, at the end of the budget: per offset -- neighbouring planes differ at every offset, the sides may flip
         std::vector<size_t> left(groups.size());
         for (size_t g = 0; g < groups.size(); ++g) left[g] = groups[g].size();
         std::vector<size_t> next(groups.size(), 0);
-        lineup.clear();
         ok = true;
         for (size_t m = 0; m < n && ok; ++m) {
             const std::vector<int> seq = arrange(left, count);
@@ -453,7 +504,7 @@ hgi_status alloc_composed(hgi_ctx *c, size_t bytes, uint32_t count, void **plane
             for (int g : seq) row.push_back(groups[(size_t)g][next[(size_t)g]++]);
             lineup.push_back(row);
         }
-        if (ok || h.size() >= max_chunks) break;
+        break;
     }
     if (!ok) {
         // could not be established within the budget: the offsets that did line up stay as they are (a partly separated stream
@@ -475,7 +526,7 @@ hgi_status alloc_composed(hgi_ctx *c, size_t bytes, uint32_t count, void **plane
     if (trace) {
         fprintf(stderr, "hgi_planes_alloc: %zu chunks created, %zu GiB of spacers, %zu groups:", h.size(), spacer_total, groups.size());
         for (auto &g : groups) fprintf(stderr, " %zu", g.size());
-        fprintf(stderr, " -> line-up %s\n", ok ? "complete" : "INCOMPLETE");
+        fprintf(stderr, " -> line-up %s\n", !ok ? "INCOMPLETE" : sided ? "complete, two sides" : "complete, per offset");
     }
     // What the probes said chunk against group representative, checked pair by pair as the planes will hold them: at every
     // chunk offset every neighbouring pair must stream at the fast rate (this is what the caller is promised).  A pair that
@@ -488,6 +539,10 @@ hgi_status alloc_composed(hgi_ctx *c, size_t bytes, uint32_t count, void **plane
         std::vector<char> used(h.size(), 0);
         for (auto &row : lineup)
             for (int j : row) used[(size_t)j] = 1;
+        // which side(s) a group supplies in this line-up: [group][0 even planes, 1 odd planes]
+        std::vector<std::array<char, 2>> on_side(groups.size(), std::array<char, 2>{{0, 0}});
+        for (auto &row : lineup)
+            for (uint32_t i = 0; i < count; ++i) on_side[(size_t)group_of[(size_t)row[i]]][i & 1] = 1;
         auto fast = [&](int a, int b, bool *yes) -> hgi_status {
             float ratio = 0;
             const hgi_status st = y.other_class(c, ptr_of(a), ptr_of(b), yes, &ratio);
@@ -503,6 +558,7 @@ hgi_status alloc_composed(hgi_ctx *c, size_t bytes, uint32_t count, void **plane
                 int tries = 0;
                 for (size_t u = 0; u < h.size() && !yes && tries < 4; ++u) {
                     if (used[u] || group_of[u] == group_of[(size_t)lineup[m][i]] || group_of[u] == group_of[(size_t)lineup[m][i + 1]]) continue;
+                    if (sided && !on_side[(size_t)group_of[u]][(i + 1) & 1]) continue;      // (the two sides stay what they are)
                     if (i + 2 < count && group_of[u] == group_of[(size_t)lineup[m][i + 2]]) continue;
                     ++tries;
                     bool a = false, b = true;
