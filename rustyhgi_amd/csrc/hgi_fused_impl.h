@@ -118,7 +118,7 @@ static_assert(TH != 64 || 18 * (buf_bytes(4) + rbuf_bytes(4) + 256) <= 160 * 102
 #define HGI_XCD_MODE -1     // the XCD dealing policy (block_role): 0 contiguous eighths, 1 whole bands round-robin, -1 by size (xcd_mode())
 #endif
 #ifndef HGI_XCD_EIGHTHS_FROM_GIB
-#define HGI_XCD_EIGHTHS_FROM_GIB 6   // launches whose interior tiles span at least this many GiB deal contiguous eighths
+#define HGI_XCD_EIGHTHS_FROM_GIB 6   // encodes whose interior tiles span at least this many GiB deal contiguous eighths
 #endif
 #ifndef HGI_DEC_REVERSE_DEFAULT
 #define HGI_DEC_REVERSE_DEFAULT 0
@@ -1985,14 +1985,17 @@ inline size_t lds_for_waves(size_t lds, int waves)
 // CONSECUTIVE bands -- is what a launch up to a few GiB wants: contiguous eighths put the XCDs' eight working points a
 // power-of-two distance of 32 ... 256 MiB apart, and those streams beat against each other in the memory system (16384^2:
 // +10 %; 64 and 128 x 4096^2: +2.5 ... +6 %; profiles/r03_ab_xcd.txt, r04_c3_xcd_sweep.txt).  Once the eighths are 768 MiB and
-// more apart that is over and eight separate fronts are FASTER than one: 384 ... 768 x 4096^2 encode -5 ... -6 %, decode
-// 0 ... -6 %; equal at 256 and at 1024 frames (profiles/r04_c3_xcd_sweep.txt, r04_c3_dec_sweep.txt).  Hence by size: contiguous
-// eighths from 6 GiB of interior tiles per plane.  (Knobs build: HGI_XCD_MODE = 0 | 1 forces one.)
-inline u32 xcd_mode(const TileGrid &g)
+// more apart that is over, and for the ENCODER eight separate fronts are then faster than one: 384 ... 768 x 4096^2 -5 ... -6 %,
+// on every box sampled at 512 frames -0.7 ... -6 % (2.65-2.79 against 2.81-2.82 ms; equal at 256 and at 1024 frames).  The
+// DECODER, at the 16 resident tiles per CU it runs deep launches with, is equal or slower with eighths on every box
+// (+0.5 ... +2.4 %: 2.79-2.86 against 2.77-2.79 ms; profiles/r04_c3_xcd_boxes.txt) and keeps the round-robin dealing.
+// Hence by direction and size: contiguous eighths for encodes from 6 GiB of interior tiles per plane.  (Knobs build:
+// HGI_XCD_MODE = 0 | 1 forces one for both directions.)
+inline u32 xcd_mode(const TileGrid &g, bool encode)
 {
     const int forced = HGI_KNOB(HGI_XCD_MODE, HGI_XCD_MODE);
     if (forced >= 0) return (u32)forced;
-    return (u64)g.nfast * TW * TH >= ((u64)HGI_XCD_EIGHTHS_FROM_GIB << 30) ? 0u : 1u;
+    return encode && (u64)g.nfast * TW * TH >= ((u64)HGI_XCD_EIGHTHS_FROM_GIB << 30) ? 0u : 1u;
 }
 
 }  // namespace
@@ -2009,7 +2012,7 @@ hipError_t HGI_TILED(launch_decode_fused)(const uint8_t *grid, uint8_t *img, con
     // DESIGN.md 6.1), so it is not shipped; g.reverse stays for the knobs build (HGI_DEC_REVERSE=1).  Order never changes the bytes.
     r.g.reverse = HGI_KNOB(HGI_DEC_REVERSE, HGI_DEC_REVERSE_DEFAULT) ? 1u : 0u;
     r.g.band = band_rows(f, false);
-    r.g.xmode = xcd_mode(r.g);
+    r.g.xmode = xcd_mode(r.g, false);
     finish_grid(r.g);
     const TileGrid &g = r.g;
     if (seeds && k < (uint32_t)kSeededMinLevels) return hipErrorInvalidValue;      // one lane per lattice point (seed_issue)
@@ -2066,7 +2069,7 @@ hipError_t HGI_TILED(launch_encode_fused)(const uint8_t *img, uint8_t *grid, con
     FusedGeom r = fused_geom(img, grid, f, row_limit);
     if (!r.ok || k < 1 || k > (u32)MAXK) return hipErrorInvalidValue;
     r.g.band = band_rows(f, true);
-    r.g.xmode = xcd_mode(r.g);
+    r.g.xmode = xcd_mode(r.g, true);
     finish_grid(r.g);
     const TileGrid &g = r.g;
     if (seeds && k < (uint32_t)kSeededMinLevels) return hipErrorInvalidValue;      // one lane per lattice point (seed_issue)

@@ -26,9 +26,11 @@
 #include <vector>
 
 #include "hgi_host.h"
+#include "hgi_lineup.h"
 
 using namespace hgi;
 using namespace hgi::host;
+using hgi::lineup::arrange;
 
 namespace {
 
@@ -145,27 +147,6 @@ hgi_status classify(hgi_ctx *c, const Yardstick &y, std::vector<std::vector<int>
     groups.push_back(std::vector<int>{cand});
     *group = (int)groups.size() - 1;
     return HGI_OK;
-}
-
-// Greedy arrangement of `count` members such that neighbours come from different groups: always take from the largest
-// remaining group that is not the one just used.  `left[g]` = members of group g still available (updated).  Returns the group
-// of every position, or an empty vector if it cannot be done.
-std::vector<int> arrange(std::vector<size_t> &left, uint32_t count)
-{
-    std::vector<int> seq;
-    std::vector<size_t> trial = left;
-    int prev = -1;
-    while (seq.size() < count) {
-        int pick = -1;
-        for (size_t g = 0; g < trial.size(); ++g)
-            if ((int)g != prev && trial[g] > 0 && (pick < 0 || trial[g] > trial[(size_t)pick])) pick = (int)g;
-        if (pick < 0) return {};
-        seq.push_back(pick);
-        --trial[(size_t)pick];
-        prev = pick;
-    }
-    left = trial;
-    return seq;
 }
 
 // ---- composed planes: bookkeeping of what hgi_planes_free has to undo ---------------------------------------------------
@@ -394,21 +375,17 @@ hgi_status alloc_composed(hgi_ctx *c, size_t bytes, uint32_t count, void **plane
     std::vector<std::vector<int>> groups;
     int last_group = -1;
     auto ptr_of = [&](int j) { return stage + (size_t)j * kChunk; };
-    std::vector<std::vector<int>> lineup;      // [offset][plane] -> chunk
+    lineup::Rows rows;      // [offset][plane] -> chunk
     bool ok = false, sided = false;
     size_t spacer_gib = 4, spacer_total = 0;
     const size_t spacer_budget = room > max_chunks ? (room - max_chunks < 96 ? room - max_chunks : 96) : 0;      // GiB (kChunk is one)
     const bool trace = HGI_SWITCH(HGI_PLANES_TRACE);
     for (;;) {
-        if (h.size() >= need && groups.size() >= 1) {
+        if (h.size() >= need) {
             // the last chunks all went to the largest group: skip ahead
             size_t big = 0;
-            for (size_t g = 1; g < groups.size(); ++g)
-                if (groups[g].size() > groups[big].size()) big = g;
             const size_t look = n < 4 ? n : 4;
-            bool stalled = groups[big].size() >= look;
-            for (size_t t = 0; t < look && stalled; ++t) stalled = groups[big][groups[big].size() - 1 - t] == (int)(h.size() - 1 - t);
-            if (stalled && spacer_total + spacer_gib <= spacer_budget) {
+            if (lineup::stalled(groups, h.size(), look, &big) && spacer_total + spacer_gib <= spacer_budget) {
                 hipMemGenericAllocationHandle_t sp;
                 if (hipMemCreate(&sp, spacer_gib * kGiB, &prop, 0) == hipSuccess) {
                     spacers.push_back(sp);
@@ -439,90 +416,20 @@ hgi_status alloc_composed(hgi_ctx *c, size_t bytes, uint32_t count, void **plane
             if (st != HGI_OK) return bail(st);
         }
         if (h.size() < need) return bail(fail(HGI_ENOMEM, "hipMemCreate: the device ran out of memory after %zu of %zu chunks", h.size(), need));
-        // Line-up, first choice: TWO SIDES.  The groups are split into a side for the even planes (image, image') and a side for
-        // the odd ones (grid), so that EVERY chunk of a plane differs in class from EVERY chunk of its neighbours, not only the
-        // one at the same offset.  That is what a launch dealt to the XCDs as contiguous eighths needs (hgi_fused_impl.h,
-        // xcd_mode(): from 6 GiB per plane the eight XCDs work on eight different chunks of each plane at one time): with a
-        // per-offset line-up whose sides flip along the plane, one XCD reads class A and writes B while another reads B and
-        // writes A, and the encoder loses 2-5 % (2.67 -> 2.71 ... 2.81 ms per 512 frames, profiles/r04_planes_sides.txt).
-        lineup.clear();
-        ok = false;
-        sided = false;
-        const size_t G = groups.size(), need_even = n * ((count + 1) / 2), need_odd = n * (count / 2);
-        if (G >= 2 && G <= 16) {
-            size_t best = 0, best_score = 0;
-            for (size_t mask = 1; mask + 1 < ((size_t)1 << G); ++mask) {
-                size_t x = 0, y = 0, xmax = 0, ymax = 0;
-                for (size_t g = 0; g < G; ++g) {
-                    const size_t sz = groups[g].size();
-                    if ((mask >> g) & 1) {
-                        x += sz;
-                        xmax = sz > xmax ? sz : xmax;
-                    } else {
-                        y += sz;
-                        ymax = sz > ymax ? sz : ymax;
-                    }
-                }
-                // feasible, and as uniform as can be: the largest group of each side should carry as much of it as possible
-                const size_t score = (xmax < need_even ? xmax : need_even) + (ymax < need_odd ? ymax : need_odd);
-                if (x >= need_even && y >= need_odd && score > best_score) {
-                    best = mask;
-                    best_score = score;
-                }
-            }
-            if (best) {
-                std::vector<size_t> by_size(G);
-                for (size_t g = 0; g < G; ++g) by_size[g] = g;
-                for (size_t a = 0; a < G; ++a)
-                    for (size_t b = a + 1; b < G; ++b)
-                        if (groups[by_size[b]].size() > groups[by_size[a]].size()) std::swap(by_size[a], by_size[b]);
-                std::vector<int> side[2];      // [0] even planes, [1] odd planes; members of the larger groups first
-                for (size_t g : by_size)
-                    for (int j : groups[g]) side[(best >> g) & 1 ? 0 : 1].push_back(j);
-                for (size_t m = 0; m < n; ++m) {
-                    std::vector<int> row;
-                    for (uint32_t i = 0; i < count; ++i) row.push_back(side[i & 1][(size_t)(i / 2) * n + m]);
-                    lineup.push_back(row);
-                }
-                ok = sided = true;
-            }
-        }
+        // Line-up (hgi_lineup.h; checked on the CPU by tests/cpp/test_lineup.cpp).  First choice: TWO SIDES -- the groups are
+        // split into a side for the even planes (image, image') and a side for the odd ones (grid), so that EVERY chunk of a
+        // plane differs in class from EVERY chunk of its neighbours, not only the one at the same offset.  That is what a launch
+        // dealt to the XCDs as contiguous eighths needs (hgi_fused_impl.h, xcd_mode(): from 6 GiB per plane the eight XCDs work
+        // on eight different chunks of each plane at one time): with a per-offset line-up whose sides flip along the plane, one
+        // XCD reads class A and writes B while another reads B and writes A (profiles/r04_planes_sides.txt).
+        ok = sided = lineup::two_sides(groups, n, count, rows);
         if (ok) break;
         if (h.size() < max_chunks) continue;      // more chunks (and spacers) first
         // second choice, at the end of the budget: per offset -- neighbouring planes differ at every offset, the sides may flip
-        std::vector<size_t> left(groups.size());
-        for (size_t g = 0; g < groups.size(); ++g) left[g] = groups[g].size();
-        std::vector<size_t> next(groups.size(), 0);
-        ok = true;
-        for (size_t m = 0; m < n && ok; ++m) {
-            const std::vector<int> seq = arrange(left, count);
-            if (seq.empty()) {
-                ok = false;
-                break;
-            }
-            std::vector<int> row;
-            for (int g : seq) row.push_back(groups[(size_t)g][next[(size_t)g]++]);
-            lineup.push_back(row);
-        }
+        ok = lineup::per_offset(groups, n, count, rows);
         break;
     }
-    if (!ok) {
-        // could not be established within the budget: the offsets that did line up stay as they are (a partly separated stream
-        // is still faster), the others take what is left, in creation order
-        std::vector<char> used(h.size(), 0);
-        for (auto &row : lineup)
-            for (int j : row) used[(size_t)j] = 1;
-        size_t at = 0;
-        while (lineup.size() < n) {
-            std::vector<int> row;
-            while (row.size() < count) {
-                while (used[at]) ++at;
-                used[at] = 1;
-                row.push_back((int)at);
-            }
-            lineup.push_back(row);
-        }
-    }
+    if (!ok) lineup::fill_rest(rows, n, count, h.size());      // what did line up stays; the rest in creation order
     if (trace) {
         fprintf(stderr, "hgi_planes_alloc: %zu chunks created, %zu GiB of spacers, %zu groups:", h.size(), spacer_total, groups.size());
         for (auto &g : groups) fprintf(stderr, " %zu", g.size());
@@ -537,11 +444,11 @@ hgi_status alloc_composed(hgi_ctx *c, size_t bytes, uint32_t count, void **plane
         for (size_t g = 0; g < groups.size(); ++g)
             for (int j : groups[g]) group_of[(size_t)j] = (int)g;
         std::vector<char> used(h.size(), 0);
-        for (auto &row : lineup)
+        for (auto &row : rows)
             for (int j : row) used[(size_t)j] = 1;
         // which side(s) a group supplies in this line-up: [group][0 even planes, 1 odd planes]
         std::vector<std::array<char, 2>> on_side(groups.size(), std::array<char, 2>{{0, 0}});
-        for (auto &row : lineup)
+        for (auto &row : rows)
             for (uint32_t i = 0; i < count; ++i) on_side[(size_t)group_of[(size_t)row[i]]][i & 1] = 1;
         auto fast = [&](int a, int b, bool *yes) -> hgi_status {
             float ratio = 0;
@@ -552,24 +459,24 @@ hgi_status alloc_composed(hgi_ctx *c, size_t bytes, uint32_t count, void **plane
         for (size_t m = 0; m < n && ok; ++m)
             for (uint32_t i = 0; i + 1 < count && ok; ++i) {
                 bool yes = false;
-                hgi_status st = fast(lineup[m][i], lineup[m][i + 1], &yes);
+                hgi_status st = fast(rows[m][i], rows[m][i + 1], &yes);
                 if (st != HGI_OK) return bail(st);
                 if (yes) continue;
                 int tries = 0;
                 for (size_t u = 0; u < h.size() && !yes && tries < 4; ++u) {
-                    if (used[u] || group_of[u] == group_of[(size_t)lineup[m][i]] || group_of[u] == group_of[(size_t)lineup[m][i + 1]]) continue;
+                    if (used[u] || group_of[u] == group_of[(size_t)rows[m][i]] || group_of[u] == group_of[(size_t)rows[m][i + 1]]) continue;
                     if (sided && !on_side[(size_t)group_of[u]][(i + 1) & 1]) continue;      // (the two sides stay what they are)
-                    if (i + 2 < count && group_of[u] == group_of[(size_t)lineup[m][i + 2]]) continue;
+                    if (i + 2 < count && group_of[u] == group_of[(size_t)rows[m][i + 2]]) continue;
                     ++tries;
                     bool a = false, b = true;
-                    st = fast(lineup[m][i], (int)u, &a);
-                    if (st == HGI_OK && a && i + 2 < count) st = fast((int)u, lineup[m][i + 2], &b);
+                    st = fast(rows[m][i], (int)u, &a);
+                    if (st == HGI_OK && a && i + 2 < count) st = fast((int)u, rows[m][i + 2], &b);
                     if (st != HGI_OK) return bail(st);
                     if (a && b) {
-                        if (trace) fprintf(stderr, "hgi_planes_alloc: offset %zu, plane %u: chunk %d exchanged for %zu\n", m, i + 1, lineup[m][i + 1], u);
-                        used[(size_t)lineup[m][i + 1]] = 0;
+                        if (trace) fprintf(stderr, "hgi_planes_alloc: offset %zu, plane %u: chunk %d exchanged for %zu\n", m, i + 1, rows[m][i + 1], u);
+                        used[(size_t)rows[m][i + 1]] = 0;
                         used[u] = 1;
-                        lineup[m][i + 1] = (int)u;
+                        rows[m][i + 1] = (int)u;
                         yes = true;
                     }
                 }
@@ -587,7 +494,7 @@ hgi_status alloc_composed(hgi_ctx *c, size_t bytes, uint32_t count, void **plane
         p.va = va;
         made.push_back(p);
         for (size_t m = 0; m < n; ++m) {
-            const size_t j = (size_t)lineup[m][i];
+            const size_t j = (size_t)rows[m][i];
             if (mapped[j]) {
                 hipError_t e = hipMemUnmap(stage + j * kChunk, kChunk);
                 if (e != hipSuccess) return bail(fail(HGI_EDEVICE, "hipMemUnmap: %s", hipGetErrorString(e)));

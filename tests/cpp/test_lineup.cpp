@@ -1,0 +1,129 @@
+// CPU check of rustyhgi_amd/csrc/hgi_lineup.h (which chunk of which memory class goes where in a set of composed planes):
+// thousands of synthetic classifications -- group counts, sizes and creation orders as the driver produces them (runs of one
+// class) and as it does not (shuffled) -- against the promises the header states.  Built by the CPU suite with
+// g++ -fsanitize=address,undefined (tests/test_sanitizers.py).
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <random>
+#include <set>
+
+#include "../../rustyhgi_amd/csrc/hgi_lineup.h"
+
+using namespace hgi::lineup;
+
+#define REQUIRE(cond)                                                          \
+    do {                                                                       \
+        if (!(cond)) {                                                         \
+            std::printf("FAILED %s:%d: %s (case %d)\n", __FILE__, __LINE__, #cond, g_case); \
+            return 1;                                                          \
+        }                                                                      \
+    } while (0)
+
+static int g_case = 0;
+
+static int group_of(const Groups &groups, int chunk)
+{
+    for (size_t g = 0; g < groups.size(); ++g)
+        for (int j : groups[g])
+            if (j == chunk) return (int)g;
+    return -1;
+}
+
+int main(int argc, char **argv)
+{
+    const int cases = argc > 1 ? atoi(argv[1]) : 20000;
+    std::mt19937_64 rng(0x48474930);
+    int sided = 0, offset_only = 0, neither = 0;
+    for (g_case = 0; g_case < cases; ++g_case) {
+        const size_t n = 1 + rng() % 16;                  // chunks per plane
+        const uint32_t count = 2 + (uint32_t)(rng() % 4);      // planes
+        const size_t created = n * count + rng() % (2 * n * count + 1);
+        const size_t G = 1 + rng() % 6;
+        // classes in runs, as the driver hands memory out, or shuffled
+        std::vector<int> cls(created);
+        if (rng() % 3) {
+            size_t at = 0;
+            int c = (int)(rng() % G);
+            while (at < created) {
+                const size_t run = 1 + rng() % (2 * n + 3);
+                for (size_t k = 0; k < run && at < created; ++k) cls[at++] = c;
+                c = (int)(rng() % G);
+            }
+        } else {
+            for (auto &c : cls) c = (int)(rng() % G);
+        }
+        // groups in order of first appearance (what classify() builds)
+        Groups groups;
+        std::vector<int> label(G, -1);
+        for (size_t j = 0; j < created; ++j) {
+            if (label[(size_t)cls[j]] < 0) {
+                label[(size_t)cls[j]] = (int)groups.size();
+                groups.push_back({});
+            }
+            groups[(size_t)label[(size_t)cls[j]]].push_back((int)j);
+        }
+        Rows rows;
+        bool two = two_sides(groups, n, count, rows), complete = two;
+        if (two) {
+            ++sided;
+            // every chunk of a plane differs in group from EVERY chunk of its neighbours
+            for (uint32_t i = 0; i + 1 < count; ++i)
+                for (size_t a = 0; a < n; ++a)
+                    for (size_t b = 0; b < n; ++b) REQUIRE(group_of(groups, rows[a][i]) != group_of(groups, rows[b][i + 1]));
+        } else {
+            complete = per_offset(groups, n, count, rows);
+            REQUIRE(rows.size() <= n);
+            if (complete) ++offset_only; else ++neither;
+            // a two-sided line-up exists whenever some split of the groups holds enough chunks on both sides: brute force says no
+            const size_t need_even = n * ((count + 1) / 2), need_odd = n * (count / 2);
+            for (size_t mask = 1; mask + 1 < ((size_t)1 << groups.size()); ++mask) {
+                size_t x = 0, y = 0;
+                for (size_t g = 0; g < groups.size(); ++g) ((mask >> g) & 1 ? x : y) += groups[g].size();
+                REQUIRE(!(x >= need_even && y >= need_odd));
+            }
+            const size_t lined = rows.size();
+            fill_rest(rows, n, count, created);
+            // the offsets that lined up keep their promise; the rest is filled with unused chunks
+            for (size_t m = 0; m < lined; ++m)
+                for (uint32_t i = 0; i + 1 < count; ++i) REQUIRE(group_of(groups, rows[m][i]) != group_of(groups, rows[m][i + 1]));
+        }
+        REQUIRE(rows.size() == n);
+        std::set<int> seen;
+        for (auto &row : rows) {
+            REQUIRE(row.size() == count);
+            for (int j : row) {
+                REQUIRE(j >= 0 && (size_t)j < created);
+                REQUIRE(seen.insert(j).second);      // every chunk at most once
+            }
+        }
+        if (complete)
+            for (size_t m = 0; m < n; ++m)
+                for (uint32_t i = 0; i + 1 < count; ++i) REQUIRE(group_of(groups, rows[m][i]) != group_of(groups, rows[m][i + 1]));
+        // stalled(): true exactly when the last `look` chunks created are the last `look` members of the largest group
+        const size_t look = n < 4 ? n : 4;
+        size_t big = 0;
+        const bool st = stalled(groups, created, look, &big);
+        size_t b = 0;
+        for (size_t g = 1; g < groups.size(); ++g)
+            if (groups[g].size() > groups[b].size()) b = g;
+        bool want = groups[b].size() >= look;
+        for (size_t t = 0; t < look && want; ++t) want = label[(size_t)cls[created - 1 - t]] == (int)b;
+        REQUIRE(st == want);
+    }
+    // the shapes seen on the device (profiles/r04_planes_sides.txt): 512 frames = 8 chunks x 3 planes
+    {
+        Groups g = {{}, {}, {}};
+        int j = 0;
+        for (int k = 0; k < 3; ++k) g[0].push_back(j++);
+        for (int k = 0; k < 6; ++k) g[1].push_back(j++);
+        for (int k = 0; k < 19; ++k) g[2].push_back(j++);
+        Rows rows;
+        REQUIRE(two_sides(g, 8, 3, rows));
+        for (size_t m = 0; m < 8; ++m) REQUIRE(group_of(g, rows[m][0]) == 2 && group_of(g, rows[m][2]) == 2 && group_of(g, rows[m][1]) != 2);
+        Groups one = {{0, 1, 2, 3, 4, 5}};
+        REQUIRE(!two_sides(one, 2, 3, rows) && !per_offset(one, 2, 3, rows));
+    }
+    std::printf("%d cases ok: %d two-sided, %d per offset only, %d not separable\n", cases, sided, offset_only, neither);
+    return 0;
+}

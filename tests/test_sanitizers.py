@@ -102,6 +102,19 @@ def test_archive_reader_on_hostile_input_under_asan_ubsan(tmp_path):
     assert p.returncode == 0 and "archive hardening ok" in p.stdout, p.stdout + p.stderr[-4000:]
 
 
+def test_plane_lineup_under_asan_ubsan(tmp_path):
+    """csrc/hgi_lineup.h -- which classified 1 GiB chunk goes where in a set of composed planes (hgi_planes_alloc above 1 GiB) --
+    is plain C++: 20 000 synthetic classifications (classes in runs, as the driver hands memory out, and shuffled) against its
+    promises: every chunk at most once; a complete line-up has neighbouring planes on different classes at every offset; a
+    two-sided one has EVERY chunk of a plane differ from EVERY chunk of its neighbours and is found whenever one exists; a
+    partial one keeps what lined up; the stall detector fires exactly when the last chunks all joined the largest group."""
+    exe = str(tmp_path / "test_lineup")
+    subprocess.check_call(["g++", "-O1", "-g", "-std=c++17", "-Wall", "-Wextra", "-fsanitize=address,undefined",
+                           "-fno-sanitize-recover=undefined", os.path.join(ROOT, "tests", "cpp", "test_lineup.cpp"), "-o", exe])
+    p = subprocess.run([exe, "20000"], capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0 and "20000 cases ok" in p.stdout, p.stdout + p.stderr[-4000:]
+
+
 def test_fastdiv_is_exact(tmp_path):
     """The tile kernels never divide: block -> tile index math goes through hgi_fastdiv.h with multipliers the host
     derives per launch.  Checked against the machine's division (UBSan on): every divisor to 70 000, 200 000 random ones."""
