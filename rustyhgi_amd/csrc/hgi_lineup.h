@@ -39,46 +39,102 @@ inline std::vector<int> arrange(std::vector<size_t> &left, uint32_t count)
     return seq;
 }
 
+// How many chunks each group of a side gives to ONE plane of that side: proportional shares of what the groups still hold
+// (`left`, over the `planes_left` planes of the side still to be served), trimmed from the largest share / topped up where most
+// is left until they add up to n.  Spreads a plane over the classes of its side as evenly as the supply allows.
+inline std::vector<size_t> plane_quota(const std::vector<size_t> &left, size_t planes_left, size_t n)
+{
+    std::vector<size_t> q(left.size());
+    size_t sum = 0;
+    for (size_t g = 0; g < left.size(); ++g) sum += q[g] = left[g] / planes_left;
+    while (sum > n) {
+        size_t big = 0;
+        for (size_t g = 1; g < q.size(); ++g)
+            if (q[g] > q[big]) big = g;
+        --q[big];
+        --sum;
+    }
+    while (sum < n) {
+        size_t pick = q.size();
+        for (size_t g = 0; g < q.size(); ++g)
+            if (left[g] > q[g] && (pick == q.size() || left[g] - q[g] > left[pick] - q[pick])) pick = g;
+        if (pick == q.size()) break;      // (cannot happen while the side holds n * planes_left chunks)
+        ++q[pick];
+        ++sum;
+    }
+    return q;
+}
+
 // First choice: TWO SIDES.  The groups are split into a side for the even planes (image, image') and a side for the odd ones
-// (grid) such that each side holds enough chunks; among the feasible splits the one whose largest groups carry most of their
-// side wins (planes as uniform in class as can be).  Planes of a side take consecutive runs of the side's members, larger groups
-// first.  Returns false (rows untouched) when no split is feasible yet.
+// (grid) such that each side holds enough chunks.  Every plane is then spread over the groups of its side as EVENLY as the
+// supply allows (plane_quota), its chunks alternating between them: an encode of 6 GiB and more per plane is dealt to the XCDs as
+// contiguous eighths, i.e. eight chunks of each plane are in use at one time, and the more classes those touch the faster it
+// runs -- measured on 512 x 4096^2 with the grid plane on 8 + 0 / 7 + 1 / 6 + 2 / 4 + 4 chunks of two classes: 2.787 / 2.730 /
+// 2.670 / 2.654 ms (profiles/r04_planes_sides.txt, r04_c3_xcd_boxes.txt).  Among the feasible splits the one with the most evenly
+// spread planes wins.  Returns false (rows untouched) when no split is feasible yet.
 inline bool two_sides(const Groups &groups, size_t n, uint32_t count, Rows &rows)
 {
-    const size_t G = groups.size(), need_even = n * ((count + 1) / 2), need_odd = n * (count / 2);
+    const size_t G = groups.size();
+    const size_t planes_of[2] = {(size_t)(count + 1) / 2, (size_t)count / 2};      // even planes, odd planes
     if (G < 2 || G > 16 || count < 2) return false;
-    size_t best = 0, best_score = 0;
-    for (size_t mask = 1; mask + 1 < ((size_t)1 << G); ++mask) {
-        size_t x = 0, y = 0, xmax = 0, ymax = 0;
-        for (size_t g = 0; g < G; ++g) {
-            const size_t sz = groups[g].size();
-            if ((mask >> g) & 1) {
-                x += sz;
-                xmax = sz > xmax ? sz : xmax;
-            } else {
-                y += sz;
-                ymax = sz > ymax ? sz : ymax;
+    // quotas[side][plane of the side][group] for a split; score = chunks that do NOT sit in their plane's largest share
+    auto evaluate = [&](size_t mask, std::vector<std::vector<size_t>> (&quota)[2]) -> long {
+        long score = 0;
+        for (int sd = 0; sd < 2; ++sd) {
+            std::vector<size_t> left(G, 0);
+            size_t have = 0;
+            for (size_t g = 0; g < G; ++g)
+                if ((((mask >> g) & 1) != 0) == (sd == 0)) have += left[g] = groups[g].size();
+            if (have < n * planes_of[sd]) return -1;
+            quota[sd].clear();
+            for (size_t p = 0; p < planes_of[sd]; ++p) {
+                std::vector<size_t> q = plane_quota(left, planes_of[sd] - p, n);
+                size_t sum = 0, big = 0;
+                for (size_t g = 0; g < G; ++g) {
+                    sum += q[g];
+                    big = q[g] > big ? q[g] : big;
+                    left[g] -= q[g];
+                }
+                if (sum != n) return -1;
+                score += (long)(n - big);
+                quota[sd].push_back(q);
             }
         }
-        const size_t score = (xmax < need_even ? xmax : need_even) + (ymax < need_odd ? ymax : need_odd);
-        if (x >= need_even && y >= need_odd && score > best_score) {
+        return score;
+    };
+    size_t best = 0;
+    long best_score = -1;
+    std::vector<std::vector<size_t>> quota[2], best_quota[2];
+    for (size_t mask = 1; mask + 1 < ((size_t)1 << G); ++mask) {
+        const long score = evaluate(mask, quota);
+        if (score > best_score) {
             best = mask;
             best_score = score;
+            best_quota[0] = quota[0];
+            best_quota[1] = quota[1];
         }
     }
     if (!best) return false;
-    std::vector<size_t> by_size(G);
-    for (size_t g = 0; g < G; ++g) by_size[g] = g;
-    for (size_t a = 0; a < G; ++a)
-        for (size_t b = a + 1; b < G; ++b)
-            if (groups[by_size[b]].size() > groups[by_size[a]].size()) std::swap(by_size[a], by_size[b]);
-    std::vector<int> side[2];      // [0] even planes, [1] odd planes; members of the larger groups first
-    for (size_t g : by_size)
-        for (int j : groups[g]) side[(best >> g) & 1 ? 0 : 1].push_back(j);
+    // hand the chunks out: plane by plane, the plane's groups taking turns (largest remaining share first)
+    std::vector<size_t> next(G, 0);
+    Rows plane_chunks(count);
+    for (uint32_t i = 0; i < count; ++i) {
+        std::vector<size_t> q = best_quota[i & 1][i / 2];
+        int prev = -1;
+        while (plane_chunks[i].size() < n) {
+            int pick = -1;
+            for (size_t g = 0; g < G; ++g)
+                if (q[g] > 0 && (int)g != prev && (pick < 0 || q[g] > q[(size_t)pick])) pick = (int)g;
+            if (pick < 0) pick = prev;      // only one group left: no more turns to take
+            plane_chunks[i].push_back(groups[(size_t)pick][next[(size_t)pick]++]);
+            --q[(size_t)pick];
+            prev = pick;
+        }
+    }
     rows.clear();
     for (size_t m = 0; m < n; ++m) {
         std::vector<int> row;
-        for (uint32_t i = 0; i < count; ++i) row.push_back(side[i & 1][(size_t)(i / 2) * n + m]);
+        for (uint32_t i = 0; i < count; ++i) row.push_back(plane_chunks[i][m]);
         rows.push_back(row);
     }
     return true;

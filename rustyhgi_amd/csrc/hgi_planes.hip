@@ -433,7 +433,18 @@ hgi_status alloc_composed(hgi_ctx *c, size_t bytes, uint32_t count, void **plane
     if (trace) {
         fprintf(stderr, "hgi_planes_alloc: %zu chunks created, %zu GiB of spacers, %zu groups:", h.size(), spacer_total, groups.size());
         for (auto &g : groups) fprintf(stderr, " %zu", g.size());
-        fprintf(stderr, " -> line-up %s\n", !ok ? "INCOMPLETE" : sided ? "complete, two sides" : "complete, per offset");
+        fprintf(stderr, " -> line-up %s;", !ok ? "INCOMPLETE" : sided ? "complete, two sides" : "complete, per offset");
+        for (uint32_t i = 0; i < count; ++i) {      // how many chunks of which group each plane got
+            std::vector<size_t> from(groups.size(), 0);
+            for (size_t m = 0; m < n; ++m)
+                for (size_t g = 0; g < groups.size(); ++g)
+                    for (int j : groups[g])
+                        if (j == rows[m][i]) ++from[g];
+            fprintf(stderr, " plane %u =", i);
+            for (size_t g = 0; g < groups.size(); ++g)
+                if (from[g]) fprintf(stderr, " %zu x g%zu", from[g], g);
+            fprintf(stderr, "%s", i + 1 < count ? "," : "\n");
+        }
     }
     // What the probes said chunk against group representative, checked pair by pair as the planes will hold them: at every
     // chunk offset every neighbouring pair must stream at the fast rate (this is what the caller is promised).  A pair that

@@ -120,7 +120,31 @@ int main(int argc, char **argv)
         for (int k = 0; k < 19; ++k) g[2].push_back(j++);
         Rows rows;
         REQUIRE(two_sides(g, 8, 3, rows));
-        for (size_t m = 0; m < 8; ++m) REQUIRE(group_of(g, rows[m][0]) == 2 && group_of(g, rows[m][2]) == 2 && group_of(g, rows[m][1]) != 2);
+        int from0 = 0, from1 = 0;
+        for (size_t m = 0; m < 8; ++m) {
+            REQUIRE(group_of(g, rows[m][0]) == 2 && group_of(g, rows[m][2]) == 2 && group_of(g, rows[m][1]) != 2);
+            (group_of(g, rows[m][1]) == 0 ? from0 : from1)++;
+        }
+        REQUIRE(from0 == 3 && from1 == 5);      // the grid plane is spread over both small classes as evenly as 3 + 6 chunks allow
+        // 7 / 5 / 16: the grid plane takes 4 + 4, alternating
+        Groups h7 = {{}, {}, {}};
+        j = 0;
+        for (int k = 0; k < 7; ++k) h7[0].push_back(j++);
+        for (int k = 0; k < 5; ++k) h7[1].push_back(j++);
+        for (int k = 0; k < 16; ++k) h7[2].push_back(j++);
+        REQUIRE(two_sides(h7, 8, 3, rows));
+        for (size_t m = 0; m + 1 < 8; ++m) REQUIRE(group_of(h7, rows[m][1]) != group_of(h7, rows[m + 1][1]) && group_of(h7, rows[m][1]) != 2);
+        // 8 / 8 / 8: two classes share the image planes half and half, the third is the grid
+        Groups e8 = {{}, {}, {}};
+        j = 0;
+        for (int gi = 0; gi < 3; ++gi)
+            for (int k = 0; k < 8; ++k) e8[(size_t)gi].push_back(j++);
+        REQUIRE(two_sides(e8, 8, 3, rows));
+        for (int pl : {0, 2}) {
+            int a = 0;
+            for (size_t m = 0; m < 8; ++m) a += group_of(e8, rows[m][(size_t)pl]) == group_of(e8, rows[0][(size_t)pl]);
+            REQUIRE(a == 4);
+        }
         Groups one = {{0, 1, 2, 3, 4, 5}};
         REQUIRE(!two_sides(one, 2, 3, rows) && !per_offset(one, 2, 3, rows));
     }
