@@ -172,3 +172,40 @@ def test_four_ranks_share_one_device_with_scatter_and_gather(oracle):
         img = oracle.synth(oracle.SYNTH_RAMP, SEED0 + 3, rank * 12, 512, 512)      # the scatter leg deals 12 frames per rank from frame 0
         want = oracle.decode(oracle.encode(img, 4, lut), 4)
         assert got == hashlib.sha256(want.tobytes()).hexdigest()[:16], "rank %d: the gathered frame is not the oracle's" % rank
+
+
+def test_traffic_record_is_tied_to_the_build(tmp_path, monkeypatch):
+    """`roofline.traffic` comes from a committed rocprofv3 record; bench.py takes it only when the record was made on this
+    workload AND on this build of the library (the hash over the library's sources recorded by tools/summarize_prof.py equals
+    the running one's) -- otherwise null with the reason.  The committed round-4 records carry the stamp of the committed tree."""
+    import bench
+    stamp = bench.build_stamp()
+    assert len(stamp["source_sha256"]) == 16 and stamp["lib"] == "libhgi_hip.so" and "gfx950" in stamp["version"]
+    # the committed records belong to the committed sources (a kernel edit without a new profile shows up here)
+    for name, frames in (("r04_traffic.json", 512), ("r04_traffic_64.json", 64)):
+        rec = json.load(open(os.path.join(ROOT, "profiles", name)))
+        assert rec["workload"] == {"frames": frames, "size": 4096, "levels": 4}
+        assert rec["build"]["source_sha256"] == stamp["source_sha256"], \
+            "profiles/%s was taken on another build: re-run tools/profile.sh and commit its traffic.json" % name
+        got, src = bench.pmc_traffic("k_dec_tiles", frames, 4096, 4, stamp)
+        assert src == "profiles/" + name and 0.99 < got / (2.0 * frames * 4096 * 4096) < 1.05
+    # another build: refused, with the reason; another workload: no record
+    got, why = bench.pmc_traffic("k_dec_tiles", 512, 4096, 4, dict(stamp, source_sha256="0" * 16))
+    assert got is None and "another build" in why
+    got, why = bench.pmc_traffic("k_dec_tiles", 500, 4096, 4, stamp)
+    assert got is None and "no committed profile" in why
+    # the stamp follows the sources: one byte more in a kernel file moves it
+    real = os.path.join(ROOT, "rustyhgi_amd", "csrc")
+    fake = tmp_path / "rustyhgi_amd" / "csrc"
+    fake.mkdir(parents=True)
+    (tmp_path / "include").mkdir()
+    import shutil
+    for f in os.listdir(real):
+        if f.endswith((".hip", ".h", ".map")) or f == "Makefile":
+            shutil.copy(os.path.join(real, f), fake / f)
+    shutil.copy(os.path.join(ROOT, "include", "hgi.h"), tmp_path / "include" / "hgi.h")
+    monkeypatch.setattr(bench, "ROOT", str(tmp_path))
+    assert bench.build_stamp()["source_sha256"] == stamp["source_sha256"]
+    with open(fake / "hgi_dev.h", "a") as f:
+        f.write("\n")
+    assert bench.build_stamp()["source_sha256"] != stamp["source_sha256"]
