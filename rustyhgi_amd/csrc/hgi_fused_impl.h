@@ -1,9 +1,9 @@
 // gfx950 (MI355X / CDNA4) fused HGI kernels: all levels of a tile in one launch, LDS-resident.
 //
-// This is the implementation.  It is compiled four times -- per direction (hgi_fused_dec.hip / hgi_fused_enc.hip:
+// This is the implementation.  It is compiled six times -- per direction (hgi_fused_dec.hip / hgi_fused_enc.hip:
 // the directions want different LDS pitches and register budgets) and per tile height (128 x 64 tiles for
-// throughput, 128 x 32 tiles for calls too small to fill the GPU; hgi_fused_*32.hip) -- and hgi_capi.hip picks the
-// build per launch.
+// throughput, 128 x 32 tiles for calls too small to fill the GPU, 128 x 16 tiles for the encode of a lone small frame;
+// hgi_fused_*32.hip, hgi_fused_*16.hip) -- and hgi_capi.hip picks the build per launch.
 //
 // Reference algorithm (paths relative to pl0q1n/RustyHGI):
 //   src/encoder.rs:39-71, src/decoder.rs:18-46, src/interpolator.rs:15-28 / :41-90, src/utils.rs:12-41

@@ -327,13 +327,14 @@ hgi_status alloc_composed(hgi_ctx *c, size_t bytes, uint32_t count, void **plane
     std::vector<char> mapped;                           // ... whether it is mapped at its staging slot
     std::vector<char> owned;                            // ... and whether a finished plane (`made`) owns it by now
     uint8_t *stage = nullptr;                           // staging range: chunk j at stage + j * kChunk while it is being classified
+    size_t stage_bytes = 0;                             // ... and what was reserved for it (max_chunks may shrink later)
     Yardstick y;
     std::vector<Composed> made;
     auto cleanup = [&](bool keep_made) {
         if (stage) {
             for (size_t j = 0; j < h.size(); ++j)
                 if (mapped[j]) (void)hipMemUnmap(stage + j * kChunk, kChunk);
-            (void)hipMemAddressFree(stage, max_chunks * kChunk);
+            (void)hipMemAddressFree(stage, stage_bytes);
         }
         stage = nullptr;
         y.drop();
@@ -365,7 +366,8 @@ hgi_status alloc_composed(hgi_ctx *c, size_t bytes, uint32_t count, void **plane
         if (st != HGI_OK) return bail(st);
     }
     if (y.make(kChunk) != HGI_OK) return bail(fail(HGI_ENOMEM, "no room for the placement yardstick (2 GiB)"));
-    PL_TRY(hipMemAddressReserve(reinterpret_cast<void **>(&stage), max_chunks * kChunk, 0, nullptr, 0));
+    stage_bytes = max_chunks * kChunk;
+    PL_TRY(hipMemAddressReserve(reinterpret_cast<void **>(&stage), stage_bytes, 0, nullptr, 0));
 
     // create, map, classify -- until at every chunk offset `count` chunks can be lined up with neighbours of different classes.
     // The driver hands out physical memory in runs of one class (8 ... 52 GiB long in one 160 GiB allocation; longer right after
