@@ -770,13 +770,14 @@ def test_release_library_ignores_the_switches_and_the_knobs_build_is_what_the_ch
 
 @pytest.mark.parametrize("mode", ["HGI_FORCE_CHECKED=1", "HGI_TILE_H=64", "HGI_TILE_H=32", "HGI_TILE_H=16", "HGI_NO_LATTICE_KERNEL=1",
                                   "HGI_DEC_REVERSE=1", "HGI_NO_LATTICE_KERNEL=1,HGI_FORCE_CHECKED=1", "HGI_NO_LATTICE_KERNEL=1,HGI_TILE_H=16",
-                                  "HGI_NO_BANDS=1"])
+                                  "HGI_NO_BANDS=1", "HGI_XCD_MODE=0"])
 def test_forced_code_paths_in_a_child_process(mode):
     """The library picks tile geometry and code path per launch: 128x16, 128x32 or 128x64 tiles, and the fully checked path only
     for widths that are not multiples of 4 or frames beyond 32-bit offsets.  A child process on the KNOBS build re-runs the
     shape-heavy parity cases with one of those choices forced: aligned shapes through the checked path, small shapes through
     64-row tiles, large ones through 32-row and (pyramids up to four levels) 16-row tiles, the decoder walking its tile list
-    backwards, large host frames without bands.  Pyramids of six to eight levels run as ONE launch that rebuilds the levels
+    backwards, large host frames without bands, every launch dealt to the XCDs as contiguous eighths (what only encodes of
+    6 GiB and more per plane get otherwise).  Pyramids of six to eight levels run as ONE launch that rebuilds the levels
     above a four-level tile for itself (the cone) -- on every tile height; deeper ones code the stride-256 lattice first -- in
     the one-workgroup lattice kernel, or, for planes beyond 8 192 points (here: HGI_NO_LATTICE_KERNEL), by host recursion:
     gather, encode, decode -- and start the cone from its planes.  The bytes must not depend on any of it."""
@@ -1070,6 +1071,52 @@ def test_planes_alloc_places_neighbours_in_different_regions(H, oracle):
             planes.probe_ms(0, 1)                  # clocks
         p01, p12, p02 = planes.probe_ms(0, 1), planes.probe_ms(1, 2), planes.probe_ms(0, 2)
         assert max(p01, p12) <= 1.03 * min(p01, p12, p02), (p01, p12, p02)
+    del img, grid, out
+    planes.close()
+    ctx.close()
+
+
+def test_literal_c3_batch_on_one_gpu(H, oracle, golden):
+    """BASELINE configs[3] as it is written -- 512 independent 4096 x 4096 frames, level 4, Medium -- in ONE call per direction
+    on one GPU (24 GiB of planes from hgi_planes_alloc, composed of 1 GiB chunks).  This is the only size at which the encoder's
+    launch is dealt to the XCDs as contiguous eighths (>= 6 GiB of interior tiles per plane, hgi_fused_impl.h xcd_mode()) and at
+    which 32-bit tile counts pass a million.  Frames from all over the batch -- on both sides of chunk and eighth boundaries --
+    are compared bit for bit with the oracle, the committed golden hashes of frames 0 and 511 must match, and the
+    reconstruction error of EVERY frame must stay within the quantizer's bound (hgi_diff_stats_dev over the whole batch)."""
+    import hashlib
+    import torch
+    from rustyhgi_amd import _ffi
+    L = _ffi.lib()
+    if torch.cuda.mem_get_info()[0] < (40 << 30):
+        pytest.skip("needs 40 GiB of free device memory")
+    ctx = H.Context(0)
+    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    F, S = 512, 4096
+    planes = H.Planes(ctx, F * S * S, 3)
+    img, grid, out = (planes.torch(i, (F, S, S)) for i in range(3))
+    _ffi.check(L.hgi_synth_u8_dev(ctx.handle, _ffi.SYNTH_RAMP, SEED0 + 3, 0, S, S, img.data_ptr(), F, S * S))
+    lut, err = oracle.linear_lut(2)
+    grid.fill_(0xA5)
+    out.fill_(0x5A)
+    _ffi.check(L.hgi_encode_u8_dev(ctx.handle, img.data_ptr(), S, S, 4, 1, lut.ctypes.data, grid.data_ptr(), F, S * S))
+    _ffi.check(L.hgi_decode_u8_dev(ctx.handle, grid.data_ptr(), S, S, 4, 1, out.data_ptr(), F, S * S))
+    torch.cuda.synchronize()
+    for f in (0, 63, 64, 200, 383, 384, 447, 511):
+        src = oracle.synth(oracle.SYNTH_RAMP, SEED0 + 3, f, S, S)
+        assert_same(img[f].cpu().numpy(), src, "encode modified its input (or the generator differs), frame %d" % f)
+        want = oracle.encode(src, 4, lut)
+        assert_same(grid[f].cpu().numpy(), want, "literal C3, encode, frame %d" % f)
+        assert_same(out[f].cpu().numpy(), oracle.decode(want, 4), "literal C3, decode, frame %d" % f)
+    for f in (0, 511):
+        g = golden["ramp3_f%d_4096/L4/q2/i1" % f]
+        assert hashlib.sha256(grid[f].cpu().numpy().tobytes()).hexdigest() == g["sha_grid"]
+        assert hashlib.sha256(out[f].cpu().numpy().tobytes()).hexdigest() == g["sha_dec"]
+    stats = torch.zeros(3 * F, dtype=torch.int64, device="cuda")
+    _ffi.check(L.hgi_diff_stats_dev(ctx.handle, img.data_ptr(), out.data_ptr(), S, S, F, S * S, stats.data_ptr()))
+    torch.cuda.synchronize()
+    st = stats.view(F, 3).cpu().numpy()
+    assert int(st[:, 1].max()) <= err and int(st[:, 1].min()) > 0, "reconstruction error out of the Medium bound somewhere in the batch"
+    assert int(st[:, 2].min()) > S * S // 2          # every frame was really coded (Medium changes most pixels of a ramp frame)
     del img, grid, out
     planes.close()
     ctx.close()
