@@ -179,13 +179,13 @@ hipError_t launch_encode_fused(const uint8_t *img, uint8_t *grid, const Frames &
 }
 
 hipError_t launch_decode_fused(const uint8_t *grid, uint8_t *img, const Frames &f, uint32_t k, int interp,
-                               const Seeds *seeds, hipStream_t s, uint32_t row_limit = 0)
+                               const Seeds *seeds, hipStream_t s, uint32_t row_limit = 0, int resident_tiles = -1)
 {
     const uint32_t rows = row_limit && row_limit < f.height ? row_limit : f.height;
     switch (use_tile_rows(f.width, rows, k, f.batch, false)) {
-    case 16: return launch_decode_fused_16(grid, img, f, k, interp, seeds, s, row_limit);
-    case 32: return launch_decode_fused_32(grid, img, f, k, interp, seeds, s, row_limit);
-    default: return launch_decode_fused_64(grid, img, f, k, interp, seeds, s, row_limit);
+    case 16: return launch_decode_fused_16(grid, img, f, k, interp, seeds, s, row_limit, resident_tiles);
+    case 32: return launch_decode_fused_32(grid, img, f, k, interp, seeds, s, row_limit, resident_tiles);
+    default: return launch_decode_fused_64(grid, img, f, k, interp, seeds, s, row_limit, resident_tiles);
     }
 }
 
@@ -283,7 +283,7 @@ hgi_status decode_impl(hgi_ctx *c, const uint8_t *grid, uint32_t w, uint32_t h, 
         const Seeds sd = {nullptr, nullptr, 0, 0, 0, sp.up};
         HIP_TRY(launch_decode_fused(grid, img, f, sp.k, interp, &sd, c->stream));
     } else {
-        HIP_TRY(launch_decode_fused(grid, img, f, sp.k, interp, nullptr, c->stream));
+        HIP_TRY(launch_decode_fused(grid, img, f, sp.k, interp, nullptr, c->stream, 0, c->probe_resident_tiles));
     }
     return HGI_OK;
 }
@@ -403,6 +403,7 @@ hgi_status hgi_ctx_create(int device, hgi_ctx **out)
     c->have_pipe = false;
     c->pin = nullptr;
     c->pin_bytes = 0;
+    c->probe_resident_tiles = -1;
     if (hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_hist[0], hipEventDisableTiming) != hipSuccess ||

@@ -112,7 +112,13 @@ static_assert(TH != 64 || 18 * (buf_bytes(4) + rbuf_bytes(4) + 256) <= 160 * 102
 #define HGI_DEC_SHALLOW_WAVES 20  // resident tiles per CU asked for on decodes 1-8 rounds deep (launch_decode_fused)
 #endif
 #ifndef HGI_DEC_DEEP_WAVES
-#define HGI_DEC_DEEP_WAVES 16     // ... and on deeper ones
+#define HGI_DEC_DEEP_WAVES 16     // ... and on deeper ones (launches that rebuild levels in the kernel or start from seed planes)
+#endif
+#ifndef HGI_DEC_STREAM_WAVES
+#define HGI_DEC_STREAM_WAVES 10   // resident tiles per CU of a plain decode (the tile holds the pyramid) of 8 192 tiles and more, rows up
+#endif                            // to 4 096 pixels and up to four levels ...
+#ifndef HGI_DEC_STREAM_WAVES_WIDE
+#define HGI_DEC_STREAM_WAVES_WIDE 12   // ... and on wider rows or five levels
 #endif
 #ifndef HGI_XCD_MODE
 #define HGI_XCD_MODE -1     // the XCD dealing policy (block_role): 0 contiguous eighths, 1 whole bands round-robin, -1 by size (xcd_mode())
@@ -2002,7 +2008,7 @@ inline u32 xcd_mode(const TileGrid &g, bool encode)
 
 #ifdef HGI_FUSED_DECODE
 hipError_t HGI_TILED(launch_decode_fused)(const uint8_t *grid, uint8_t *img, const Frames &f, uint32_t k, int interp,
-                                          const Seeds *seeds, hipStream_t s, uint32_t row_limit)
+                                          const Seeds *seeds, hipStream_t s, uint32_t row_limit, int resident_tiles)
 {
     FusedGeom r = fused_geom(grid, img, f, row_limit);
     if (!r.ok || k < 1 || k > (u32)MAXK) return hipErrorInvalidValue;
@@ -2023,16 +2029,36 @@ hipError_t HGI_TILED(launch_decode_fused)(const uint8_t *grid, uint8_t *img, con
     if (seeds && !cone && !seeds->rec) return hipErrorInvalidValue;
     const dim3 b(NL);
     const int nh = k >= 2 ? (int)k : 1;
-    // A decode between one and eight rounds of resident tiles deep (8 192 ... 65 536 tiles: a lone 16384^2 frame has 32 768)
-    // runs with 20 tiles per CU instead of the 32 its LDS allows: the rate is the same down to 16 (round 1, and
-    // profiles/r03_waves_sweep.txt: 101.3 us at 32, 99.1 at 20, 98.5 at 16, 109.8 at 12), the tile lifetime -- what filling
-    // and draining the chip costs -- shorter.  (The encoder needs all 20 it can get: 98 us, 106 at 16.)  Deeper launches run
-    // with 16: the longer the launch, the more 32 resident tiles per CU cost it (round 4, profiles/r04_c3_dec_sweep.txt:
-    // 64 x 4096^2 348.9 -> 346.8 us, 256 x 1432 -> 1393, 512 x 2883 -> 2792: with twice the L2's worth of tiles in flight per XCD
-    // the halo rows of a band are fetched again, 1.06 x the algorithmic bytes in round 1's counters; at 16 they are not).
+    // How many tiles a CU holds at one time (the dynamic LDS is padded to that: lds_for_waves).  Its LDS would allow 32.
+    //  * Fewer than 8 192 tiles: all it can get -- the launch ends when its slowest wave does.
+    //  * A PLAIN decode (the tile holds the pyramid: no seeds) of 8 192 tiles and more: TEN on rows up to 4 096 pixels and up to
+    //    four levels, twelve otherwise.  Round 4, in-process A/B of builds on the same placed planes (tools/ab.py,
+    //    profiles/r04_ab_dec_waves.txt): 64 x 4096^2 level 4 against the 16 of the round's first builds: 9 tiles -1.9 %, 10 -5.2 %,
+    //    11 -3.1 %, 12 -0.8 %; 256 x -6.3 %, 512 x -5.5 % (2.789 -> 2.636 ms = 0.815 of 8 TB/s), 40 / 24 / 16 x -4.3 / -4.1 / -3.4 %,
+    //    8 x -0.8 %; levels 1 / 2 -1.4 / -2.1 %; 300 x 1920 x 1080 -2.3 %.  On 8192- and 16384-wide rows and at five levels twelve
+    //    is the better number (-2.8 / -2.3 ... -3.6 / -2.0 % against -2.4 / -0.6 ... -2.3 / -0.2 % at ten).  The likely reason:
+    //    with ten tiles per CU the 320 tiles an XCD has in flight read 2.7 MB at a time, which -- halo lines included -- stays in
+    //    its 4 MB L2; at 16 and more it does not (round 1 counted 1.06 x the algorithmic bytes fetched at 32); below ten the
+    //    latency is no longer covered.
+    //  * A decode that rebuilds levels above its tiles (the cone) or starts from seed planes: 20 on launches one to eight
+    //    rounds of resident tiles deep (8 192 ... 65 536 tiles: a lone 16384^2 frame at level 8 has 32 768; the tile lifetime --
+    //    what filling and draining the chip costs -- is shorter at the same rate: 101.3 us at 32, 99.1 at 20, 98.5 at 16, 109.8
+    //    at 12, profiles/r03_waves_sweep.txt), 16 on deeper ones; these lose with ten or twelve (+3 ... +10 %: the cone's far
+    //    loads and its walk want the occupancy).  (The encoder needs all 20 it can get: 98 us, 106 at 16.)
     const int dec_waves_forced = HGI_KNOB(HGI_DEC_WAVES, -1);
     const u64 tiles = (u64)g.nfast + g.nedge;
-    const int dec_waves = dec_waves_forced >= 0 ? dec_waves_forced : tiles >= 65536 ? HGI_DEC_DEEP_WAVES : tiles >= 8192 ? HGI_DEC_SHALLOW_WAVES : 0;
+    int dec_waves = 0;
+    if (resident_tiles >= 0)
+        dec_waves = resident_tiles;      // the caller's choice (the placement probe, hgi_planes.hip: it has to keep measuring the
+                                         // same thing whatever the policy or a knob says)
+    else if (dec_waves_forced >= 0)
+        dec_waves = dec_waves_forced;
+    else if (tiles < 8192)
+        dec_waves = 0;
+    else if (!seeds)
+        dec_waves = f.width <= 4096 && k <= 4 ? HGI_DEC_STREAM_WAVES : HGI_DEC_STREAM_WAVES_WIDE;
+    else
+        dec_waves = tiles >= 65536 ? HGI_DEC_DEEP_WAVES : HGI_DEC_SHALLOW_WAVES;
     const size_t lds = lds_for_waves((size_t)buf_bytes(nh), dec_waves);
     const dim3 blocks(((g.nedge + 7u) & ~7u) + g.nfast);
 #define HGI_DEC(I, SE) hipLaunchKernelGGL((k_dec_tiles<I, SE, TH>), blocks, b, lds, s, grid, img, f, k, sd, g, r.aligned)

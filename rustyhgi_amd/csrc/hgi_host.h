@@ -29,6 +29,7 @@ struct hgi_ctx {
     bool have_pipe;
     uint8_t *pin;             // pinned host memory (entropy stage: histograms and stream sizes come down without stalling the host)
     size_t pin_bytes;
+    int probe_resident_tiles; // -1 except inside the placement probe, whose decode launches run at a fixed occupancy (hgi_planes.hip)
 };
 
 namespace hgi {

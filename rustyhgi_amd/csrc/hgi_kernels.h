@@ -62,10 +62,11 @@ hipError_t launch_encode_level(uint8_t *rec, uint8_t *grid, const Frames &f, uin
 
 // ---- fused path: the last k <= kFusedMaxLevels levels of every tile in one launch ------------
 // (_64 / _32 = tile rows; k <= kFusedMaxLevels resp. kFusedMaxLevelsSmall; row_limit: pixel rows (multiple of 64)
-// above which tile rows are launched, 0 = all -- bands of a frame that is still being uploaded)
+// above which tile rows are launched, 0 = all -- bands of a frame that is still being uploaded; resident_tiles: tiles per CU a
+// decode launch is held to, -1 = the library's policy (hgi_fused_impl.h) -- the placement probe asks for 0 = all the LDS allows)
 #define HGI_DECLARE_FUSED(TH)                                                                                      \
     hipError_t launch_decode_fused_##TH(const uint8_t *grid, uint8_t *img, const Frames &f, uint32_t k, int interp, \
-                                        const Seeds *seeds, hipStream_t s, uint32_t row_limit);                    \
+                                        const Seeds *seeds, hipStream_t s, uint32_t row_limit, int resident_tiles); \
     hipError_t launch_encode_fused_##TH(const uint8_t *img, uint8_t *grid, const Frames &f, uint32_t k, int interp, \
                                         const Lut256 &lut, bool lut_is_identity, const Seeds *seeds, hipStream_t s, \
                                         uint32_t row_limit);

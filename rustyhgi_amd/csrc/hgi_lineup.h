@@ -70,16 +70,19 @@ inline std::vector<size_t> plane_quota(const std::vector<size_t> &left, size_t p
 // supply allows (plane_quota), its chunks alternating between them: an encode of 6 GiB and more per plane is dealt to the XCDs as
 // contiguous eighths, i.e. eight chunks of each plane are in use at one time, and the more classes those touch the faster it
 // runs -- measured on 512 x 4096^2 with the grid plane on 8 + 0 / 7 + 1 / 6 + 2 / 4 + 4 chunks of two classes: 2.787 / 2.730 /
-// 2.670 / 2.654 ms (profiles/r04_planes_sides.txt, r04_c3_xcd_boxes.txt).  Among the feasible splits the one with the most evenly
-// spread planes wins.  Returns false (rows untouched) when no split is feasible yet.
-inline bool two_sides(const Groups &groups, size_t n, uint32_t count, Rows &rows)
+// 2.670 / 2.654 ms (profiles/r04_planes_sides.txt, r04_c3_xcd_boxes.txt); how the image planes are spread does not show.  Among the
+// feasible splits the one with the most evenly spread planes wins, the odd planes (what an encode WRITES) counting twice.
+// Returns false (rows untouched) when no split is feasible yet.  *odd_spread (optional) receives, for the chosen line-up, the
+// smallest number of chunks any odd plane has OUTSIDE its largest class (0: some grid plane sits on one class only).
+inline bool two_sides(const Groups &groups, size_t n, uint32_t count, Rows &rows, size_t *odd_spread = nullptr)
 {
     const size_t G = groups.size();
     const size_t planes_of[2] = {(size_t)(count + 1) / 2, (size_t)count / 2};      // even planes, odd planes
     if (G < 2 || G > 16 || count < 2) return false;
     // quotas[side][plane of the side][group] for a split; score = chunks that do NOT sit in their plane's largest share
-    auto evaluate = [&](size_t mask, std::vector<std::vector<size_t>> (&quota)[2]) -> long {
+    auto evaluate = [&](size_t mask, std::vector<std::vector<size_t>> (&quota)[2], size_t *spread) -> long {
         long score = 0;
+        *spread = n;
         for (int sd = 0; sd < 2; ++sd) {
             std::vector<size_t> left(G, 0);
             size_t have = 0;
@@ -96,25 +99,28 @@ inline bool two_sides(const Groups &groups, size_t n, uint32_t count, Rows &rows
                     left[g] -= q[g];
                 }
                 if (sum != n) return -1;
-                score += (long)(n - big);
+                score += (long)(sd == 1 ? 2 : 1) * (long)(n - big);
+                if (sd == 1 && n - big < *spread) *spread = n - big;
                 quota[sd].push_back(q);
             }
         }
         return score;
     };
-    size_t best = 0;
+    size_t best = 0, best_spread = 0, spread = 0;
     long best_score = -1;
     std::vector<std::vector<size_t>> quota[2], best_quota[2];
     for (size_t mask = 1; mask + 1 < ((size_t)1 << G); ++mask) {
-        const long score = evaluate(mask, quota);
+        const long score = evaluate(mask, quota, &spread);
         if (score > best_score) {
             best = mask;
             best_score = score;
+            best_spread = spread;
             best_quota[0] = quota[0];
             best_quota[1] = quota[1];
         }
     }
     if (!best) return false;
+    if (odd_spread) *odd_spread = best_spread;
     // hand the chunks out: plane by plane, the plane's groups taking turns (largest remaining share first)
     std::vector<size_t> next(G, 0);
     Rows plane_chunks(count);

@@ -43,6 +43,15 @@ hgi_status probe_pair_ms(hgi_ctx *c, const uint8_t *prev, uint8_t *cand, size_t 
     rows &= ~(size_t)63;
     const uint32_t h = (uint32_t)rows;
     constexpr int kWarm = 2, kTimed = 4;
+    // The probe is a decode launch at ALL the resident tiles per CU its LDS allows (32), not at the ten the library runs such
+    // a decode with: at ten the decoder no longer cares where its planes lie (which is part of why ten is faster), at 32 it
+    // shows the classes best (0.93-0.94 across classes against 0.97-1.0 within one) -- and what the placement is for by now is
+    // the ENCODER, whose time follows the same pairing (0.349 against 0.367 ms per 64 frames).
+    struct Occupancy {
+        hgi_ctx *c;
+        explicit Occupancy(hgi_ctx *ctx) : c(ctx) { c->probe_resident_tiles = 0; }
+        ~Occupancy() { c->probe_resident_tiles = -1; }
+    } occupancy(c);
     for (int i = 0; i < kWarm + kTimed; ++i) {
         if (i == kWarm) HIP_TRY(hipEventRecord(c->ev_probe[0], c->stream));
         c->ws_used = 0;
@@ -424,9 +433,13 @@ hgi_status alloc_composed(hgi_ctx *c, size_t bytes, uint32_t count, void **plane
         // dealt to the XCDs as contiguous eighths needs (hgi_fused_impl.h, xcd_mode(): from 6 GiB per plane the eight XCDs work
         // on eight different chunks of each plane at one time): with a per-offset line-up whose sides flip along the plane, one
         // XCD reads class A and writes B while another reads B and writes A (profiles/r04_planes_sides.txt).
-        ok = sided = lineup::two_sides(groups, n, count, rows);
-        if (ok) break;
+        size_t odd_spread = 0;
+        ok = sided = lineup::two_sides(groups, n, count, rows, &odd_spread);
+        // A line-up that leaves a grid plane (almost) on one class costs the encoder of a large batch 3-6 % (hgi_lineup.h): a
+        // few more chunks -- at most two planes' worth beyond the request -- usually bring the second class.
+        if (ok && (odd_spread * 8 >= n * 3 || n < 4 || h.size() >= need + 2 * n || h.size() >= max_chunks)) break;
         if (h.size() < max_chunks) continue;      // more chunks (and spacers) first
+        if (ok) break;
         // second choice, at the end of the budget: per offset -- neighbouring planes differ at every offset, the sides may flip
         ok = lineup::per_offset(groups, n, count, rows);
         break;

@@ -134,12 +134,27 @@ int main(int argc, char **argv)
         for (int k = 0; k < 16; ++k) h7[2].push_back(j++);
         REQUIRE(two_sides(h7, 8, 3, rows));
         for (size_t m = 0; m + 1 < 8; ++m) REQUIRE(group_of(h7, rows[m][1]) != group_of(h7, rows[m + 1][1]) && group_of(h7, rows[m][1]) != 2);
+        // 11 / 15 / 6 (a box of the pool): the grid plane cannot be spread, the image planes are (5 + 3); ONE more chunk of the second
+        // class and the sides swap: the grid plane gets 4 + 4 -- which is why alloc_composed keeps looking a little longer
+        {
+            Groups b = {{}, {}, {}};
+            int t = 0;
+            for (int k = 0; k < 11; ++k) b[0].push_back(t++);
+            for (int k = 0; k < 15; ++k) b[1].push_back(t++);
+            for (int k = 0; k < 6; ++k) b[2].push_back(t++);
+            size_t sp = 99;
+            REQUIRE(two_sides(b, 8, 3, rows, &sp) && sp == 0);
+            b[1].push_back(t++);
+            REQUIRE(two_sides(b, 8, 3, rows, &sp) && sp == 4);
+            for (size_t m = 0; m < 8; ++m) REQUIRE(group_of(b, rows[m][0]) == 1 && group_of(b, rows[m][2]) == 1 && group_of(b, rows[m][1]) != 1);
+        }
         // 8 / 8 / 8: two classes share the image planes half and half, the third is the grid
         Groups e8 = {{}, {}, {}};
         j = 0;
         for (int gi = 0; gi < 3; ++gi)
             for (int k = 0; k < 8; ++k) e8[(size_t)gi].push_back(j++);
-        REQUIRE(two_sides(e8, 8, 3, rows));
+        size_t spread = 99;
+        REQUIRE(two_sides(e8, 8, 3, rows, &spread) && spread == 0);      // the one odd plane sits on one class: nothing else left
         for (int pl : {0, 2}) {
             int a = 0;
             for (size_t m = 0; m < 8; ++m) a += group_of(e8, rows[m][(size_t)pl]) == group_of(e8, rows[0][(size_t)pl]);
