@@ -140,10 +140,19 @@ size_t ws_need(const hgi_ctx *c, uint32_t w, uint32_t h, uint32_t levels, size_t
 // the dependent chain per wave.  Measured crossover on MI355X at level 4 (tools/size_sweep.py): equal at ~2000
 // tiles; 32-row ahead by 15-35 % below ~1200, 64-row ahead by 12 % at 4000.  A single small frame (up to about two
 // waves per CU of 32-row tiles) ends when its slowest wave does, and that wave's chain is mostly its own VALU work:
-// 128 x 16 tiles halve the finest level's share of it (profiles/r03_sizes.txt).  (Knobs build: HGI_TILE_H = 16 | 32 | 64
-// forces one where the pyramid fits -- the test suite runs every geometry on every shape; HGI_TILE16_MAX moves the lower
-// crossover.)
-uint32_t use_tile_rows(uint32_t w, uint32_t h, uint32_t k, size_t batch, bool encode)
+// 128 x 16 tiles halve the finest level's share of it (profiles/r03_sizes.txt).
+// Round 4: a PLAIN encode (the tile holds the pyramid: no seeds) keeps the 32-row tiles on large calls too, on rows up to 8 192
+// pixels and below 6 GiB per plane.  The encoder needs its 20 resident tiles per CU (fewer: -2 ... -6 %), and with 64-row tiles
+// those read 5.5 MB at a time per XCD -- more than its 4 MB L2; with 32-row tiles it is half (the decoder gets the same effect
+// from holding ten 64-row tiles, hgi_fused_impl.h launch_decode_fused).  Measured, one process per setting on the knobs build
+// (profiles/r04_enc_tile_rows.txt): 64 x 4096^2 level 4 356.0 -> 341.9 us (-4.0 %), 128 x -3.3 %, 256 x -2.7 %, levels 1 / 2 / 5
+// -2.6 / -3.7 / -5.6 %, 16 x 8192^2 -1.5 %, 1 / 4 x 4096^2 -9 / -6 %, 16 x 1920 x 1080 -10 %; no change at 2 and 8 x 4096^2.  Not on
+// 16384-wide rows (+7 %), not for encodes that rebuild levels in the kernel (the cone: +12 ... +19 %), and not from 6 GiB per
+// plane, where the launch is dealt to the XCDs as contiguous eighths and the 64-row tiles stay ahead on every box sampled
+// (2.65-2.78 against 2.73-2.80 ms per 512 frames).
+// (Knobs build: HGI_TILE_H = 16 | 32 | 64 forces one where the pyramid fits -- the test suite runs every geometry on every
+// shape; HGI_TILE16_MAX moves the lower crossover.)
+uint32_t use_tile_rows(uint32_t w, uint32_t h, uint32_t k, size_t batch, bool encode, bool plain)
 {
     const int forced = HGI_KNOB(HGI_TILE_H, 0);
     const uint64_t tiny_max = (uint64_t)HGI_KNOB(HGI_TILE16_MAX, HGI_TILE16_MAX);
@@ -155,7 +164,9 @@ uint32_t use_tile_rows(uint32_t w, uint32_t h, uint32_t k, size_t batch, bool en
     const uint64_t tx = (w + kTileW - 1) / kTileW;
     const uint64_t tiles64 = tx * ((h + 63) / 64) * batch, tiles32 = tx * ((h + 31) / 32) * batch;
     if (encode && fits16 && tiles32 <= tiny_max) return 16;      // (decode sits on the launch floor with 32-row tiles already)
-    return tiles64 < 1536 ? 32 : 64;
+    if (tiles64 < 1536) return 32;
+    if (encode && plain && w <= 8192 && (uint64_t)w * h * batch < ((uint64_t)6 << 30)) return 32;
+    return 64;
 }
 
 // Pyramids deeper than eight levels: the one-workgroup-per-frame kernel codes the lattice plane when it is small (at most
@@ -171,7 +182,7 @@ hipError_t launch_encode_fused(const uint8_t *img, uint8_t *grid, const Frames &
                                const Lut256 &lut, bool ident, const Seeds *seeds, hipStream_t s, uint32_t row_limit = 0)
 {
     const uint32_t rows = row_limit && row_limit < f.height ? row_limit : f.height;   // what this launch really covers
-    switch (use_tile_rows(f.width, rows, k, f.batch, true)) {
+    switch (use_tile_rows(f.width, rows, k, f.batch, true, seeds == nullptr)) {
     case 16: return launch_encode_fused_16(img, grid, f, k, interp, lut, ident, seeds, s, row_limit);
     case 32: return launch_encode_fused_32(img, grid, f, k, interp, lut, ident, seeds, s, row_limit);
     default: return launch_encode_fused_64(img, grid, f, k, interp, lut, ident, seeds, s, row_limit);
@@ -182,7 +193,7 @@ hipError_t launch_decode_fused(const uint8_t *grid, uint8_t *img, const Frames &
                                const Seeds *seeds, hipStream_t s, uint32_t row_limit = 0, int resident_tiles = -1)
 {
     const uint32_t rows = row_limit && row_limit < f.height ? row_limit : f.height;
-    switch (use_tile_rows(f.width, rows, k, f.batch, false)) {
+    switch (use_tile_rows(f.width, rows, k, f.batch, false, seeds == nullptr)) {
     case 16: return launch_decode_fused_16(grid, img, f, k, interp, seeds, s, row_limit, resident_tiles);
     case 32: return launch_decode_fused_32(grid, img, f, k, interp, seeds, s, row_limit, resident_tiles);
     default: return launch_decode_fused_64(grid, img, f, k, interp, seeds, s, row_limit, resident_tiles);
