@@ -37,6 +37,9 @@ hgi_status fail(hgi_status st, const char *fmt, ...)
 namespace {
 
 // Compile-time constants of the release library (hgi_knobs.h: the knobs build reads the same names from the environment)
+#ifndef HGI_ENC_L1_TILE_ROWS
+#define HGI_ENC_L1_TILE_ROWS 16    // tile rows of a plain one-level encode (the finest pass alone) on large calls: use_tile_rows()
+#endif
 #ifndef HGI_TILE16_MAX
 #define HGI_TILE16_MAX 600    // an ENCODE of at most this many 32-row tiles runs on 16-row tiles instead (profiles/r03_sizes.txt: 1920 x 1080 is 510)
 #endif
@@ -165,6 +168,10 @@ uint32_t use_tile_rows(uint32_t w, uint32_t h, uint32_t k, size_t batch, bool en
     const uint64_t tiles64 = tx * ((h + 63) / 64) * batch, tiles32 = tx * ((h + 31) / 32) * batch;
     if (encode && fits16 && tiles32 <= tiny_max) return 16;      // (decode sits on the launch floor with 32-row tiles already)
     if (tiles64 < 1536) return 32;
+    // one level (the finest pass alone, P_fine): a tile has next to no halo there, and still smaller tiles keep still less in
+    // flight: 16 rows, at any size (64 x 4096^2: 339 -> 333 us; 512 x: 2.69 ms whatever the planes' classes, where the 64-row
+    // tiles dealt as eighths give 2.64 ... 2.89; profiles/r04_pfine_sweep.txt)
+    if (encode && plain && k == 1 && w <= 8192) return HGI_ENC_L1_TILE_ROWS;
     if (encode && plain && w <= 8192 && (uint64_t)w * h * batch < ((uint64_t)6 << 30)) return 32;
     return 64;
 }

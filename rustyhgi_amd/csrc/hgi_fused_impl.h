@@ -120,6 +120,9 @@ static_assert(TH != 64 || 18 * (buf_bytes(4) + rbuf_bytes(4) + 256) <= 160 * 102
 #ifndef HGI_DEC_STREAM_WAVES_WIDE
 #define HGI_DEC_STREAM_WAVES_WIDE 12   // ... and on wider rows or five levels
 #endif
+#ifndef HGI_DEC_STREAM_WAVES_L1
+#define HGI_DEC_STREAM_WAVES_L1 8      // ... and at ONE level (the finest pass alone: a tile's lifetime is shortest there)
+#endif
 #ifndef HGI_XCD_MODE
 #define HGI_XCD_MODE -1     // the XCD dealing policy (block_role): 0 contiguous eighths, 1 whole bands round-robin, -1 by size (xcd_mode())
 #endif
@@ -2039,7 +2042,8 @@ hipError_t HGI_TILED(launch_decode_fused)(const uint8_t *grid, uint8_t *img, con
     //    is the better number (-2.8 / -2.3 ... -3.6 / -2.0 % against -2.4 / -0.6 ... -2.3 / -0.2 % at ten).  The likely reason:
     //    with ten tiles per CU the 320 tiles an XCD has in flight read 2.7 MB at a time, which -- halo lines included -- stays in
     //    its 4 MB L2; at 16 and more it does not (round 1 counted 1.06 x the algorithmic bytes fetched at 32); below ten the
-    //    latency is no longer covered.
+    //    latency is no longer covered.  At ONE level (the finest pass alone, P_fine) eight: 64 x 4096^2 0.3360 -> 0.3277 ms, 512 x
+    //    2.768 -> 2.692 (profiles/r04_ab_pfine.txt).
     //  * A decode that rebuilds levels above its tiles (the cone) or starts from seed planes: 20 on launches one to eight
     //    rounds of resident tiles deep (8 192 ... 65 536 tiles: a lone 16384^2 frame at level 8 has 32 768; the tile lifetime --
     //    what filling and draining the chip costs -- is shorter at the same rate: 101.3 us at 32, 99.1 at 20, 98.5 at 16, 109.8
@@ -2056,7 +2060,7 @@ hipError_t HGI_TILED(launch_decode_fused)(const uint8_t *grid, uint8_t *img, con
     else if (tiles < 8192)
         dec_waves = 0;
     else if (!seeds)
-        dec_waves = f.width <= 4096 && k <= 4 ? HGI_DEC_STREAM_WAVES : HGI_DEC_STREAM_WAVES_WIDE;
+        dec_waves = f.width > 4096 || k > 4 ? HGI_DEC_STREAM_WAVES_WIDE : k == 1 ? HGI_DEC_STREAM_WAVES_L1 : HGI_DEC_STREAM_WAVES;
     else
         dec_waves = tiles >= 65536 ? HGI_DEC_DEEP_WAVES : HGI_DEC_SHALLOW_WAVES;
     const size_t lds = lds_for_waves((size_t)buf_bytes(nh), dec_waves);
