@@ -65,6 +65,23 @@ inline std::vector<size_t> plane_quota(const std::vector<size_t> &left, size_t p
     return q;
 }
 
+// How far a plane is spread: of its n chunks, taken q[g] from group g, how many lie OUTSIDE the class it has most of.  A group with
+// a single member does not count as a class of its own here: such chunks are typically the ones that straddle two classes (their
+// probes come out between the populations against every group: 0.966 / 0.970 / 0.971 of the yardstick where members are at 0.98-1.03
+// and strangers at 0.92-0.95) -- fine as neighbours, but a grid plane on 6 + 1 + 1 of them runs like one on 8 + 0
+// (profiles/r04_two_classes.txt).
+inline size_t outside_largest(const Groups &groups, const std::vector<size_t> &q, size_t n)
+{
+    size_t big = 0, lone = 0;
+    for (size_t g = 0; g < q.size(); ++g) {
+        if (groups[g].size() < 2)
+            lone += q[g];
+        else
+            big = q[g] > big ? q[g] : big;
+    }
+    return n > big + lone ? n - big - lone : 0;
+}
+
 // First choice: TWO SIDES.  The groups are split into a side for the even planes (image, image') and a side for the odd ones
 // (grid) such that each side holds enough chunks.  Every plane is then spread over the groups of its side as EVENLY as the
 // supply allows (plane_quota), its chunks alternating between them: an encode of 6 GiB and more per plane is dealt to the XCDs as
@@ -73,7 +90,7 @@ inline std::vector<size_t> plane_quota(const std::vector<size_t> &left, size_t p
 // 2.670 / 2.654 ms (profiles/r04_planes_sides.txt, r04_c3_xcd_boxes.txt); how the image planes are spread does not show.  Among the
 // feasible splits the one with the most evenly spread planes wins, the odd planes (what an encode WRITES) counting twice.
 // Returns false (rows untouched) when no split is feasible yet.  *odd_spread (optional) receives, for the chosen line-up, the
-// smallest number of chunks any odd plane has OUTSIDE its largest class (0: some grid plane sits on one class only).
+// smallest number of chunks any odd plane has OUTSIDE its largest class (outside_largest; 0: some grid plane sits on one class only).
 inline bool two_sides(const Groups &groups, size_t n, uint32_t count, Rows &rows, size_t *odd_spread = nullptr)
 {
     const size_t G = groups.size();
@@ -92,15 +109,15 @@ inline bool two_sides(const Groups &groups, size_t n, uint32_t count, Rows &rows
             quota[sd].clear();
             for (size_t p = 0; p < planes_of[sd]; ++p) {
                 std::vector<size_t> q = plane_quota(left, planes_of[sd] - p, n);
-                size_t sum = 0, big = 0;
+                size_t sum = 0;
                 for (size_t g = 0; g < G; ++g) {
                     sum += q[g];
-                    big = q[g] > big ? q[g] : big;
                     left[g] -= q[g];
                 }
                 if (sum != n) return -1;
-                score += (long)(sd == 1 ? 2 : 1) * (long)(n - big);
-                if (sd == 1 && n - big < *spread) *spread = n - big;
+                const size_t out = outside_largest(groups, q, n);
+                score += (long)(sd == 1 ? 2 : 1) * (long)out;
+                if (sd == 1 && out < *spread) *spread = out;
                 quota[sd].push_back(q);
             }
         }
@@ -146,8 +163,8 @@ inline bool two_sides(const Groups &groups, size_t n, uint32_t count, Rows &rows
     return true;
 }
 
-// Second choice, at the end of the budget: per offset -- neighbouring planes differ at every offset, but the sides may flip
-// along the plane.  Fills rows as far as it gets; returns whether all n offsets lined up.
+// Last choice, at the end of the budget without two sides: per offset -- neighbouring planes differ at every offset, but the sides
+// may flip along the plane.  Size-greedy (whatever completes).  Fills rows as far as it gets; returns whether all n offsets lined up.
 inline bool per_offset(const Groups &groups, size_t n, uint32_t count, Rows &rows)
 {
     std::vector<size_t> left(groups.size()), next(groups.size(), 0);
@@ -161,6 +178,76 @@ inline bool per_offset(const Groups &groups, size_t n, uint32_t count, Rows &row
         rows.push_back(row);
     }
     return true;
+}
+
+// Second choice, where two sides leave a grid plane on one class (two classes are all the search found): per offset again, but
+// SPREADING every plane over the groups: at each offset a plane prefers the group it has used least so far
+// (ties: the group with most left), as long as the remaining offsets can still be completed the size-greedy way; where they could
+// not, the offset is arranged size-greedy itself.  With two groups of 12 and more chunks each, three planes of eight alternate
+// perfectly (4 + 4 each); with 27 / 13 the grid plane still gets 4 + 4; with 28 / 10, 6 + 2.  Returns whether all n offsets
+// lined up (the same promise as per_offset).
+inline bool alternating(const Groups &groups, size_t n, uint32_t count, Rows &rows)
+{
+    const size_t G = groups.size();
+    std::vector<size_t> left(G), next(G, 0);
+    for (size_t g = 0; g < G; ++g) left[g] = groups[g].size();
+    std::vector<std::vector<size_t>> used(count, std::vector<size_t>(G, 0));      // [plane][group] chunks taken so far
+    auto can_finish = [&](std::vector<size_t> trial, size_t offsets) {
+        for (size_t m = 0; m < offsets; ++m)
+            if (arrange(trial, count).empty()) return false;
+        return true;
+    };
+    rows.clear();
+    for (size_t m = 0; m < n; ++m) {
+        std::vector<size_t> trial = left;
+        std::vector<int> seq;
+        int prev = -1;
+        for (uint32_t i = 0; i < count; ++i) {
+            int pick = -1;
+            for (size_t g = 0; g < G; ++g) {
+                if ((int)g == prev || trial[g] == 0) continue;
+                if (pick < 0 || used[i][g] < used[i][(size_t)pick] || (used[i][g] == used[i][(size_t)pick] && trial[g] > trial[(size_t)pick])) pick = (int)g;
+            }
+            if (pick < 0) break;
+            seq.push_back(pick);
+            --trial[(size_t)pick];
+            prev = pick;
+        }
+        if (seq.size() < count || !can_finish(trial, n - m - 1)) {
+            trial = left;
+            seq = arrange(trial, count);
+            if (seq.empty()) return false;
+        }
+        left = trial;
+        std::vector<int> row;
+        for (uint32_t i = 0; i < count; ++i) {
+            const size_t g = (size_t)seq[i];
+            ++used[i][g];
+            row.push_back(groups[g][next[g]++]);
+        }
+        rows.push_back(row);
+    }
+    return true;
+}
+
+// For a line-up `rows` over `groups`: the smallest number of chunks any odd plane has OUTSIDE its largest class (what two_sides
+// reports as *odd_spread).
+inline size_t odd_spread_of(const Groups &groups, const Rows &rows, uint32_t count)
+{
+    size_t chunks = 0;
+    for (auto &g : groups)
+        for (int j : g) chunks = (size_t)j + 1 > chunks ? (size_t)j + 1 : chunks;
+    std::vector<int> group_of(chunks, -1);
+    for (size_t g = 0; g < groups.size(); ++g)
+        for (int j : groups[g]) group_of[(size_t)j] = (int)g;
+    size_t spread = rows.size();
+    for (uint32_t i = 1; i < count; i += 2) {
+        std::vector<size_t> per(groups.size(), 0);
+        for (auto &row : rows) ++per[(size_t)group_of[(size_t)row[i]]];
+        const size_t out = outside_largest(groups, per, rows.size());
+        if (out < spread) spread = out;
+    }
+    return spread;
 }
 
 // Could not be established within the budget: the offsets that did line up stay as they are (a partly separated stream is still

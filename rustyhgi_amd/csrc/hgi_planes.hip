@@ -387,7 +387,8 @@ hgi_status alloc_composed(hgi_ctx *c, size_t bytes, uint32_t count, void **plane
     int last_group = -1;
     auto ptr_of = [&](int j) { return stage + (size_t)j * kChunk; };
     lineup::Rows rows;      // [offset][plane] -> chunk
-    bool ok = false, sided = false;
+    bool ok = false, sided = false, two_only = false;
+    size_t odd_spread = 0;
     size_t spacer_gib = 4, spacer_total = 0;
     const size_t spacer_budget = room > max_chunks ? (room - max_chunks < 96 ? room - max_chunks : 96) : 0;      // GiB (kChunk is one)
     const bool trace = HGI_SWITCH(HGI_PLANES_TRACE);
@@ -433,22 +434,54 @@ hgi_status alloc_composed(hgi_ctx *c, size_t bytes, uint32_t count, void **plane
         // dealt to the XCDs as contiguous eighths needs (hgi_fused_impl.h, xcd_mode(): from 6 GiB per plane the eight XCDs work
         // on eight different chunks of each plane at one time): with a per-offset line-up whose sides flip along the plane, one
         // XCD reads class A and writes B while another reads B and writes A (profiles/r04_planes_sides.txt).
-        size_t odd_spread = 0;
-        ok = sided = lineup::two_sides(groups, n, count, rows, &odd_spread);
+        const lineup::Groups *from = &groups;
+        lineup::Groups two_largest;
+        if (HGI_KNOB(HGI_PLANES_TWO_CLASSES, 0)) {
+            // knobs build (tests, experiments): a device on which the search finds two classes only, emulated by lining up the
+            // chunks of the two largest groups alone
+            size_t a = 0, b = 0;
+            for (size_t g = 1; g < groups.size(); ++g)
+                if (groups[g].size() > groups[a].size()) a = g;
+            for (size_t g = 0; g < groups.size(); ++g)
+                if (g != a && (b == a || groups[g].size() > groups[b].size())) b = g;
+            if (a == b || groups[a].size() < n * ((count + 1) / 2) || groups[b].size() < n * (count / 2)) {
+                if (h.size() < max_chunks) continue;
+            } else {
+                two_largest.push_back(groups[a]);
+                two_largest.push_back(groups[b]);
+                from = &two_largest;
+                two_only = true;
+            }
+        }
+        ok = sided = lineup::two_sides(*from, n, count, rows, &odd_spread);
         // A line-up that leaves a grid plane (almost) on one class costs the encoder of a large batch 3-6 % (hgi_lineup.h): a
         // few more chunks -- at most two planes' worth beyond the request -- usually bring the second class.
-        if (ok && (odd_spread * 8 >= n * 3 || n < 4 || h.size() >= need + 2 * n || h.size() >= max_chunks)) break;
+        const bool searched = h.size() >= need + 2 * n || h.size() >= max_chunks || two_only;
+        if (ok && (odd_spread * 8 >= n * 3 || n < 4 || searched)) {
+            // They did not (two classes is all the search found): PER OFFSET then -- neighbouring planes differ at every offset
+            // and every plane alternates between the classes.  Some XCDs then read class A and write B while others read B and
+            // write A, which costs less than a grid plane on one class does: 512 x 4096^2, both line-ups of the same two
+            // groups, encode 2.800-2.814 -> 2.724-2.735 ms, decode 2.61-2.68 -> 2.64-2.72 (profiles/r04_two_classes.txt).
+            // (A grid plane on 7 + 1 chunks of two classes is level with it, on 6 + 2 ahead: hgi_lineup.h.)
+            lineup::Rows alternating;
+            if (odd_spread * 8 < n && n >= 4 && !HGI_SWITCH(HGI_PLANES_SIDES_ONLY) && lineup::alternating(*from, n, count, alternating) &&
+                lineup::odd_spread_of(*from, alternating, count) * 4 >= n) {
+                rows = alternating;
+                sided = false;
+            }
+            break;
+        }
         if (h.size() < max_chunks) continue;      // more chunks (and spacers) first
         if (ok) break;
-        // second choice, at the end of the budget: per offset -- neighbouring planes differ at every offset, the sides may flip
-        ok = lineup::per_offset(groups, n, count, rows);
+        // at the end of the budget without two sides: per offset, as far as it gets
+        ok = lineup::per_offset(*from, n, count, rows);
         break;
     }
     if (!ok) lineup::fill_rest(rows, n, count, h.size());      // what did line up stays; the rest in creation order
     if (trace) {
         fprintf(stderr, "hgi_planes_alloc: %zu chunks created, %zu GiB of spacers, %zu groups:", h.size(), spacer_total, groups.size());
         for (auto &g : groups) fprintf(stderr, " %zu", g.size());
-        fprintf(stderr, " -> line-up %s;", !ok ? "INCOMPLETE" : sided ? "complete, two sides" : "complete, per offset");
+        fprintf(stderr, " -> line-up %s%s;", !ok ? "INCOMPLETE" : sided ? "complete, two sides" : "complete, per offset", two_only ? " (of the two largest groups alone)" : "");
         for (uint32_t i = 0; i < count; ++i) {      // how many chunks of which group each plane got
             std::vector<size_t> from(groups.size(), 0);
             for (size_t m = 0; m < n; ++m)

@@ -6,6 +6,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <random>
+#include <array>
 #include <set>
 
 #include "../../rustyhgi_amd/csrc/hgi_lineup.h"
@@ -64,9 +65,23 @@ int main(int argc, char **argv)
             groups[(size_t)label[(size_t)cls[j]]].push_back((int)j);
         }
         Rows rows;
-        bool two = two_sides(groups, n, count, rows), complete = two;
+        size_t reported = 99;
+        bool two = two_sides(groups, n, count, rows, &reported), complete = two;
         if (two) {
             ++sided;
+            REQUIRE(count < 2 || odd_spread_of(groups, rows, count) == reported);
+            // what alloc_composed does when the odd planes come out (almost) on one class: the per-offset line-up of the same
+            // groups, if complete, keeps the promise of every offset and uses every chunk once
+            Rows alt;
+            if (alternating(groups, n, count, alt)) {
+                REQUIRE(alt.size() == n);
+                std::set<int> once;
+                for (auto &row : alt) {
+                    for (uint32_t i = 0; i + 1 < count; ++i) REQUIRE(group_of(groups, row[i]) != group_of(groups, row[i + 1]));
+                    for (int j : row) REQUIRE(once.insert(j).second);
+                }
+                REQUIRE(odd_spread_of(groups, alt, count) <= n);
+            }
             // every chunk of a plane differs in group from EVERY chunk of its neighbours
             for (uint32_t i = 0; i + 1 < count; ++i)
                 for (size_t a = 0; a < n; ++a)
@@ -159,6 +174,43 @@ int main(int argc, char **argv)
             int a = 0;
             for (size_t m = 0; m < 8; ++m) a += group_of(e8, rows[m][(size_t)pl]) == group_of(e8, rows[0][(size_t)pl]);
             REQUIRE(a == 4);
+        }
+        // two classes is all there is (18 / 18): two sides leave the grid plane on one class; the per-offset line-up alternates every
+        // plane (4 + 4), which is what alloc_composed then takes (odd_spread_of tells it)
+        {
+            Groups two = {{}, {}};
+            int t = 0;
+            for (int k = 0; k < 18; ++k) two[0].push_back(t++);
+            for (int k = 0; k < 18; ++k) two[1].push_back(t++);
+            size_t sp = 99;
+            REQUIRE(two_sides(two, 8, 3, rows, &sp) && sp == 0 && odd_spread_of(two, rows, 3) == 0);
+            Rows alt;
+            REQUIRE(alternating(two, 8, 3, alt) && odd_spread_of(two, alt, 3) == 4);
+            for (size_t m = 0; m < 8; ++m) {
+                REQUIRE(group_of(two, alt[m][0]) != group_of(two, alt[m][1]) && group_of(two, alt[m][1]) != group_of(two, alt[m][2]));
+                if (m) REQUIRE(group_of(two, alt[m][1]) != group_of(two, alt[m - 1][1]));
+            }
+            // uneven supplies, as a device hands them out: 27 / 13 still gives the grid plane 4 + 4, 28 / 10 gives it 6 + 2 (an
+            // offset at which the grid plane takes the large class costs two chunks of the small one), 30 / 8 nothing
+            for (auto want : {std::array<size_t, 3>{{27, 13, 4}}, std::array<size_t, 3>{{28, 10, 2}}, std::array<size_t, 3>{{30, 8, 0}}, std::array<size_t, 3>{{9, 11, 4}}}) {
+                Groups u = {{}, {}};
+                int v = 0;
+                for (size_t k = 0; k < want[0]; ++k) u[0].push_back(v++);
+                for (size_t k = 0; k < want[1]; ++k) u[1].push_back(v++);
+                const size_t nn = want[0] == 9 ? 4 : 8;
+                REQUIRE(alternating(u, nn, 3, alt) && alt.size() == nn);
+                for (auto &row : alt) REQUIRE(group_of(u, row[0]) != group_of(u, row[1]) && group_of(u, row[1]) != group_of(u, row[2]));
+                REQUIRE(odd_spread_of(u, alt, 3) == (want[0] == 9 ? 2 : want[2]));
+            }
+            REQUIRE(two_sides(h7, 8, 3, rows, &sp) && sp == 4 && odd_spread_of(h7, rows, 3) == 4);
+            // 24 / 14 / 1 / 1 (a box of the pool): the two lone chunks are no classes to spread a grid plane over -- two sides report 0,
+            // and the alternating line-up of the same groups gives 4 + 4
+            Groups lone = {{}, {}, {38}, {39}};
+            t = 0;
+            for (int k = 0; k < 24; ++k) lone[0].push_back(t++);
+            for (int k = 0; k < 14; ++k) lone[1].push_back(t++);
+            REQUIRE(two_sides(lone, 8, 3, rows, &sp) && sp == 0);
+            REQUIRE(alternating(lone, 8, 3, alt) && odd_spread_of(lone, alt, 3) >= 3);
         }
         Groups one = {{0, 1, 2, 3, 4, 5}};
         REQUIRE(!two_sides(one, 2, 3, rows) && !per_offset(one, 2, 3, rows));

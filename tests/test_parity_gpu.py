@@ -1137,10 +1137,12 @@ def test_planes_larger_than_a_chunk_are_composed_and_released(H, oracle):
     torch.cuda.synchronize()
     torch.cuda.empty_cache()
     free0 = torch.cuda.mem_get_info()[0]
-    F, S = 160, 4096                                     # 2.5 GiB per plane: three chunks each, the last one partly used
+    S = 4096
+    F = int(os.environ.get("HGI_TEST_COMPOSED_FRAMES", "160"))      # 2.5 GiB per plane: three chunks each, the last one partly used
+    chunks = (F * S * S + (1 << 30) - 1) >> 30
     planes = H.Planes(ctx, F * S * S, 3)
     assert len(set(planes.pointers)) == 3 and all(planes.pointers)
-    assert torch.cuda.mem_get_info()[0] <= free0 - 3 * (3 << 30) + (64 << 20)      # whole GiB chunks are what is held
+    assert torch.cuda.mem_get_info()[0] <= free0 - 3 * (chunks << 30) + (64 << 20)      # whole GiB chunks are what is held
     img, grid, out = (planes.torch(i, (F, S, S)) for i in range(3))
     _ffi.check(L.hgi_synth_u8_dev(ctx.handle, _ffi.SYNTH_RAMP, SEED0 + 3, 0, S, S, img.data_ptr(), F, S * S))
     lut = oracle.linear_lut(2)[0]
@@ -1161,7 +1163,7 @@ def test_planes_larger_than_a_chunk_are_composed_and_released(H, oracle):
         ms = ctypes.c_float(0)
         t = {}
         for a, b in ((0, 1), (1, 2)):
-            for m in range(2):
+            for m in range(chunks):
                 _ffi.check(L.hgi_probe_pair_u8_dev(ctx.handle, planes.pointers[a] + (m << 30), planes.pointers[b] + (m << 30), 1 << 30, ctypes.byref(ms)))
                 t[(a, b, m)] = ms.value
         assert max(t.values()) <= 1.04 * min(t.values()), t
@@ -1172,6 +1174,26 @@ def test_planes_larger_than_a_chunk_are_composed_and_released(H, oracle):
     torch.cuda.empty_cache()      # (torch keeps the clone's and the reductions' blocks cached: not ours)
     assert torch.cuda.mem_get_info()[0] >= free0 - (64 << 20), "hgi_planes_free did not return the chunks"
     ctx.close()
+
+
+def test_composed_planes_where_the_search_finds_two_classes_only():
+    """When two memory classes are all hgi_planes_alloc finds, a two-sided line-up leaves the grid plane on ONE class, which costs
+    the encoder of a large batch 3 % -- it then lines the planes up per offset, every plane alternating between the two
+    (csrc/hgi_planes.hip, alloc_composed; profiles/r04_two_classes.txt).  A child on the KNOBS build emulates such a device
+    (HGI_PLANES_TWO_CLASSES: only the two largest groups are lined up) and runs the composed-planes test above on planes of four
+    chunks: the codec bit-exact across the boundaries, every GiB offset of both pairs at the fast rate, every byte returned."""
+    import subprocess
+    import sys
+    env = knobs_env(HGI_PLANES_TWO_CLASSES="1", HGI_PLANES_TRACE="1", HGI_TEST_COMPOSED_FRAMES="256")
+    here = os.path.dirname(os.path.abspath(__file__))
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(here, "test_parity_gpu.py"), "-m", "gpu", "-q", "-x", "-s",
+                        "-k", "test_planes_larger_than_a_chunk_are_composed_and_released"],
+                       env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "1 passed" in r.stdout, r.stdout[-3000:] + r.stderr[-3000:]
+    lines = [l for l in (r.stdout + r.stderr).splitlines() if "groups:" in l]
+    assert lines, r.stderr[-2000:]
+    if "of the two largest groups alone" in lines[-1]:      # (the emulation needs two groups of 8 and 4 chunks within the budget)
+        assert "complete, per offset" in lines[-1] and "plane 1 = 2 x g" in lines[-1], lines[-1]
 
 
 @pytest.mark.parametrize("w,h,levels,q", [(256, 256, 4, 2), (256, 256, 4, 0), (1920, 1080, 4, 2), (13, 7, 3, 1), (1, 1, 0, 0),
