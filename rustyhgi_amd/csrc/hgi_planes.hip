@@ -389,6 +389,7 @@ hgi_status alloc_composed(hgi_ctx *c, size_t bytes, uint32_t count, void **plane
     lineup::Rows rows;      // [offset][plane] -> chunk
     bool ok = false, sided = false, two_only = false;
     size_t odd_spread = 0;
+    std::vector<std::pair<int, int>> distinct;      // pairs of groups (by their first chunks) seen to be two classes on a second probe
     size_t spacer_gib = 4, spacer_total = 0;
     const size_t spacer_budget = room > max_chunks ? (room - max_chunks < 96 ? room - max_chunks : 96) : 0;      // GiB (kChunk is one)
     const bool trace = HGI_SWITCH(HGI_PLANES_TRACE);
@@ -454,9 +455,53 @@ hgi_status alloc_composed(hgi_ctx *c, size_t bytes, uint32_t count, void **plane
             }
         }
         ok = sided = lineup::two_sides(*from, n, count, rows, &odd_spread);
-        // A line-up that leaves a grid plane (almost) on one class costs the encoder of a large batch 3-6 % (hgi_lineup.h): a
-        // few more chunks -- at most two planes' worth beyond the request -- usually bring the second class.
-        const bool searched = h.size() >= need + 2 * n || h.size() >= max_chunks || two_only;
+        // A line-up that leaves a grid plane (almost) on one class costs the encoder of a large batch 3-6 % (hgi_lineup.h): more
+        // chunks, behind spacers where the driver stays in one class, usually bring another -- sometimes only at the end of the
+        // budget of three times the request (a third class after 69 chunks and 92 GiB of spacers, 1.7 s: encode 2.666 ms where the
+        // two classes found until then gave 2.732, profiles/r04_two_classes.txt).
+        // The spread of a grid plane is worth what the classes under it are: two groups it is spread over must stream at the fast
+        // rate against EACH OTHER as well -- checked once per pair, on their newest members (the groups were founded on one probe
+        // of their first; 512 frames on a grid plane "spread" over two groups that were one class: 2.81 ms, like 8 + 0).  Groups
+        // that fail are merged, and the line-up is made again.
+        while (ok && !two_only && n >= 4 && odd_spread * 8 >= n) {
+            std::vector<int> group_of(h.size(), -1);
+            for (size_t g = 0; g < groups.size(); ++g)
+                for (int j : groups[g]) group_of[(size_t)j] = (int)g;
+            bool merged = false;
+            for (uint32_t i = 1; i < count && !merged; i += 2) {
+                std::vector<size_t> mine;      // the groups of two and more chunks this plane sits on
+                for (size_t m = 0; m < n; ++m) {
+                    const size_t g = (size_t)group_of[(size_t)rows[m][i]];
+                    bool seen = groups[g].size() < 2;
+                    for (size_t v : mine) seen = seen || v == g;
+                    if (!seen) mine.push_back(g);
+                }
+                for (size_t x = 0; x < mine.size() && !merged; ++x)
+                    for (size_t z = x + 1; z < mine.size() && !merged; ++z) {
+                        const size_t g = mine[x] < mine[z] ? mine[x] : mine[z], o = mine[x] < mine[z] ? mine[z] : mine[x];
+                        const std::pair<int, int> key(groups[g][0], groups[o][0]);
+                        bool known = false;
+                        for (auto &k : distinct) known = known || k == key;
+                        if (known) continue;
+                        bool other = false;
+                        float ratio = 0;
+                        const hgi_status st = y.other_class(c, ptr_of(groups[g].back()), ptr_of(groups[o].back()), &other, &ratio);
+                        if (st != HGI_OK) return bail(st);
+                        if (trace) fprintf(stderr, "hgi_planes_alloc: groups %zu and %zu under plane %u, chunks %d -> %d: %.3f of the yardstick -> %s\n", g, o, i, groups[g].back(), groups[o].back(), ratio, other ? "two classes" : "ONE class: merged");
+                        if (other) {
+                            distinct.push_back(key);
+                        } else {
+                            groups[g].insert(groups[g].end(), groups[o].begin(), groups[o].end());
+                            groups.erase(groups.begin() + (long)o);
+                            last_group = -1;
+                            merged = true;
+                        }
+                    }
+            }
+            if (!merged) break;
+            ok = sided = lineup::two_sides(groups, n, count, rows, &odd_spread);
+        }
+        const bool searched = h.size() >= need + (size_t)HGI_KNOB(HGI_PLANES_SEARCH_PLANES, 6) * n || h.size() >= max_chunks || two_only;
         if (ok && (odd_spread * 8 >= n * 3 || n < 4 || searched)) {
             // They did not (two classes is all the search found): PER OFFSET then -- neighbouring planes differ at every offset
             // and every plane alternates between the classes.  Some XCDs then read class A and write B while others read B and
@@ -522,10 +567,14 @@ hgi_status alloc_composed(hgi_ctx *c, size_t bytes, uint32_t count, void **plane
                 if (st != HGI_OK) return bail(st);
                 if (yes) continue;
                 int tries = 0;
-                for (size_t u = 0; u < h.size() && !yes && tries < 4; ++u) {
-                    if (used[u] || group_of[u] == group_of[(size_t)rows[m][i]] || group_of[u] == group_of[(size_t)rows[m][i + 1]]) continue;
+                // (first the unused chunks of other groups; then -- two classes may be all there is -- those of the failing chunk's own
+                // group: a chunk that straddles two classes joins a group and still fails against some members of the other)
+                for (size_t v = 0; v < 2 * h.size() && !yes && tries < 4; ++v) {
+                    const size_t u = v % h.size();
+                    const bool own = group_of[u] == group_of[(size_t)rows[m][i + 1]];
+                    if (used[u] || group_of[u] == group_of[(size_t)rows[m][i]] || own != (v >= h.size())) continue;
                     if (sided && !on_side[(size_t)group_of[u]][(i + 1) & 1]) continue;      // (the two sides stay what they are)
-                    if (i + 2 < count && group_of[u] == group_of[(size_t)rows[m][i + 2]]) continue;
+                    if (!own && i + 2 < count && group_of[u] == group_of[(size_t)rows[m][i + 2]]) continue;
                     ++tries;
                     bool a = false, b = true;
                     st = fast(rows[m][i], (int)u, &a);

@@ -35,5 +35,7 @@ esac
 case " $PASSES " in *" c4 "*) tools/c4_profile.sh "${TAG}_c4" > "$OUT/c4.log" 2>&1; echo "c4 rc=$?" >> "$OUT/passes.log";; esac
 HGI_PROF_FRAMES=$FRAMES python3 tools/summarize_prof.py "$OUT" > "$OUT/summary.md" 2>"$OUT/summarize.err"
 python3 tools/summarize_prof.py "$OUT" --traffic $FRAMES 4096 4 > "$OUT/traffic.json" 2>>"$OUT/summarize.err"
+# the raw per-launch counter tables are tens of MiB per pass (gpurun brings back 64 MiB at most): KEEP_RAW=1 keeps them
+[ -n "${KEEP_RAW:-}" ] || find "$OUT" -name '*_counter_collection.csv' -delete
 cat "$OUT/passes.log"
 tail -60 "$OUT/summary.md"
