@@ -772,7 +772,7 @@ class Codec:
         info = {"mode": self.args.placement}
         if self.planes is not None:
             info.update({"api": "hgi_planes_alloc(bytes, %d): neighbouring planes in different HBM regions (DESIGN.md 5.1)" % self.planes.count,
-                         "separated": self.planes.separated})
+                         "separated": self.planes.separated, "report": self.planes.report})
         if not compare:
             return info
         a = torch.empty((F, S, S), dtype=torch.uint8, device=self.dev)

@@ -117,7 +117,7 @@ struct Shard {
     int device = 0;
     size_t first = 0, frames = 0;
     // results
-    std::string error;
+    std::string error, planes_report;
     double alloc_s = 0, wall_s = 0, encode_ms = 0, decode_ms = 0;
     int separated = 0, settle_steps = 0;
     unsigned long long max_err = 0, sq_err = 0, checksum = 0;
@@ -146,6 +146,7 @@ static void worker(Shard &sh, uint32_t S, uint32_t levels, int steps, int warmup
         auto t0 = clk::now();
         MT(hgi_planes_alloc(ctx, sh.frames * n, 3, planes, &sh.separated));
         sh.alloc_s = std::chrono::duration<double>(clk::now() - t0).count();
+        if (!failed) sh.planes_report = hgi_planes_report(ctx);
     }
     if (!failed) MT(hgi_synth_u8_dev(ctx, HGI_SYNTH_RAMP, 0x48474930u + 3, sh.first, S, S, planes[0], sh.frames, n));
     auto step = [&] {
@@ -280,6 +281,7 @@ static int run(int argc, char **argv)
         std::printf("  device %d: frames %4zu (from %4zu)  planes %.3f s %s  settle %3d steps  encode %.4f ms  decode %.4f ms  (%.4f of 8 TB/s on the slower)  max err %llu  checksum %016llx\n",
                     sh.device, sh.frames, sh.first, sh.alloc_s, sh.separated ? "separated" : "NOT separated", sh.settle_steps, sh.encode_ms, sh.decode_ms,
                     2.0 * sh.frames * S * S / (std::max(sh.encode_ms, sh.decode_ms) * 1e-3) / 8e12, sh.max_err, sh.checksum);
+    for (auto &sh : shards) std::printf("  device %d planes: %s\n", sh.device, sh.planes_report.c_str());
     std::printf("  aggregate: %.1f Mpixels/s encode+decode (%.4f ms per step, max over the device threads)\n", value, wall / steps * 1e3);
     // one machine-readable line (the GPU test and profiles/r04_bench_cpp.txt read it)
     std::printf("{\"harness\": \"bench_cpp --devices\", \"devices\": %d, \"same_device\": %s, \"global_frames\": %zu, \"steps\": %d, \"value\": %.1f, "

@@ -220,10 +220,15 @@ HGI_API hgi_status hgi_huffman_plan(const uint64_t hist[286], uint8_t lens[286],
 /*    1 GiB (hipMemCreate) are mapped, chosen chunk by chunk (size rounded up to whole GiB).   */
 /*    Bounded: at most 3 x the requested bytes are ever created as candidates, plus at most    */
 /*    96 GiB of never-mapped spacers when the driver keeps handing out one class; what is not  */
-/*    handed out is released before the call returns (three planes of 8 GiB: 0.5-2 s).         */
+/*    handed out is released before the call returns (three planes of 8 GiB: 1-2 s).           */
 /* HGI_NO_PLACEMENT=1 in the environment skips all of it (plain allocations): the one variable */
 /* the library reads.  Call it while the device is otherwise idle: it measures.                */
 HGI_API hgi_status hgi_planes_alloc(hgi_ctx *ctx, size_t bytes, uint32_t count, void **planes, int *separated);
+/* One line on what the last hgi_planes_alloc of this ctx found and did -- candidates created,   */
+/* how many share which class, which line-up the planes got -- for logs and bench records (how   */
+/* fast a large encode runs follows it).  Owned by the ctx, overwritten by its    */
+/* next hgi_planes_alloc; "" before the first.                                                   */
+HGI_API const char *hgi_planes_report(hgi_ctx *ctx);
 HGI_API hgi_status hgi_planes_free(hgi_ctx *ctx, uint32_t count, void **planes);
 /* The probe itself: mean milliseconds of one decode launch streaming d_src -> d_dst over      */
 /* min(bytes, 2 GiB).  Overwrites d_dst.  Compare pairings of the caller's own buffers with it. */

@@ -52,6 +52,8 @@ extern "C" {
     /// `count` device planes of at least `bytes`, neighbours in different HBM classes (release with hgi_planes_free only)
     pub fn hgi_planes_alloc(ctx: *mut HgiCtx, bytes: usize, count: u32, planes: *mut *mut c_void, separated: *mut c_int) -> c_int;
     pub fn hgi_planes_free(ctx: *mut HgiCtx, count: u32, planes: *mut *mut c_void) -> c_int;
+    /// one line on what the ctx's last hgi_planes_alloc found and did (owned by the ctx)
+    pub fn hgi_planes_report(ctx: *mut HgiCtx) -> *const c_char;
     /// synthetic frames generated in place (kind 0 xy = benches/bench.rs:26-28, 1 noise, 2 ramp; frame f uses index first_frame + f)
     pub fn hgi_synth_u8_dev(ctx: *mut HgiCtx, kind: c_int, seed: u64, first_frame: u64, width: u32, height: u32,
                             d_out: *mut c_void, batch: usize, frame_stride: usize) -> c_int;

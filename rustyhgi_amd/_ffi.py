@@ -47,6 +47,7 @@ SYMBOLS = [
     ("hgi_huffman_plan", _int, [_vp, _vp, _vp, _vp, _sz, ctypes.POINTER(_sz)]),
     ("hgi_planes_alloc", _int, [_vp, _sz, _u32, ctypes.POINTER(_vp), ctypes.POINTER(_int)]),
     ("hgi_planes_free", _int, [_vp, _u32, ctypes.POINTER(_vp)]),
+    ("hgi_planes_report", ctypes.c_char_p, [_vp]),
     ("hgi_probe_pair_u8_dev", _int, [_vp, _vp, _vp, _sz, ctypes.POINTER(ctypes.c_float)]),
     ("hgi_timer_start", _int, [_vp]),
     ("hgi_timer_stop", _int, [_vp, ctypes.POINTER(ctypes.c_float)]),

@@ -422,6 +422,7 @@ hgi_status hgi_ctx_create(int device, hgi_ctx **out)
     c->pin = nullptr;
     c->pin_bytes = 0;
     c->probe_resident_tiles = -1;
+    c->planes_report[0] = 0;
     if (hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_hist[0], hipEventDisableTiming) != hipSuccess ||

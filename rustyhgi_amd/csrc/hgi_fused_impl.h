@@ -1996,8 +1996,9 @@ inline size_t lds_for_waves(size_t lds, int waves)
 // +10 %; 64 and 128 x 4096^2: +2.5 ... +6 %; profiles/r03_ab_xcd.txt, r04_c3_xcd_sweep.txt).  Once the eighths are 768 MiB and
 // more apart that is over, and for the ENCODER eight separate fronts are then faster than one: 384 ... 768 x 4096^2 -5 ... -6 %,
 // on every box sampled at 512 frames -0.7 ... -6 % (2.65-2.79 against 2.81-2.82 ms; equal at 256 and at 1024 frames).  The
-// DECODER, at the 16 resident tiles per CU it runs deep launches with, is equal or slower with eighths on every box
-// (+0.5 ... +2.4 %: 2.79-2.86 against 2.77-2.79 ms; profiles/r04_c3_xcd_boxes.txt) and keeps the round-robin dealing.
+// DECODER is slower with eighths on every box -- at the ten resident tiles per CU it runs with +3 ... +5 % (2.77-2.80 against
+// 2.66-2.69 ms; at 16, where it stood when the policy was made, +0.5 ... +2.4 %; profiles/r04_c3_xcd_boxes.txt) -- and keeps the
+// round-robin dealing.
 // Hence by direction and size: contiguous eighths for encodes from 6 GiB of interior tiles per plane.  (Knobs build:
 // HGI_XCD_MODE = 0 | 1 forces one for both directions.)
 inline u32 xcd_mode(const TileGrid &g, bool encode)

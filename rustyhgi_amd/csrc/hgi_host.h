@@ -30,6 +30,7 @@ struct hgi_ctx {
     uint8_t *pin;             // pinned host memory (entropy stage: histograms and stream sizes come down without stalling the host)
     size_t pin_bytes;
     int probe_resident_tiles; // -1 except inside the placement probe, whose decode launches run at a fixed occupancy (hgi_planes.hip)
+    char planes_report[384];  // what the last hgi_planes_alloc on this ctx found and did (hgi_planes_report)
 };
 
 namespace hgi {

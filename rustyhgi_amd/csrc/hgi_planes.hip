@@ -14,10 +14,13 @@
 //   * larger planes (the 512-frame C3 batch has three of 8 GiB): no single allocation of that size can be relied on to stay
 //     in one class, so a plane is COMPOSED -- physical chunks of 1 GiB (hipMemCreate) are classified one by one and mapped
 //     behind one another into one reserved address range per plane (hipMemAddressReserve / hipMemMap) such that at every
-//     offset neighbouring planes sit on chunks of different classes (round 4; alloc_composed).  The search is bounded by
+//     offset neighbouring planes sit on chunks of different classes (round 4; alloc_composed) -- on TWO SIDES (image planes on
+//     one set of classes, the grid plane spread over the others) where three classes are in reach, every plane ALTERNATING
+//     between the classes where two are all there is (hgi_lineup.h).  The search is bounded by
 //     bytes: at most 3 x the requested chunks are ever created (plus at most 96 GiB of never-mapped spacers when the driver
 //     keeps handing out one class), every pair is checked before the planes are built, everything not handed out is released.
 #include <hip/hip_runtime.h>
+#include <stdarg.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <array>
@@ -158,6 +161,22 @@ hgi_status classify(hgi_ctx *c, const Yardstick &y, std::vector<std::vector<int>
     return HGI_OK;
 }
 
+// the ctx's one-line account of its last hgi_planes_alloc (truncated, never overrun)
+struct Report {
+    char *buf;
+    size_t cap, len;
+    Report(char *b, size_t n) : buf(b), cap(n), len(0) { buf[0] = 0; }
+    void add(const char *fmt, ...) __attribute__((format(printf, 2, 3)))
+    {
+        if (len + 1 >= cap) return;
+        va_list ap;
+        va_start(ap, fmt);
+        const int w = vsnprintf(buf + len, cap - len, fmt, ap);
+        va_end(ap);
+        if (w > 0) len = len + (size_t)w < cap ? len + (size_t)w : cap - 1;
+    }
+};
+
 // ---- composed planes: bookkeeping of what hgi_planes_free has to undo ---------------------------------------------------
 struct Composed {
     void *va;
@@ -222,6 +241,9 @@ hgi_status alloc_whole(hgi_ctx *c, size_t bytes, uint32_t count, void **planes, 
         bufs.push_back(p);
     }
     auto hand_out = [&](const std::vector<int> &order) {
+        Report r(c->planes_report, sizeof c->planes_report);
+        r.add("%zu whole allocations of %zu MiB as candidates, %zu spacers; planes =", bufs.size(), bytes >> 20, spacers.size());
+        for (uint32_t i = 0; i < count; ++i) r.add(" %d", order[i]);
         std::vector<char> used(bufs.size(), 0);
         for (uint32_t i = 0; i < count; ++i) {
             planes[i] = bufs[(size_t)order[i]];
@@ -523,21 +545,23 @@ hgi_status alloc_composed(hgi_ctx *c, size_t bytes, uint32_t count, void **plane
         break;
     }
     if (!ok) lineup::fill_rest(rows, n, count, h.size());      // what did line up stays; the rest in creation order
-    if (trace) {
-        fprintf(stderr, "hgi_planes_alloc: %zu chunks created, %zu GiB of spacers, %zu groups:", h.size(), spacer_total, groups.size());
-        for (auto &g : groups) fprintf(stderr, " %zu", g.size());
-        fprintf(stderr, " -> line-up %s%s;", !ok ? "INCOMPLETE" : sided ? "complete, two sides" : "complete, per offset", two_only ? " (of the two largest groups alone)" : "");
+    {   // what was found and done, for hgi_planes_report (and the trace)
+        Report r(c->planes_report, sizeof c->planes_report);
+        r.add("%zu chunks created, %zu GiB of spacers, %zu groups:", h.size(), spacer_total, groups.size());
+        for (auto &g : groups) r.add(" %zu", g.size());
+        r.add(" -> line-up %s%s;", !ok ? "INCOMPLETE" : sided ? "complete, two sides" : "complete, per offset", two_only ? " (of the two largest groups alone)" : "");
         for (uint32_t i = 0; i < count; ++i) {      // how many chunks of which group each plane got
             std::vector<size_t> from(groups.size(), 0);
             for (size_t m = 0; m < n; ++m)
                 for (size_t g = 0; g < groups.size(); ++g)
                     for (int j : groups[g])
                         if (j == rows[m][i]) ++from[g];
-            fprintf(stderr, " plane %u =", i);
+            r.add(" plane %u =", i);
             for (size_t g = 0; g < groups.size(); ++g)
-                if (from[g]) fprintf(stderr, " %zu x g%zu", from[g], g);
-            fprintf(stderr, "%s", i + 1 < count ? "," : "\n");
+                if (from[g]) r.add(" %zu x g%zu", from[g], g);
+            if (i + 1 < count) r.add(",");
         }
+        if (trace) fprintf(stderr, "hgi_planes_alloc: %s\n", c->planes_report);
     }
     // What the probes said chunk against group representative, checked pair by pair as the planes will hold them: at every
     // chunk offset every neighbouring pair must stream at the fast rate (this is what the caller is promised).  A pair that
@@ -659,6 +683,7 @@ hgi_status hgi_planes_alloc(hgi_ctx *c, size_t bytes, uint32_t count, void **pla
     if (count == 0 || bytes == 0) return HGI_OK;
     HIP_TRY(hipSetDevice(c->device));
     const bool placing = count > 1 && !getenv("HGI_NO_PLACEMENT");
+    snprintf(c->planes_report, sizeof c->planes_report, "plain allocations (%s)", placing ? "planes below 128 MiB are not probed" : count > 1 ? "HGI_NO_PLACEMENT" : "one plane");
     if (!placing || bytes < ((size_t)128 << 20)) return alloc_plain(bytes, count, planes);
     if (bytes > kComposeAbove) return alloc_composed(c, bytes, count, planes, separated);
     // Planes of 128 MiB up to (not including) 1 GiB: a launch that reads one and writes the next (2 x 256 MiB for a lone 16384^2
@@ -675,6 +700,8 @@ hgi_status hgi_planes_alloc(hgi_ctx *c, size_t bytes, uint32_t count, void **pla
     }
     return alloc_whole(c, bytes, count, planes, separated);
 }
+
+const char *hgi_planes_report(hgi_ctx *c) { return c ? c->planes_report : ""; }
 
 hgi_status hgi_planes_free(hgi_ctx *c, uint32_t count, void **planes)
 {

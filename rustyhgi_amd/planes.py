@@ -28,6 +28,8 @@ class Planes:
         self._arr = arr
         self.pointers = [int(p or 0) for p in arr]
         self.separated = bool(sep.value)
+        # what the library found and did (hgi_planes_report; the ctx overwrites it at its next hgi_planes_alloc)
+        self.report = (_ffi.lib().hgi_planes_report(ctx.handle) or b"").decode()
 
     def torch(self, index, shape):
         """uint8 CUDA tensor viewing plane `index` (no copy; valid while this object lives)."""

@@ -1143,6 +1143,8 @@ def test_planes_larger_than_a_chunk_are_composed_and_released(H, oracle):
     planes = H.Planes(ctx, F * S * S, 3)
     assert len(set(planes.pointers)) == 3 and all(planes.pointers)
     assert torch.cuda.mem_get_info()[0] <= free0 - 3 * (chunks << 30) + (64 << 20)      # whole GiB chunks are what is held
+    # hgi_planes_report: what the call found and did -- "12 chunks created, 0 GiB of spacers, 3 groups: 4 2 6 -> line-up ..."
+    assert "chunks created" in planes.report and "line-up" in planes.report and "plane 2 =" in planes.report, planes.report
     img, grid, out = (planes.torch(i, (F, S, S)) for i in range(3))
     _ffi.check(L.hgi_synth_u8_dev(ctx.handle, _ffi.SYNTH_RAMP, SEED0 + 3, 0, S, S, img.data_ptr(), F, S * S))
     lut = oracle.linear_lut(2)[0]
