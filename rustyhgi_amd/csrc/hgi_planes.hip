@@ -477,10 +477,6 @@ hgi_status alloc_composed(hgi_ctx *c, size_t bytes, uint32_t count, void **plane
             }
         }
         ok = sided = lineup::two_sides(*from, n, count, rows, &odd_spread);
-        // A line-up that leaves a grid plane (almost) on one class costs the encoder of a large batch 3-6 % (hgi_lineup.h): more
-        // chunks, behind spacers where the driver stays in one class, usually bring another -- sometimes only at the end of the
-        // budget of three times the request (a third class after 69 chunks and 92 GiB of spacers, 1.7 s: encode 2.666 ms where the
-        // two classes found until then gave 2.732, profiles/r04_two_classes.txt).
         // The spread of a grid plane is worth what the classes under it are: two groups it is spread over must stream at the fast
         // rate against EACH OTHER as well -- checked once per pair, on their newest members (the groups were founded on one probe
         // of their first; 512 frames on a grid plane "spread" over two groups that were one class: 2.81 ms, like 8 + 0).  Groups
@@ -523,9 +519,13 @@ hgi_status alloc_composed(hgi_ctx *c, size_t bytes, uint32_t count, void **plane
             if (!merged) break;
             ok = sided = lineup::two_sides(groups, n, count, rows, &odd_spread);
         }
+        // A line-up that leaves a grid plane (almost) on one class costs the encoder of a large batch 3-6 % (hgi_lineup.h): more
+        // chunks, behind spacers where the driver stays in one class, usually bring another -- sometimes only at the end of the
+        // budget of three times the request (a third class after 69 chunks and 92 GiB of spacers, 1.7 s: encode 2.666 ms where the
+        // two classes found until then gave 2.732, profiles/r04_two_classes.txt).
         const bool searched = h.size() >= need + (size_t)HGI_KNOB(HGI_PLANES_SEARCH_PLANES, 6) * n || h.size() >= max_chunks || two_only;
         if (ok && (odd_spread * 8 >= n * 3 || n < 4 || searched)) {
-            // They did not (two classes is all the search found): PER OFFSET then -- neighbouring planes differ at every offset
+            // Where they did not (two classes is all the search found): PER OFFSET -- neighbouring planes differ at every offset
             // and every plane alternates between the classes.  Some XCDs then read class A and write B while others read B and
             // write A, which costs less than a grid plane on one class does: 512 x 4096^2, both line-ups of the same two
             // groups, encode 2.800-2.814 -> 2.724-2.735 ms, decode 2.61-2.68 -> 2.64-2.72 (profiles/r04_two_classes.txt).
@@ -683,8 +683,11 @@ hgi_status hgi_planes_alloc(hgi_ctx *c, size_t bytes, uint32_t count, void **pla
     if (count == 0 || bytes == 0) return HGI_OK;
     HIP_TRY(hipSetDevice(c->device));
     const bool placing = count > 1 && !getenv("HGI_NO_PLACEMENT");
-    snprintf(c->planes_report, sizeof c->planes_report, "plain allocations (%s)", placing ? "planes below 128 MiB are not probed" : count > 1 ? "HGI_NO_PLACEMENT" : "one plane");
-    if (!placing || bytes < ((size_t)128 << 20)) return alloc_plain(bytes, count, planes);
+    c->planes_report[0] = 0;
+    if (!placing || bytes < ((size_t)128 << 20)) {
+        snprintf(c->planes_report, sizeof c->planes_report, "plain allocations (%s)", placing ? "planes below 128 MiB are not probed" : count > 1 ? "HGI_NO_PLACEMENT" : "one plane");
+        return alloc_plain(bytes, count, planes);
+    }
     if (bytes > kComposeAbove) return alloc_composed(c, bytes, count, planes, separated);
     // Planes of 128 MiB up to (not including) 1 GiB: a launch that reads one and writes the next (2 x 256 MiB for a lone 16384^2
     // frame) no longer fits the 256 MiB Infinity Cache, so placement matters to it (16384^2 level 8: encode 101 -> 98.3 us,
@@ -696,6 +699,7 @@ hgi_status hgi_planes_alloc(hgi_ctx *c, size_t bytes, uint32_t count, void **pla
         const hgi_status st = alloc_whole(c, kGiB, count, planes, separated);
         if (st != HGI_ENOMEM) return st;
         if (separated) *separated = 0;
+        snprintf(c->planes_report, sizeof c->planes_report, "plain allocations (no room for candidates of 1 GiB)");
         return alloc_plain(bytes, count, planes);
     }
     return alloc_whole(c, bytes, count, planes, separated);
