@@ -50,6 +50,8 @@ fn main() {
                 let mut planes: [*mut c_void; 3] = [ptr::null_mut(); 3];
                 let mut separated: c_int = 0;
                 check(ffi::hgi_planes_alloc(ctx, frames * n, 3, planes.as_mut_ptr(), &mut separated), "hgi_planes_alloc");
+                let placed = std::ffi::CStr::from_ptr(ffi::hgi_planes_report(ctx)).to_string_lossy().into_owned();
+                eprintln!("device {}: {}", d, placed);
                 check(ffi::hgi_synth_u8_dev(ctx, 2, 0x4847_4930 + 3, first as u64, S, S, planes[0], frames, n), "hgi_synth_u8_dev");
                 let step = || {
                     check(ffi::hgi_encode_u8_dev(ctx, planes[0], S, S, LEVELS, ffi::HGI_INTERP_CROSSED, lut.as_ptr(), planes[1], frames, n), "encode");

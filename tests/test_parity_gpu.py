@@ -1046,10 +1046,12 @@ def test_planes_alloc_places_neighbours_in_different_regions(H, oracle):
     ctx.set_stream(torch.cuda.current_stream().cuda_stream)
     small = H.Planes(ctx, 1 << 20, 2)                      # below the probe size: plain allocations, not separated
     assert len(small.pointers) == 2 and all(small.pointers) and not small.separated
+    assert small.report.startswith("plain allocations"), small.report      # hgi_planes_report: every path says what it did
     small.close()
     F, S = 64, 4096
     planes = H.Planes(ctx, F * S * S, 3)
     assert len(set(planes.pointers)) == 3 and all(planes.pointers)
+    assert "whole allocations of 1024 MiB as candidates" in planes.report and "planes =" in planes.report, planes.report
     img, grid, out = (planes.torch(i, (F, S, S)) for i in range(3))
     assert img.data_ptr() == planes.pointers[0] and grid.data_ptr() == planes.pointers[1]
     from rustyhgi_amd import _ffi
