@@ -735,7 +735,9 @@ class Codec:
             _ffi.check(_ffi.lib().hgi_synth_u8_dev(self.ctx.handle, _ffi.SYNTH_RAMP, SEED0 + 3, 0, S, S,
                                                    allf.data_ptr(), world * fx, S * S))
         mine_in = torch.empty((fx, S, S), dtype=torch.uint8, device=dev)
-        grids, outs = self.grids[:fx], self.outs[:fx]
+        # what crosses the links lives in plain allocations (planes above 1 GiB are composed of mapped physical chunks, which a
+        # peer cannot be assumed to reach); the grid, which stays on the device, is the placed plane
+        grids, outs = self.grids[:fx], torch.empty((fx, S, S), dtype=torch.uint8, device=dev)
 
         def xstep():
             batch.scatter_frames(dist, allf, mine_in)
@@ -761,7 +763,7 @@ class Codec:
                    "transport": ("gloo through host memory, all ranks on one device: PLUMBING ONLY, not a bandwidth figure" if self.args.share_gpu
                                  else "torch.distributed scatter / gather over RCCL (xGMI)"),
                    "note": "frames scattered from and gathered to GPU 0; per-link bound, reported beside the sharded number, never as it"}
-        del allf, allo, mine_in
+        del allf, allo, mine_in, outs
         self._restore()
         return res
 
