@@ -229,3 +229,33 @@ def test_reference_held_docs_pair(oracle):
     # ... but NOT the same bytes: recorded so that nobody mistakes the PNG for a golden vector of this revision
     # (double-rounded, plain-rounded and floor predictors were all tried: none reproduces it)
     assert 0.5 < float((dec == after).mean()) < 0.95
+
+
+def test_two_restatements_agree_on_arbitrary_shapes_and_tables(oracle):
+    """The C restatement (scalar, the reference's traversal order) and the numpy one (whole-level array algebra) are two
+    structurally different readings of the same six source files: they must agree bit for bit -- here on shapes, level counts
+    (0 ... 12, deeper than the image is large), predictors and ARBITRARY 256-byte tables (any `Quantizator` a caller may
+    tabulate, src/quantizator.rs:12-15; random tables make the overflow fallback of src/encoder.rs:56-60 fire all the time)
+    drawn by hypothesis, with the encoder's in-place reconstruction and the fallback count compared as well."""
+    from hypothesis import given, settings, HealthCheck, strategies as st
+
+    @settings(max_examples=120, deadline=None, derandomize=True, suppress_health_check=list(HealthCheck))
+    @given(st.integers(1, 70), st.integers(1, 70), st.integers(0, 12), st.integers(0, 1), st.integers(0, 2**32 - 1),
+           st.sampled_from(["table", "linear", "noop", "smooth"]))
+    def check(w, h, levels, interp, seed, kind):
+        rng = np.random.default_rng(seed)
+        if kind == "smooth":      # small residuals: the quantizer's dead zone and the fallback's edge
+            base = rng.integers(0, 256)
+            img = np.clip(base + rng.integers(-6, 7, (h, w)).cumsum(axis=1) // 3, 0, 255).astype(np.uint8)
+        else:
+            img = rng.integers(0, 256, (h, w), dtype=np.uint8)
+        lut = {"table": lambda: rng.integers(0, 256, 256, dtype=np.uint8), "noop": oracle.noop_lut,
+               "linear": lambda: oracle.linear_lut(int(rng.integers(0, 4)))[0],
+               "smooth": lambda: oracle.linear_lut(int(rng.integers(1, 4)))[0]}[kind]()
+        g1, r1, f1 = oracle.encode(img, levels, lut, interp, want_rec=True)
+        g2, r2, f2 = NP.encode(img, levels, lut, interp, want_rec=True)
+        assert (g1 == g2).all() and (r1 == r2).all() and int(f1) == int(f2), (w, h, levels, interp, seed, kind)
+        d1, d2 = oracle.decode(g1, levels, interp), NP.decode(g1, levels, interp)
+        assert (d1 == d2).all() and (d1 == r1).all(), (w, h, levels, interp, seed, kind)      # the decoder reproduces the encoder's reconstruction
+
+    check()
