@@ -145,14 +145,15 @@ size_t ws_need(const hgi_ctx *c, uint32_t w, uint32_t h, uint32_t levels, size_t
 // waves per CU of 32-row tiles) ends when its slowest wave does, and that wave's chain is mostly its own VALU work:
 // 128 x 16 tiles halve the finest level's share of it (profiles/r03_sizes.txt).
 // Round 4: a PLAIN encode (the tile holds the pyramid: no seeds) keeps the 32-row tiles on large calls too, on rows up to 8 192
-// pixels and below 6 GiB per plane.  The encoder needs its 20 resident tiles per CU (fewer: -2 ... -6 %), and with 64-row tiles
+// pixels and below four GiB per plane (kEncodeEighthsFromGiB).  The encoder needs its 20 resident tiles per CU (fewer: -2 ... -6 %), and with 64-row tiles
 // those read 5.5 MB at a time per XCD -- more than its 4 MB L2; with 32-row tiles it is half (the decoder gets the same effect
 // from holding ten 64-row tiles, hgi_fused_impl.h launch_decode_fused).  Measured, one process per setting on the knobs build
 // (profiles/r04_enc_tile_rows.txt): 64 x 4096^2 level 4 356.0 -> 341.9 us (-4.0 %), 128 x -3.3 %, 256 x -2.7 %, levels 1 / 2 / 5
 // -2.6 / -3.7 / -5.6 %, 16 x 8192^2 -1.5 %, 1 / 4 x 4096^2 -9 / -6 %, 16 x 1920 x 1080 -10 %; no change at 2 and 8 x 4096^2.  Not on
-// 16384-wide rows (+7 %), not for encodes that rebuild levels in the kernel (the cone: +12 ... +19 %), and not from 6 GiB per
+// 16384-wide rows (+7 %), not for encodes that rebuild levels in the kernel (the cone: +12 ... +19 %), and not from four GiB per
 // plane, where the launch is dealt to the XCDs as contiguous eighths and the 64-row tiles stay ahead on every box sampled
-// (2.65-2.78 against 2.73-2.80 ms per 512 frames).
+// (2.65-2.78 against 2.73-2.80 ms per 512 frames; 1.329 against 1.340 ms per 256, 1.661 against 1.675 per 320, 80 x 8192^2 1.673
+// against 1.732: profiles/r04_mid_sizes.txt).
 // (Knobs build: HGI_TILE_H = 16 | 32 | 64 forces one where the pyramid fits -- the test suite runs every geometry on every
 // shape; HGI_TILE16_MAX moves the lower crossover.)
 uint32_t use_tile_rows(uint32_t w, uint32_t h, uint32_t k, size_t batch, bool encode, bool plain)
@@ -172,7 +173,9 @@ uint32_t use_tile_rows(uint32_t w, uint32_t h, uint32_t k, size_t batch, bool en
     // flight: 16 rows, at any size (64 x 4096^2: 339 -> 333 us; 512 x: 2.69 ms whatever the planes' classes, where the 64-row
     // tiles dealt as eighths give 2.64 ... 2.89; profiles/r04_pfine_sweep.txt)
     if (encode && plain && k == 1 && w <= 8192) return HGI_ENC_L1_TILE_ROWS;
-    if (encode && plain && w <= 8192 && (uint64_t)w * h * batch < ((uint64_t)6 << 30)) return 32;
+    // (the same measure as xcd_mode(): the bytes of the 64-row tiles that lie entirely inside the frames)
+    const uint64_t interior64 = (uint64_t)(w / kTileW) * (h / 64) * batch * kTileW * 64;
+    if (encode && plain && w <= 8192 && interior64 < ((uint64_t)kEncodeEighthsFromGiB << 30)) return 32;
     return 64;
 }
 

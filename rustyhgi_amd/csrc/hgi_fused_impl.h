@@ -127,7 +127,7 @@ static_assert(TH != 64 || 18 * (buf_bytes(4) + rbuf_bytes(4) + 256) <= 160 * 102
 #define HGI_XCD_MODE -1     // the XCD dealing policy (block_role): 0 contiguous eighths, 1 whole bands round-robin, -1 by size (xcd_mode())
 #endif
 #ifndef HGI_XCD_EIGHTHS_FROM_GIB
-#define HGI_XCD_EIGHTHS_FROM_GIB 6   // encodes whose interior tiles span at least this many GiB deal contiguous eighths
+#define HGI_XCD_EIGHTHS_FROM_GIB kEncodeEighthsFromGiB   // encodes whose interior tiles span at least this many GiB deal contiguous eighths
 #endif
 #ifndef HGI_DEC_REVERSE_DEFAULT
 #define HGI_DEC_REVERSE_DEFAULT 0
@@ -1999,8 +1999,11 @@ inline size_t lds_for_waves(size_t lds, int waves)
 // DECODER is slower with eighths on every box -- at the ten resident tiles per CU it runs with +3 ... +5 % (2.77-2.80 against
 // 2.66-2.69 ms; at 16, where it stood when the policy was made, +0.5 ... +2.4 %; profiles/r04_c3_xcd_boxes.txt) -- and keeps the
 // round-robin dealing.
-// Hence by direction and size: contiguous eighths for encodes from 6 GiB of interior tiles per plane.  (Knobs build:
-// HGI_XCD_MODE = 0 | 1 forces one for both directions.)
+// Hence by direction and size: contiguous eighths for encodes from FOUR GiB of interior tiles per plane (kEncodeEighthsFromGiB; six
+// until the planes' line-up spread the grid plane over two classes -- since then, against round-robin on 32-row tiles, the encoder
+// of 256 / 320 x 4096^2: 1.374 -> 1.329 / 1.722 -> 1.661 ms, 80 x 8192^2 -1.1 %, 1280 x 2048^2 -1.9 %, 20 x 16384^2 -7 %; at
+// 192 x 4096^2, three GiB, still level or behind; profiles/r04_mid_sizes.txt).  (Knobs build: HGI_XCD_MODE = 0 | 1 forces one
+// for both directions.)
 inline u32 xcd_mode(const TileGrid &g, bool encode)
 {
     const int forced = HGI_KNOB(HGI_XCD_MODE, HGI_XCD_MODE);

@@ -21,6 +21,9 @@ constexpr int kFusedMaxLevelsSmall = 5;   // ... a 32-row tile
 constexpr int kFusedMaxLevelsTiny = 4;    // ... and a 16-row tile
 constexpr int kSeededMinLevels = 4;       // a seeded launch gives each lattice point of a tile's halo frame a lane: (128 >> k) + 2 by (64 >> k) + 2 <= 64
 constexpr int kThreads = 64;  // ONE wave owns a tile: no workgroup barriers anywhere
+// A plain encode of this many GiB per plane and more is dealt to the XCDs as contiguous eighths (hgi_fused_impl.h, xcd_mode()) and
+// runs on 64-row tiles (hgi_capi.hip, use_tile_rows()); below, whole bands round-robin and 32-row tiles.  One number for both.
+constexpr int kEncodeEighthsFromGiB = 4;
 
 // 256-entry quantizer table passed BY VALUE in the kernarg segment: no device-side table to
 // keep alive, nothing to synchronise, capturable.

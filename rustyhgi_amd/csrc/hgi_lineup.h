@@ -84,7 +84,7 @@ inline size_t outside_largest(const Groups &groups, const std::vector<size_t> &q
 
 // First choice: TWO SIDES.  The groups are split into a side for the even planes (image, image') and a side for the odd ones
 // (grid) such that each side holds enough chunks.  Every plane is then spread over the groups of its side as EVENLY as the
-// supply allows (plane_quota), its chunks alternating between them: an encode of 6 GiB and more per plane is dealt to the XCDs as
+// supply allows (plane_quota), its chunks alternating between them: an encode of 4 GiB and more per plane is dealt to the XCDs as
 // contiguous eighths, i.e. eight chunks of each plane are in use at one time, and the more classes those touch the faster it
 // runs -- measured on 512 x 4096^2 with the grid plane on 8 + 0 / 7 + 1 / 6 + 2 / 4 + 4 chunks of two classes: 2.787 / 2.730 /
 // 2.670 / 2.654 ms (profiles/r04_planes_sides.txt, r04_c3_xcd_boxes.txt); how the image planes are spread does not show.  Among the

@@ -454,7 +454,7 @@ hgi_status alloc_composed(hgi_ctx *c, size_t bytes, uint32_t count, void **plane
         // Line-up (hgi_lineup.h; checked on the CPU by tests/cpp/test_lineup.cpp).  First choice: TWO SIDES -- the groups are
         // split into a side for the even planes (image, image') and a side for the odd ones (grid), so that EVERY chunk of a
         // plane differs in class from EVERY chunk of its neighbours, not only the one at the same offset.  That is what a launch
-        // dealt to the XCDs as contiguous eighths needs (hgi_fused_impl.h, xcd_mode(): from 6 GiB per plane the eight XCDs work
+        // dealt to the XCDs as contiguous eighths needs (hgi_fused_impl.h, xcd_mode(): from 4 GiB per plane the eight XCDs work
         // on eight different chunks of each plane at one time): with a per-offset line-up whose sides flip along the plane, one
         // XCD reads class A and writes B while another reads B and writes A (profiles/r04_planes_sides.txt).
         const lineup::Groups *from = &groups;

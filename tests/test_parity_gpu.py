@@ -777,7 +777,7 @@ def test_forced_code_paths_in_a_child_process(mode):
     shape-heavy parity cases with one of those choices forced: aligned shapes through the checked path, small shapes through
     64-row tiles, large ones through 32-row and (pyramids up to four levels) 16-row tiles, the decoder walking its tile list
     backwards, large host frames without bands, every launch dealt to the XCDs as contiguous eighths (what only encodes of
-    6 GiB and more per plane get otherwise).  Pyramids of six to eight levels run as ONE launch that rebuilds the levels
+    4 GiB and more per plane get otherwise).  Pyramids of six to eight levels run as ONE launch that rebuilds the levels
     above a four-level tile for itself (the cone) -- on every tile height; deeper ones code the stride-256 lattice first -- in
     the one-workgroup lattice kernel, or, for planes beyond 8 192 points (here: HGI_NO_LATTICE_KERNEL), by host recursion:
     gather, encode, decode -- and start the cone from its planes.  The bytes must not depend on any of it."""
@@ -1080,9 +1080,9 @@ def test_planes_alloc_places_neighbours_in_different_regions(H, oracle):
 
 def test_literal_c3_batch_on_one_gpu(H, oracle, golden):
     """BASELINE configs[3] as it is written -- 512 independent 4096 x 4096 frames, level 4, Medium -- in ONE call per direction
-    on one GPU (24 GiB of planes from hgi_planes_alloc, composed of 1 GiB chunks).  This is the only size at which the encoder's
-    launch is dealt to the XCDs as contiguous eighths (>= 6 GiB of interior tiles per plane, hgi_fused_impl.h xcd_mode()) and at
-    which 32-bit tile counts pass a million.  Frames from all over the batch -- on both sides of chunk and eighth boundaries --
+    on one GPU (24 GiB of planes from hgi_planes_alloc, composed of 1 GiB chunks).  Its encoder's launch is dealt to the XCDs as contiguous eighths (>= 4 GiB of interior tiles per plane, hgi_fused_impl.h
+    xcd_mode(); the 256-frame child of test_composed_planes_where_the_search_finds_two_classes_only is the other such size in the
+    suite) and its 32-bit tile counts pass a million.  Frames from all over the batch -- on both sides of chunk and eighth boundaries --
     are compared bit for bit with the oracle, the committed golden hashes of frames 0 and 511 must match, and the
     reconstruction error of EVERY frame must stay within the quantizer's bound (hgi_diff_stats_dev over the whole batch)."""
     import hashlib
